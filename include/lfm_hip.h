@@ -1,0 +1,189 @@
+/*
+ * lfm_hip.h -- C ABI of liblfm_hip.so: the MI355X (gfx950) replacement for
+ * LightFM's native extension `lightfm._lightfm_fast`.
+ *
+ * Every entry point names the reference interface it replaces
+ *   PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
+ *   LFM = /root/reference/lightfm/lightfm.py
+ * and is what a ctypes/cffi binding inside the reference's lightfm/_lightfm_fast.py
+ * would bind.  Plain pointers and sizes only; all buffers
+ * are HOST buffers owned by the caller (numpy arrays in the reference), exactly
+ * like the typed memoryviews the Cython functions take.  Weights are updated in
+ * place (one-shot calls) or kept device-resident between calls (session API).
+ *
+ * All functions return 0 on success and a negative LFM_E* code on failure;
+ * lfm_last_error() returns a thread-local description.  There is no CPU
+ * fallback: without a usable HIP device every compute call fails with
+ * LFM_ENODEV.
+ */
+#ifndef LFM_HIP_H
+#define LFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFM_OK 0
+#define LFM_EINVAL (-1)   /* bad argument (the reference would raise ValueError) */
+#define LFM_ENODEV (-2)   /* no HIP device / HIP runtime failure */
+#define LFM_ENOMEM (-3)   /* device or host allocation failed */
+#define LFM_ECOMM (-4)    /* RCCL failure */
+#define LFM_EUNSUPPORTED (-5)
+
+/* CSRMatrix (PYX:145-182): int32 indices/indptr, float32 data, C-contiguous. */
+typedef struct lfm_csr {
+    const int32_t *indices;
+    const int32_t *indptr;
+    const float *data;
+    int32_t rows, cols;
+    int64_t nnz;
+} lfm_csr;
+
+/* FastLightFM (PYX:185-259): the 12 weight arrays in constructor order plus the
+ * hyper-parameters.  *_W/_G/_M are [n_feat, d] row-major float32, *_b/_bG/_bM
+ * are [n_feat].  lr/rho/eps are float32 exactly as the reference stores them. */
+typedef struct lfm_model {
+    float *item_W, *item_G, *item_M, *item_b, *item_bG, *item_bM;
+    float *user_W, *user_G, *user_M, *user_b, *user_bG, *user_bM;
+    int32_t n_item_feat, n_user_feat;
+    int32_t d;        /* no_components */
+    int32_t adadelta; /* 0 = adagrad, 1 = adadelta */
+    float lr, rho, eps;
+    int32_t max_sampled;
+    double item_scale, user_scale; /* always 1.0 between calls (PYX:674-675) */
+} lfm_model;
+
+/* Execution modes (not part of the reference's Python API). */
+#define LFM_MODE_PARALLEL 0 /* Hogwild over thousands of wavefronts; one PRNG stream per
+                               shuffled position (seed = f(seeds[0], position))        */
+#define LFM_MODE_SERIAL 1   /* ONE wavefront walks the shuffled list in order with the
+                               reference's per-thread rand_r streams: reproduces the
+                               reference (num_threads = n_seeds run back to back)
+                               bit for bit; for parity tests                           */
+
+typedef struct lfm_opts {
+    int32_t mode;               /* LFM_MODE_* */
+    int32_t launches_per_epoch; /* parallel mode: kernel launches per epoch (a launch
+                                   boundary is a device-wide release/acquire); 0 = auto */
+    int32_t first_batch;        /* negatives scored speculatively in the first batch; 0 = auto */
+    int32_t reserved;
+    int32_t *neg_log;           /* host [n] or NULL: chosen negative per shuffled position, -1 = none */
+    int32_t *sampled_log;       /* host [n] or NULL: draws consumed per shuffled position */
+    int64_t counters[4];        /* out: positives visited, draws, updates, in_positives probes */
+    float kernel_ms;            /* out: device time of the epoch's kernels (HIP events)   */
+} lfm_opts;
+
+#define LFM_LOSS_LOGISTIC 0
+#define LFM_LOSS_WARP 1
+#define LFM_LOSS_BPR 2
+#define LFM_LOSS_WARP_KOS 3
+
+const char *lfm_last_error(void);
+int lfm_device_count(void);
+/* name (<=255 chars) and CU count of a device; used by bench.py */
+int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------
+ * One-shot epoch drivers: upload, run ONE epoch on device 0, download.
+ * Drop-in for the Cython functions of the same name; `seeds` is
+ * random_state.randint(0, INT32_MAX, size=num_threads).astype(uint32)
+ * (PYX:812-814) drawn by the caller so its RandomState advances identically.
+ * `opts` may be NULL (parallel mode, defaults).
+ * ------------------------------------------------------------------------ */
+
+/* fit_warp, PYX:784-912 (call site LFM:695-711) */
+int lfm_fit_warp(const lfm_csr *item_features, const lfm_csr *user_features,
+                 const lfm_csr *interactions, const int32_t *user_ids, const int32_t *item_ids,
+                 const float *Y, const float *sample_weight, const int32_t *shuffle_indices,
+                 int64_t n, lfm_model *model, double item_alpha, double user_alpha,
+                 const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts);
+
+/* fit_bpr, PYX:1074-1182 (LFM:713-728) */
+int lfm_fit_bpr(const lfm_csr *item_features, const lfm_csr *user_features,
+                const lfm_csr *interactions, const int32_t *user_ids, const int32_t *item_ids,
+                const float *Y, const float *sample_weight, const int32_t *shuffle_indices,
+                int64_t n, lfm_model *model, double item_alpha, double user_alpha,
+                const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts);
+
+/* fit_logistic, PYX:694-781 (LFM:746-759) */
+int lfm_fit_logistic(const lfm_csr *item_features, const lfm_csr *user_features,
+                     const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                     const float *sample_weight, const int32_t *shuffle_indices, int64_t n,
+                     lfm_model *model, double item_alpha, double user_alpha, lfm_opts *opts);
+
+/* fit_warp_kos, PYX:915-1071 (LFM:730-744) */
+int lfm_fit_warp_kos(const lfm_csr *item_features, const lfm_csr *user_features,
+                     const lfm_csr *data, const int32_t *user_ids,
+                     const int32_t *shuffle_indices, int64_t n, lfm_model *model,
+                     double item_alpha, double user_alpha, int32_t k, int32_t n_positives,
+                     const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts);
+
+/* predict_lightfm, PYX:1185-1229 (LFM:862-870): predictions[i] for pairs */
+int lfm_predict(const lfm_csr *item_features, const lfm_csr *user_features,
+                const int32_t *user_ids, const int32_t *item_ids, float *predictions, int64_t n,
+                const lfm_model *model);
+
+/* predict_ranks, PYX:1232-1323 (LFM:979-987): ranks[] += count, in place */
+int lfm_predict_ranks(const lfm_csr *item_features, const lfm_csr *user_features,
+                      const lfm_csr *test_interactions, const lfm_csr *train_interactions,
+                      float *ranks, const lfm_model *model);
+
+/* calculate_auc_from_rank, PYX:1326-1376 (evaluation.py:247-249).  rank_data is
+ * sorted in place per row exactly like the reference. */
+int lfm_auc_from_rank(const lfm_csr *ranks, const int32_t *num_train_positives, float *rank_data,
+                      float *auc);
+
+/* __test_in_positives, PYX:1380-1385 (tests/test_fast_functions.py:9-17); 1/0 or <0 */
+int lfm_in_positives(int32_t row, int32_t col, const lfm_csr *mat);
+
+/* ------------------------------------------------------------------------
+ * Device-resident session: what LightFM.fit_partial's epoch loop (LFM:654-664)
+ * uses so weights/CSR/COO are uploaded once per fit_partial, not once per epoch.
+ * ------------------------------------------------------------------------ */
+typedef struct lfm_session lfm_session;
+
+/* Uploads the model and both feature matrices to `device`. */
+int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
+                       const lfm_csr *item_features, const lfm_csr *user_features);
+/* Uploads the training COO (+ positives lookup CSR; NULL for logistic).  Y and
+ * sample_weight may alias (LFM:412-415).  item_ids/Y/sample_weight NULL for k-OS. */
+int lfm_session_set_interactions(lfm_session *s, const lfm_csr *positives,
+                                 const int32_t *user_ids, const int32_t *item_ids,
+                                 const float *Y, const float *sample_weight, int64_t n);
+/* Shuffle slots: device copies of shuffle index arrays (slot 0 is the default). */
+int lfm_session_upload_shuffle(lfm_session *s, int32_t slot, const int32_t *shuffle, int64_t n);
+/* One epoch with the shuffle held in `slot`. */
+int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, double item_alpha,
+                      double user_alpha, int32_t k, int32_t n_positives, const uint32_t *seeds,
+                      int32_t n_seeds, lfm_opts *opts);
+/* 1 if every item/user embedding and bias is finite (LFM:447-464), else 0. */
+int lfm_session_check_finite(lfm_session *s);
+/* Pairwise predictions with the resident weights (ids are host arrays). */
+int lfm_session_predict(lfm_session *s, const int32_t *user_ids, const int32_t *item_ids,
+                        float *predictions, int64_t n);
+int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, const lfm_csr *train,
+                              float *ranks);
+/* Copies the 12 arrays back into the caller's buffers. */
+int lfm_session_sync_to_host(lfm_session *s, lfm_model *model);
+int lfm_session_destroy(lfm_session *s);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU (no reference counterpart): one process per GPU,
+ * interactions sharded by user; after every epoch the replicated item-side
+ * tables are merged with an RCCL all-reduce of their per-epoch deltas.
+ * ------------------------------------------------------------------------ */
+#define LFM_UNIQUE_ID_BYTES 128
+int lfm_comm_unique_id(char id[LFM_UNIQUE_ID_BYTES]);
+int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID_BYTES], int32_t rank,
+                          int32_t nranks);
+/* Merge user-side tables too (rows are disjoint across ranks with identity user
+ * features, so this is an exact union); call once before sync_to_host. */
+int lfm_session_comm_merge_users(lfm_session *s);
+int lfm_session_comm_barrier(lfm_session *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFM_HIP_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of liblfm_hip.so (C ABI: include/lfm_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing, or no HIP
+device is usable, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "liblfm_hip.so")
+
+F32P = C.POINTER(C.c_float)
+I32P = C.POINTER(C.c_int32)
+U32P = C.POINTER(C.c_uint32)
+
+LOSS_IDS = {"logistic": 0, "warp": 1, "bpr": 2, "warp-kos": 3}
+MODE_PARALLEL, MODE_SERIAL = 0, 1
+UNIQUE_ID_BYTES = 128
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+class LfmCSR(C.Structure):
+    _fields_ = [("indices", I32P), ("indptr", I32P), ("data", F32P),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int64)]
+
+
+MODEL_ARRAYS = ("item_W", "item_G", "item_M", "item_b", "item_bG", "item_bM",
+                "user_W", "user_G", "user_M", "user_b", "user_bG", "user_bM")
+
+
+class LfmModel(C.Structure):
+    _fields_ = ([(n, F32P) for n in MODEL_ARRAYS] + [
+        ("n_item_feat", C.c_int32), ("n_user_feat", C.c_int32), ("d", C.c_int32),
+        ("adadelta", C.c_int32), ("lr", C.c_float), ("rho", C.c_float), ("eps", C.c_float),
+        ("max_sampled", C.c_int32), ("item_scale", C.c_double), ("user_scale", C.c_double)])
+
+
+class LfmOpts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("launches_per_epoch", C.c_int32),
+                ("first_batch", C.c_int32), ("reserved", C.c_int32),
+                ("neg_log", I32P), ("sampled_log", I32P),
+                ("counters", C.c_int64 * 4), ("kernel_ms", C.c_float)]
+
+
+# every symbol include/lfm_hip.h declares (tests check the .so exports them all)
+EXPORTS = (
+    "lfm_last_error", "lfm_device_count", "lfm_device_info",
+    "lfm_fit_warp", "lfm_fit_bpr", "lfm_fit_logistic", "lfm_fit_warp_kos",
+    "lfm_predict", "lfm_predict_ranks", "lfm_auc_from_rank", "lfm_in_positives",
+    "lfm_session_create", "lfm_session_set_interactions", "lfm_session_upload_shuffle",
+    "lfm_session_epoch", "lfm_session_check_finite", "lfm_session_predict",
+    "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_destroy",
+    "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge_users",
+    "lfm_session_comm_barrier",
+)
+
+_lib = None
+
+
+def lib():
+    """Loads liblfm_hip.so; raises HipBackendError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                "%s not found: build it with `python -m lightfm_amd.build` "
+                "(the HIP backend has no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.lfm_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if name != "lfm_last_error":
+                getattr(l, name).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    """Maps LFM_E* codes to the exception types the reference raises."""
+    if rc >= 0:
+        return rc
+    msg = lib().lfm_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -3:
+        raise MemoryError(msg)
+    if rc == -5:
+        raise NotImplementedError(msg)
+    raise HipBackendError(msg)
+
+
+def f32p(a):
+    return a.ctypes.data_as(F32P) if a is not None else None
+
+
+def i32p(a):
+    return a.ctypes.data_as(I32P) if a is not None else None
+
+
+def u32p(a):
+    return a.ctypes.data_as(U32P) if a is not None else None
+
+
+def require(a, dtype, ndim, name):
+    """The typed-memoryview contract of the Cython signatures (`flt[::1]`, `int[::1]`)."""
+    if not isinstance(a, np.ndarray):
+        raise TypeError("%s must be a numpy array" % name)
+    if a.dtype != dtype:
+        raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s' (%s)"
+                         % (np.dtype(dtype).name, a.dtype.name, name))
+    if a.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d) (%s)"
+                         % (ndim, a.ndim, name))
+    if not a.flags.c_contiguous:
+        raise ValueError("ndarray is not C-contiguous (%s)" % name)
+    return a
+
+
+def device_count():
+    return lib().lfm_device_count()
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cus = C.c_int32()
+    mem = C.c_int64()
+    check(lib().lfm_device_info(device, name, C.byref(cus), C.byref(mem)))
+    return name.value.decode(), cus.value, mem.value

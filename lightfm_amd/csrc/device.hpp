@@ -1,0 +1,456 @@
+// device.hpp -- gfx950 device-side building blocks shared by the epoch kernels.
+//
+// Work mapping (wave64): ONE wavefront owns one interaction at a time.  Lane l
+// owns embedding components c = l, l+64, ... (NC = ceil(d/64) registers), so a
+// feature row is a coalesced read, and -- because Adagrad/Adadelta are strictly
+// per-coordinate (PYX:416-449) -- every lane read-modify-writes only its own
+// column: no intra-wave conflicts.  Control flow (sampling loop, in_positives,
+// feature loops) is wave-uniform.
+//
+// The float32 summation ORDER of the reference (PYX:287-334) is kept: the
+// representations of the user and of every candidate item are staged in a
+// wave-private LDS tile and lane r computes the whole sequential dot product of
+// tile row r, so up to 16 candidate scores cost one 64..d-step pass.
+//
+// PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lfm {
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr double MAX_REG_SCALE = 1000000.0;  // PYX:19
+constexpr double MAX_LOSS = 10.0;            // PYX:817
+
+struct DCsr {
+    const int32_t *indices;
+    const int32_t *indptr;
+    const float *data;
+    int32_t rows, cols;
+    int32_t identity;  // 1: indptr[i]=i, indices[i]=i, data[i]=1 (host-verified) -> no CSR reads
+};
+
+// side 0 = item, 1 = user
+struct DModel {
+    float *W[2], *G[2], *M[2], *b[2], *bG[2], *bM[2];
+    int32_t n_feat[2];
+    int32_t d;
+    int32_t adadelta;
+    float lr, rho, eps;
+    int32_t max_sampled;
+    double *scales;  // device [2]: item_scale, user_scale (PYX:214-215)
+};
+
+struct FitArgs {
+    DCsr itf, usf, pos;
+    DModel m;
+    const int32_t *user_ids, *item_ids;
+    const float *Y, *weight;
+    const int32_t *shuffle;
+    int64_t n;           // all examples (BPR modulo, PYX:1124)
+    int64_t begin, end;  // shuffled positions of this launch
+    double item_alpha, user_alpha;
+    const uint32_t *seeds;
+    int32_t seed_idx;      // serial mode: which per-thread stream this launch continues
+    const double *logtab;  // [max_sampled+1] log term of the WARP loss, host libm
+    int32_t serial;
+    int32_t tile_rows, tile_stride, first_batch;
+    int32_t k, n_pos;      // k-OS
+    int32_t pair_cap;      // k-OS: LDS pair slots per wave
+    int32_t *neg_log, *sampled_log;
+    unsigned long long *counters;  // [4]
+    double *scale_prod;            // [2] parallel mode: product of (1+alpha*avg_lr) of this launch
+};
+
+// ------------------------------------------------------------------ lanes ---
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float unif(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ int read_lane(int v, int l)
+{
+    return __builtin_amdgcn_readlane(v, uni(l));
+}
+__device__ __forceinline__ float read_lanef(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), uni(l)));
+}
+__device__ __forceinline__ double read_laned(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), uni(l));
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), uni(l));
+    return __hiloint2double(hi, lo);
+}
+// LDS traffic between lanes of ONE wave: LDS ops of a wave execute in order, so a
+// compiler-level barrier is all that is needed.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------- PRNG ---
+
+// PYX:64-76
+__device__ __forceinline__ uint32_t temper(uint32_t x)
+{
+    x ^= x >> 11;
+    x ^= (x << 7) & 0x9D2C5680u;
+    x ^= (x << 15) & 0xEFC60000u;
+    x ^= x >> 18;
+    return x;
+}
+// PYX:79-81: seed = seed*1103515245+12345; return temper(seed)/2
+__device__ __forceinline__ uint32_t lcg(uint32_t s) { return s * 1103515245u + 12345u; }
+__device__ __forceinline__ uint32_t draw(uint32_t s) { return temper(s) >> 1; }
+
+// Parallel mode: stream owned by shuffled position i (same rule as
+// oracle/lfm_oracle.c:orc_position_seed).
+__device__ __forceinline__ uint32_t position_seed(uint32_t base, uint64_t i)
+{
+    uint32_t h = base + (uint32_t)i * 0x9E3779B9u + (uint32_t)(i >> 32) * 0x85EBCA6Bu;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// ---------------------------------------------------------- table access ---
+
+// Embedding tables are written concurrently by other CUs; read them past the
+// (never-refreshed) per-CU L1 with agent-scope relaxed loads (global_load sc1).
+__device__ __forceinline__ float ldw(const float *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// PYX:270-284 as a 64-ary search: each round the wave probes 64 evenly spaced
+// entries of the sorted row, so rows up to 4096 long need 2 dependent loads.
+__device__ __forceinline__ bool in_positives(const DCsr &p, int item, int user, int lane)
+{
+    int lo = uni(p.indptr[user]), hi = uni(p.indptr[user + 1]);
+    while (hi - lo > WAVE) {
+        int step = (hi - lo + WAVE - 1) >> 6;
+        int idx = lo + lane * step;
+        bool ok = idx < hi;
+        int v = ok ? p.indices[idx] : 0x7fffffff;
+        unsigned long long m = __ballot(ok && v <= item);
+        int cnt = __popcll(m);
+        if (cnt == 0) return false;
+        lo = lo + (cnt - 1) * step;
+        hi = min(hi, lo + step);
+    }
+    int idx = lo + lane;
+    bool hit = (idx < hi) && (p.indices[idx] == item);
+    return __ballot(hit) != 0ull;
+}
+
+template <int NC>
+struct Rep {
+    float v[NC];  // component lane+64q
+    float bias;   // wave-uniform
+};
+
+// compute_representation, PYX:287-317 (w = (float)((double)data*scale), C_OMP:4896;
+// float32 multiply then add, features in CSR order).
+template <int NC>
+__device__ __forceinline__ void load_rep(const DCsr &f, const float *W, const float *b, int d,
+                                         int row, double scale, int lane, Rep<NC> &r)
+{
+    if (f.identity) {
+        float w = (float)(1.0 * scale);
+        const float *wr = W + (size_t)row * d;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            int c = lane + WAVE * q;
+            float x = (c < d) ? ldw(wr + c) : 0.0f;
+            r.v[q] = __fadd_rn(0.0f, __fmul_rn(w, x));
+        }
+        r.bias = __fadd_rn(0.0f, __fmul_rn(w, ldw(b + row)));
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) r.v[q] = 0.0f;
+    r.bias = 0.0f;
+    int s = uni(f.indptr[row]), e = uni(f.indptr[row + 1]);
+    for (int k = s; k < e; ++k) {
+        int feat = uni(f.indices[k]);
+        float w = (float)((double)unif(f.data[k]) * scale);
+        const float *wr = W + (size_t)feat * d;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            int c = lane + WAVE * q;
+            float x = (c < d) ? ldw(wr + c) : 0.0f;
+            r.v[q] = __fadd_rn(r.v[q], __fmul_rn(w, x));
+        }
+        r.bias = __fadd_rn(r.bias, __fmul_rn(w, ldw(b + feat)));
+    }
+}
+
+template <int NC>
+__device__ __forceinline__ void rep_to_tile(float *trow, const Rep<NC> &r, int d, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        int c = lane + WAVE * q;
+        if (c < d) trow[c] = r.v[q];
+    }
+    if (lane == 0) trow[d] = r.bias;
+}
+
+template <int NC>
+__device__ __forceinline__ void rep_from_tile(const float *trow, int d, int lane, Rep<NC> &r)
+{
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        int c = lane + WAVE * q;
+        r.v[q] = (c < d) ? trow[c] : 0.0f;
+    }
+    r.bias = trow[d];
+}
+
+// compute_prediction_from_repr, PYX:320-334: sequential float32 sum starting
+// from the two biases.  One lane walks one tile row.
+__device__ __forceinline__ float tile_dot(const float *u, const float *v, int d)
+{
+    float acc = __fadd_rn(u[d], v[d]);
+    int c = 0;
+    if ((d & 3) == 0) {
+        for (; c < d; c += 4) {
+            float4 a = *reinterpret_cast<const float4 *>(u + c);
+            float4 x = *reinterpret_cast<const float4 *>(v + c);
+            acc = __fadd_rn(acc, __fmul_rn(a.x, x.x));
+            acc = __fadd_rn(acc, __fmul_rn(a.y, x.y));
+            acc = __fadd_rn(acc, __fmul_rn(a.z, x.z));
+            acc = __fadd_rn(acc, __fmul_rn(a.w, x.w));
+        }
+    } else {
+        for (; c < d; ++c) acc = __fadd_rn(acc, __fmul_rn(u[c], v[c]));
+    }
+    return acc;
+}
+
+// PYX:262-267
+__device__ __forceinline__ float sigmoidf_ref(float v)
+{
+    return (float)(1.0 / (1.0 + exp(-(double)v)));
+}
+
+// ------------------------------------------------------------ optimizer ---
+
+struct Hyper {
+    int adadelta;
+    float lr, rho, eps;
+};
+
+// One optimizer cell: PYX:416-449 with the float64 promotions of C_OMP:5340-5560.
+// `atomic`: publish new-old with global_atomic_add_f32 (exactly the new value when
+// nobody else touched the cell); otherwise plain stores (serial mode).
+__device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, double w, double g,
+                                              const Hyper &h, double alpha, bool atomic)
+{
+    float oW = ldw(Wp), oG = ldw(Gp);
+    float nW, nG;
+    double lr;
+    if (h.adadelta) {
+        float oM = ldw(Mp);
+        float rg = __fmul_rn(h.rho, oG);
+        double wg = w * g;
+        nG = (float)((double)rg + (1.0 - (double)h.rho) * (wg * wg));
+        float me = __fadd_rn(oM, h.eps), ge = __fadd_rn(nG, h.eps);
+        lr = sqrt((double)me) / sqrt((double)ge);
+        double upd = (lr * g) * w;
+        float rm = __fmul_rn(h.rho, oM);
+        float nM = (float)((double)rm + (1.0 - (double)h.rho) * (upd * upd));
+        nW = (float)((double)oW - upd);
+        if (atomic) {
+            float dM = __fsub_rn(nM, oM);
+            if (dM != 0.0f) atomicAdd(Mp, dM);
+        } else {
+            *Mp = nM;
+        }
+    } else {
+        lr = (double)h.lr / sqrt((double)oG);
+        nW = (float)((double)oW - (lr * w) * g);
+        double gw = g * w;
+        nG = (float)((double)oG + gw * gw);
+    }
+    nW = (float)((double)nW * (1.0 + alpha * lr));
+    if (atomic) {
+        float dW = __fsub_rn(nW, oW), dG = __fsub_rn(nG, oG);
+        if (dW != 0.0f) atomicAdd(Wp, dW);
+        if (dG != 0.0f) atomicAdd(Gp, dG);
+    } else {
+        *Wp = nW;
+        *Gp = nG;
+    }
+    return lr;
+}
+
+// Learning rates summed the way the reference sums them (PYX:571-638): one
+// partial per (row, coordinate) and per row's biases.
+template <int NC>
+struct LrSums {
+    double bias[3];
+    double comp[3][NC];
+};
+
+// update_biases + update_features for ONE row of a feature matrix (PYX:337-451).
+// x[q] is the per-lane factor of the gradient: g = gcoef * (double)x[q].
+template <int NC>
+__device__ __forceinline__ void update_row(const DCsr &f, int row, int side, const DModel &m,
+                                           const float (&x)[NC], double gcoef, double gbias,
+                                           double alpha, bool atomic, int lane, double &lr_bias,
+                                           double (&lr_comp)[NC])
+{
+    const Hyper h{m.adadelta, m.lr, m.rho, m.eps};
+    const int d = m.d;
+    int s, e;
+    if (f.identity) { s = row; e = row + 1; }
+    else { s = uni(f.indptr[row]); e = uni(f.indptr[row + 1]); }
+    lr_bias = 0.0;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) lr_comp[q] = 0.0;
+    // biases first (PYX:571-599)
+    for (int k = s; k < e; ++k) {
+        int feat = f.identity ? k : uni(f.indices[k]);
+        double w = f.identity ? 1.0 : (double)unif(f.data[k]);
+        double lr = 0.0;
+        if (lane == 0)
+            lr = cell_update(m.b[side] + feat, m.bG[side] + feat, m.bM[side] + feat, w, gbias, h,
+                             alpha, atomic);
+        lr_bias += read_laned(lr, 0);
+    }
+    // then every coordinate (PYX:602-638); lane owns its coordinates
+    for (int k = s; k < e; ++k) {
+        int feat = f.identity ? k : uni(f.indices[k]);
+        double w = f.identity ? 1.0 : (double)unif(f.data[k]);
+        size_t base = (size_t)feat * d;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            int c = lane + WAVE * q;
+            if (c < d) {
+                double g = gcoef * (double)x[q];
+                lr_comp[q] += cell_update(m.W[side] + base + c, m.G[side] + base + c,
+                                          m.M[side] + base + c, w, g, h, alpha, atomic);
+            }
+        }
+    }
+}
+
+// Ordered (reference order) or tree sum of the learning-rate partials -> the
+// avg_learning_rate of PYX:640-649 before the division.
+template <int NC, int NROWS>
+__device__ __forceinline__ double sum_lr(const double (&lr_bias)[3], const double (&lr_comp)[3][NC],
+                                         int d, bool ordered, int lane)
+{
+    if (!ordered) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < NROWS; ++r)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) t += lr_comp[r][q];
+        t = wave_sum(t);
+#pragma unroll
+        for (int r = 0; r < NROWS; ++r) t += lr_bias[r];
+        return t;
+    }
+    double avg = 0.0;
+    for (int r = 0; r < NROWS; ++r) avg += lr_bias[r];
+    for (int c = 0; c < d; ++c) {
+        int q = c >> 6, l = c & 63;
+        for (int r = 0; r < NROWS; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < NC; ++qq)
+                if (qq == q) v = lr_comp[r][qq];
+            avg += read_laned(v, l);
+        }
+    }
+    return avg;
+}
+
+__device__ __forceinline__ int row_len(const DCsr &f, int row)
+{
+    return f.identity ? 1 : (f.indptr[row + 1] - f.indptr[row]);
+}
+
+struct Scales {
+    double item, user;    // scales used when computing representations
+    double prod_i, prod_u;  // parallel mode: this wave's pending (1+alpha*avg) factors
+};
+
+__device__ __forceinline__ void apply_scale_step(Scales &sc, double avg, double ia, double ua,
+                                                 bool serial)
+{
+    if (ia == 0.0 && ua == 0.0) return;  // exact no-op in the reference (scale *= 1.0)
+    if (serial) {
+        sc.item *= (1.0 + ia * avg);
+        sc.user *= (1.0 + ua * avg);
+    } else {
+        sc.prod_i *= (1.0 + ia * avg);
+        sc.prod_u *= (1.0 + ua * avg);
+    }
+}
+
+// warp_update, PYX:537-649: positive item row (g = -loss*u), negative item row
+// (g = +loss*u), user row (g = loss*(neg - pos), float32 subtraction).
+template <int NC>
+__device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int user, int pos,
+                                            int neg, const Rep<NC> &U, const Rep<NC> &P,
+                                            const Rep<NC> &N, Scales &sc, int lane)
+{
+    const bool atomic = !a.serial;
+    double lrb[3], lrc[3][NC];
+    float diff[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(N.v[q], P.v[q]);
+    // Every address sees its read-modify-writes in the reference's order: a lane keeps
+    // pos -> neg -> user for its coordinates, lane 0 does the same for the bias cells.
+    update_row<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+    update_row<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
+    update_row<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
+    if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
+        double avg = sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
+        int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
+        avg /= (double)cells;
+        apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
+    }
+}
+
+// update, PYX:454-534 (logistic): item row g = loss*u, user row g = loss*item.
+template <int NC>
+__device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int user, int item,
+                                            const Rep<NC> &U, const Rep<NC> &I, Scales &sc, int lane)
+{
+    const bool atomic = !a.serial;
+    double lrb[3] = {0.0, 0.0, 0.0}, lrc[3][NC];
+    update_row<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+    update_row<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
+    if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
+        double avg = sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
+        int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
+        avg /= (double)cells;
+        apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
+    }
+}
+
+}  // namespace lfm

@@ -1,0 +1,38 @@
+// kernels.hpp -- host-callable launchers implemented in the .hip files.
+#pragma once
+#include <algorithm>
+#include "device.hpp"
+
+namespace lfm {
+
+struct PredictArgs {
+    DCsr itf, usf;
+    DModel m;
+    const int32_t *uids, *iids;
+    float *out;
+    int64_t n;
+    int32_t tile_rows, tile_stride;
+};
+
+struct RanksArgs {
+    const float *user_rep;  // [n_test_users_rows, rs] dense representations (bias at [d])
+    const float *item_rep;  // [n_items, rs]
+    int32_t rs, d;
+    DCsr test, train;
+    float *ranks;           // aligned with test.data
+};
+
+hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st);
+hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
+hipError_t launch_regularize(const DModel &m, int force, hipStream_t st);
+hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);
+
+hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st);
+// dense representation table of every row of f (PYX:287-317), out[row*rs + 0..d]
+hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs,
+                           float *out, hipStream_t st);
+hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
+hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
+                      float *auc, hipStream_t st);
+
+}  // namespace lfm

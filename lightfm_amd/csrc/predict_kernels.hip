@@ -1,0 +1,210 @@
+// predict_kernels.hip -- scoring / evaluation kernels.
+//
+// predict_lightfm          PYX:1185-1229
+// predict_ranks            PYX:1232-1323
+// calculate_auc_from_rank  PYX:1326-1376
+// All scores use the reference's sequential float32 summation order, so ranks
+// (integer counts of score comparisons) are bit-identical.
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace lfm {
+
+// One wavefront scores tile_rows/2 (user, item) pairs per pass.
+template <int NC>
+__global__ __launch_bounds__(256) void predict_kernel(PredictArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), wib = threadIdx.x >> 6, d = a.m.d, TS = a.tile_stride;
+    float *tile = smem + (size_t)wib * a.tile_rows * TS;
+    const int PP = a.tile_rows / 2;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wib;
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t i0 = gw * PP; i0 < a.n; i0 += nw * PP) {
+        int np_ = (int)min((int64_t)PP, a.n - i0);
+        for (int p = 0; p < np_; ++p) {
+            int user = uni(a.uids[i0 + p]), item = uni(a.iids[i0 + p]);
+            Rep<NC> U, I;
+            load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, 1.0, lane, U);
+            load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, item, 1.0, lane, I);
+            rep_to_tile<NC>(tile + (size_t)(2 * p) * TS, U, d, lane);
+            rep_to_tile<NC>(tile + (size_t)(2 * p + 1) * TS, I, d, lane);
+        }
+        wave_sync();
+        if (lane < np_)
+            a.out[i0 + lane] = tile_dot(tile + (size_t)(2 * lane) * TS, tile + (size_t)(2 * lane + 1) * TS, d);
+        wave_sync();
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void rep_rows_kernel(DCsr f, const float *W, const float *b, int d,
+                                                       int rs, float *out)
+{
+    const int lane = lane_id();
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t row = gw; row < f.rows; row += nw) {
+        Rep<NC> r;
+        load_rep<NC>(f, W, b, d, (int)row, 1.0, lane, r);
+        float *o = out + (size_t)row * rs;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            int c = lane + WAVE * q;
+            if (c < d) o[c] = r.v[q];
+        }
+        if (lane == 0) o[d] = r.bias;
+    }
+}
+
+__device__ __forceinline__ float dense_dot(const float *u, const float *v, int d)
+{
+    float acc = __fadd_rn(u[d], v[d]);
+    for (int c = 0; c < d; ++c) acc = __fadd_rn(acc, __fmul_rn(u[c], v[c]));
+    return acc;
+}
+
+__device__ __forceinline__ bool bsearch_row(const DCsr &m, int row, int item)
+{
+    int lo = m.indptr[row], hi = m.indptr[row + 1];
+    while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        int v = m.indices[mid];
+        if (v == item) return true;
+        if (v < item) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+constexpr int RANK_CHUNK = 256;
+
+// One 256-thread workgroup per user with test interactions (PYX:1264-1319).
+__global__ __launch_bounds__(256) void ranks_kernel(RanksArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *urep = smem;                               // [rs]
+    float *tscore = smem + a.rs;                      // [RANK_CHUNK]
+    int *tid_ = reinterpret_cast<int *>(tscore + RANK_CHUNK);  // [RANK_CHUNK]
+    int *tcount = tid_ + RANK_CHUNK;                  // [RANK_CHUNK]
+    const int lane = lane_id();
+    for (int user = blockIdx.x; user < a.test.rows; user += gridDim.x) {
+        int rs0 = a.test.indptr[user], re0 = a.test.indptr[user + 1];
+        if (re0 == rs0) continue;
+        __syncthreads();
+        for (int c = threadIdx.x; c <= a.d; c += blockDim.x) urep[c] = a.user_rep[(size_t)user * a.rs + c];
+        for (int c0 = rs0; c0 < re0; c0 += RANK_CHUNK) {
+            int m = min(RANK_CHUNK, re0 - c0);
+            __syncthreads();
+            if ((int)threadIdx.x < m) {
+                int it = a.test.indices[c0 + threadIdx.x];
+                tid_[threadIdx.x] = it;
+                tscore[threadIdx.x] = dense_dot(urep, a.item_rep + (size_t)it * a.rs, a.d);
+                tcount[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            int n_items = a.test.cols;
+            int rounds = (n_items + blockDim.x - 1) / blockDim.x;
+            for (int r = 0; r < rounds; ++r) {
+                int j = r * blockDim.x + threadIdx.x;
+                bool live = j < n_items && !bsearch_row(a.train, user, j);  // PYX:1303-1304
+                float sj = 0.0f;
+                if (live) sj = dense_dot(urep, a.item_rep + (size_t)j * a.rs, a.d);
+                for (int t = 0; t < m; ++t) {
+                    bool hit = live && (j != tid_[t]) && (sj >= tscore[t]);  // PYX:1317-1319
+                    unsigned long long mk = __ballot(hit);
+                    if (lane == 0 && mk) atomicAdd(&tcount[t], __popcll(mk));
+                }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < m) a.ranks[c0 + threadIdx.x] += (float)tcount[threadIdx.x];
+        }
+    }
+}
+
+__device__ void heap_sift(float *x, int start, int end)
+{
+    int root = start;
+    while (2 * root + 1 <= end) {
+        int child = 2 * root + 1, sw = root;
+        if (x[sw] < x[child]) sw = child;
+        if (child + 1 <= end && x[sw] < x[child + 1]) sw = child + 1;
+        if (sw == root) return;
+        float t = x[root]; x[root] = x[sw]; x[sw] = t;
+        root = sw;
+    }
+}
+
+// One thread per user (PYX:1336-1376); the row of rank_data is sorted ascending in place.
+__global__ void auc_kernel(DCsr ranks, const int32_t *ntp, float *rank_data, float *auc)
+{
+    int user = blockIdx.x * blockDim.x + threadIdx.x;
+    if (user >= ranks.rows) return;
+    int rs0 = ranks.indptr[user], re0 = ranks.indptr[user + 1];
+    int npos = re0 - rs0;
+    int nneg = ranks.cols - (npos + ntp[user]);
+    if (npos == 0 || nneg == ranks.cols) { auc[user] = 0.5f; return; }
+    float *x = rank_data + rs0;
+    for (int s = (npos - 2) / 2; s >= 0; --s) heap_sift(x, s, npos - 1);
+    for (int e = npos - 1; e > 0; --e) {
+        float t = x[e]; x[e] = x[0]; x[0] = t;
+        heap_sift(x, 0, e - 1);
+    }
+    float acc = auc[user];
+    for (int i = 0; i < npos; ++i) {
+        float rank = ranks.data[rs0 + i];
+        rank = __fsub_rn(rank, (float)i);
+        if (rank < 0.0f) rank = 0.0f;
+        acc = (float)((double)acc + (1.0 - (double)__fdiv_rn(rank, (float)nneg)));
+    }
+    if (npos != 0) acc = __fdiv_rn(acc, (float)npos);
+    auc[user] = acc;
+}
+
+template <int NC>
+static hipError_t predict_nc(const PredictArgs &a, int grid, size_t smem, hipStream_t st)
+{
+    predict_kernel<NC><<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st)
+{
+    int d = a.m.d;
+    if (d <= 64) return predict_nc<1>(a, grid, smem, st);
+    if (d <= 128) return predict_nc<2>(a, grid, smem, st);
+    if (d <= 256) return predict_nc<4>(a, grid, smem, st);
+    if (d <= 512) return predict_nc<8>(a, grid, smem, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs, float *out,
+                           hipStream_t st)
+{
+    if (f.rows <= 0) return hipSuccess;
+    int grid = (int)std::min<int64_t>(4096, ((int64_t)f.rows + 3) / 4);
+    if (d <= 64) rep_rows_kernel<1><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
+    else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
+    else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
+    else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_ranks(const RanksArgs &a, hipStream_t st)
+{
+    if (a.test.rows <= 0) return hipSuccess;
+    int grid = std::min(a.test.rows, 8192);
+    size_t smem = sizeof(float) * (size_t)(a.rs + 3 * RANK_CHUNK);
+    ranks_kernel<<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_auc(const DCsr &ranks, const int32_t *ntp, float *rank_data, float *auc,
+                      hipStream_t st)
+{
+    if (ranks.rows <= 0) return hipSuccess;
+    auc_kernel<<<(ranks.rows + 255) / 256, 256, 0, st>>>(ranks, ntp, rank_data, auc);
+    return hipGetLastError();
+}
+
+}  // namespace lfm

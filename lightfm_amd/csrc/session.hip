@@ -1,0 +1,857 @@
+// session.hip -- host side of liblfm_hip.so: the C ABI of include/lfm_hip.h.
+//
+// Device-resident state for one model on one GPU (weights, feature CSRs, training
+// COO, shuffle slots), the epoch driver that replaces the prange loops of
+// _lightfm_fast.pyx.template (PYX:719-724, 819-825, 951-957, 1107-1113), and the
+// one-shot entry points that mirror the Cython functions one for one.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "../../include/lfm_hip.h"
+#include "device.hpp"
+#include "kernels.hpp"
+
+using namespace lfm;
+
+// ------------------------------------------------------------------ errors ---
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? LFM_ENOMEM : LFM_ENODEV,               \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+#define LFM_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != LFM_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *lfm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lfm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name) { strncpy(name, p.name, 255); name[255] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return LFM_OK;
+}
+
+// ------------------------------------------------------------ device memory ---
+
+template <typename T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count)
+    {
+        if (count == n && p) return LFM_OK;
+        release();
+        if (count == 0) return LFM_OK;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) return fail(LFM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        n = count;
+        return LFM_OK;
+    }
+    int upload(const T *src, size_t count)
+    {
+        LFM_TRY(alloc(count));
+        if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return LFM_OK;
+    }
+    int download(T *dst) const
+    {
+        if (n) HIP_TRY(hipMemcpy(dst, p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return LFM_OK;
+    }
+};
+
+struct DevCsr {
+    DBuf<int32_t> indices, indptr;
+    DBuf<float> data;
+    int32_t rows = 0, cols = 0;
+    int64_t nnz = 0;
+    bool identity = false;
+
+    static bool is_identity(const lfm_csr *m)
+    {
+        if (m->nnz != m->rows || m->cols < m->rows) return false;
+        for (int32_t i = 0; i < m->rows; ++i)
+            if (m->indptr[i] != i || m->indices[i] != i || m->data[i] != 1.0f) return false;
+        return m->indptr[m->rows] == m->rows;
+    }
+    int upload(const lfm_csr *m, bool detect_identity, bool need_data)
+    {
+        rows = m->rows;
+        cols = m->cols;
+        nnz = m->nnz;
+        identity = detect_identity && is_identity(m);
+        if (identity) {  // never dereferenced on device
+            indices.release();
+            indptr.release();
+            data.release();
+            return LFM_OK;
+        }
+        LFM_TRY(indptr.upload(m->indptr, (size_t)m->rows + 1));
+        LFM_TRY(indices.upload(m->indices, (size_t)m->nnz));
+        if (need_data) LFM_TRY(data.upload(m->data, (size_t)m->nnz));
+        return LFM_OK;
+    }
+    DCsr view() const { return DCsr{indices.p, indptr.p, data.p, rows, cols, identity ? 1 : 0}; }
+};
+
+static int validate_csr(const lfm_csr *m, const char *what)
+{
+    if (!m) return fail(LFM_EINVAL, std::string(what) + ": null matrix");
+    if (m->rows < 0 || m->cols < 0 || m->nnz < 0) return fail(LFM_EINVAL, std::string(what) + ": negative size");
+    if (!m->indptr || (m->nnz && (!m->indices || !m->data)))
+        return fail(LFM_EINVAL, std::string(what) + ": null buffer");
+    if (m->indptr[0] != 0 || (int64_t)m->indptr[m->rows] != m->nnz)
+        return fail(LFM_EINVAL, std::string(what) + ": indptr does not span nnz");
+    return LFM_OK;
+}
+
+// ------------------------------------------------------------------ RCCL ---
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+            r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+            r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+            r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        }
+    }
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) return nullptr;
+    return &r;
+}
+
+#define NCCL_TRY(expr)                                                                     \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess)                                                             \
+            return fail(LFM_ECOMM, std::string(#expr) + ": " +                             \
+                                       (rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error")); \
+    } while (0)
+
+// ---------------------------------------------------------------- session ---
+
+struct lfm_session {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cus = 256;
+
+    // model: [side][kind] with kind 0..5 = W,G,M,b,bG,bM ; side 0 item, 1 user
+    DBuf<float> tab[2][6];
+    int32_t n_feat[2] = {0, 0};
+    int32_t d = 0, adadelta = 0, max_sampled = 0;
+    float lr = 0, rho = 0, eps = 0;
+    DBuf<double> scales;      // [2]
+    DBuf<double> scale_prod;  // [2]
+    DBuf<unsigned long long> counters;
+    DBuf<uint32_t> seeds;
+    DBuf<double> logtab;
+    DBuf<int> flag;
+
+    DevCsr itf, usf, pos;
+    DBuf<int32_t> user_ids, item_ids;
+    DBuf<float> Y, weight;
+    bool weight_aliases_Y = false;
+    int64_t n = 0;
+    std::vector<DBuf<int32_t> *> shuffles;
+    DBuf<int32_t> neg_log, sampled_log;
+
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    DBuf<float> snap[2][6];
+    bool user_snap_valid = false;
+
+    ~lfm_session()
+    {
+        for (auto *s : shuffles) delete s;
+        if (comm && rccl()) rccl()->CommDestroy(comm);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    DModel dmodel()
+    {
+        DModel m;
+        for (int s = 0; s < 2; ++s) {
+            m.W[s] = tab[s][0].p;
+            m.G[s] = tab[s][1].p;
+            m.M[s] = tab[s][2].p;
+            m.b[s] = tab[s][3].p;
+            m.bG[s] = tab[s][4].p;
+            m.bM[s] = tab[s][5].p;
+            m.n_feat[s] = n_feat[s];
+        }
+        m.d = d;
+        m.adadelta = adadelta;
+        m.lr = lr;
+        m.rho = rho;
+        m.eps = eps;
+        m.max_sampled = max_sampled;
+        m.scales = scales.p;
+        return m;
+    }
+};
+
+static float *host_tab(const lfm_model *m, int side, int kind)
+{
+    float *const t[2][6] = {
+        {m->item_W, m->item_G, m->item_M, m->item_b, m->item_bG, m->item_bM},
+        {m->user_W, m->user_G, m->user_M, m->user_b, m->user_bG, m->user_bM}};
+    return t[side][kind];
+}
+
+static size_t tab_count(const lfm_session *s, int side, int kind)
+{
+    return kind < 3 ? (size_t)s->n_feat[side] * s->d : (size_t)s->n_feat[side];
+}
+
+static bool kind_used(const lfm_session *s, int kind) { return s->adadelta || (kind != 2 && kind != 5); }
+
+static int validate_model(const lfm_model *m)
+{
+    if (!m) return fail(LFM_EINVAL, "null model");
+    if (m->d <= 0) return fail(LFM_EINVAL, "no_components must be positive");
+    if (m->d > 512) return fail(LFM_EUNSUPPORTED, "no_components > 512 is not supported by the HIP backend");
+    if (m->n_item_feat < 0 || m->n_user_feat < 0) return fail(LFM_EINVAL, "negative feature count");
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 6; ++k)
+            if (!host_tab(m, s, k) && (s == 0 ? m->n_item_feat : m->n_user_feat) > 0)
+                return fail(LFM_EINVAL, "null weight array");
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
+                                  const lfm_csr *item_features, const lfm_csr *user_features)
+{
+    if (!out) return fail(LFM_EINVAL, "null out pointer");
+    *out = nullptr;
+    LFM_TRY(validate_model(model));
+    LFM_TRY(validate_csr(item_features, "item_features"));
+    LFM_TRY(validate_csr(user_features, "user_features"));
+    if (item_features->cols > model->n_item_feat || user_features->cols > model->n_user_feat)
+        return fail(LFM_EINVAL, "feature matrix has more columns than there are embeddings");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(LFM_ENODEV, "no HIP device available (the HIP backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(LFM_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    lfm_session *s = new lfm_session();
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->cus = prop.multiProcessorCount;
+    int rc = LFM_OK;
+    auto guard = [&](int r) { if (r != LFM_OK && rc == LFM_OK) rc = r; };
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        delete s;
+        return fail(LFM_ENODEV, "cannot create HIP stream/events");
+    }
+    s->n_feat[0] = model->n_item_feat;
+    s->n_feat[1] = model->n_user_feat;
+    s->d = model->d;
+    s->adadelta = model->adadelta;
+    s->max_sampled = model->max_sampled;
+    s->lr = model->lr;
+    s->rho = model->rho;
+    s->eps = model->eps;
+    for (int side = 0; side < 2 && rc == LFM_OK; ++side)
+        for (int k = 0; k < 6 && rc == LFM_OK; ++k)
+            if (kind_used(s, k)) guard(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
+    double sc[2] = {model->item_scale, model->user_scale}, one[2] = {1.0, 1.0};
+    if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
+    if (rc == LFM_OK) guard(s->scale_prod.upload(one, 2));
+    if (rc == LFM_OK) guard(s->counters.alloc(4));
+    if (rc == LFM_OK) guard(s->flag.alloc(1));
+    if (rc == LFM_OK) guard(s->itf.upload(item_features, true, true));
+    if (rc == LFM_OK) guard(s->usf.upload(user_features, true, true));
+    if (rc != LFM_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_destroy(lfm_session *s)
+{
+    if (!s) return LFM_OK;
+    (void)hipSetDevice(s->device);
+    delete s;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *positives,
+                                            const int32_t *user_ids, const int32_t *item_ids,
+                                            const float *Y, const float *sample_weight, int64_t n)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (n < 0 || n > 0x7fffffffLL) return fail(LFM_EINVAL, "interaction count out of int32 range");
+    if (n && !user_ids) return fail(LFM_EINVAL, "null user_ids");
+    HIP_TRY(hipSetDevice(s->device));
+    s->n = n;
+    if (positives) {
+        LFM_TRY(validate_csr(positives, "interactions"));
+        LFM_TRY(s->pos.upload(positives, false, false));
+    }
+    LFM_TRY(s->user_ids.upload(user_ids, (size_t)n));
+    if (item_ids) LFM_TRY(s->item_ids.upload(item_ids, (size_t)n));
+    if (Y) LFM_TRY(s->Y.upload(Y, (size_t)n));
+    s->weight_aliases_Y = (sample_weight == Y);
+    if (sample_weight && !s->weight_aliases_Y) LFM_TRY(s->weight.upload(sample_weight, (size_t)n));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_upload_shuffle(lfm_session *s, int32_t slot, const int32_t *shuffle, int64_t n)
+{
+    if (!s || slot < 0 || slot > 4096) return fail(LFM_EINVAL, "bad shuffle slot");
+    if (n != s->n) return fail(LFM_EINVAL, "shuffle length differs from the interaction count");
+    HIP_TRY(hipSetDevice(s->device));
+    while ((int)s->shuffles.size() <= slot) s->shuffles.push_back(new DBuf<int32_t>());
+    return s->shuffles[slot]->upload(shuffle, (size_t)n);
+}
+
+static void static_chunk(int64_t n, int32_t T, int32_t t, int64_t *lo, int64_t *hi)
+{
+    int64_t q = n / T, r = n % T;  // libgomp static schedule, no chunk clause (C_OMP:7224)
+    if (t < r) { *lo = (q + 1) * t; *hi = *lo + q + 1; }
+    else { *lo = q * t + r; *hi = *lo + q; }
+}
+
+// ------------------------------------------------------------- multi-GPU ---
+
+__global__ void sub_inplace_kernel(float *x, const float *y, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) x[j] -= y[j];
+}
+__global__ void add_inplace_kernel(float *x, const float *y, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) x[j] += y[j];
+}
+
+static int snapshot_side(lfm_session *s, int side)
+{
+    for (int k = 0; k < 6; ++k) {
+        if (!kind_used(s, k)) continue;
+        size_t cnt = tab_count(s, side, k);
+        LFM_TRY(s->snap[side][k].alloc(cnt));
+        if (cnt)
+            HIP_TRY(hipMemcpyAsync(s->snap[side][k].p, s->tab[side][k].p, cnt * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s->stream));
+    }
+    return LFM_OK;
+}
+
+// X := X_start + sum over ranks (X_rank - X_start): the local-SGD merge of SURVEY 8(e).
+static int merge_side(lfm_session *s, int side)
+{
+    Rccl *r = rccl();
+    if (!r) return fail(LFM_ECOMM, "librccl.so not available");
+    for (int k = 0; k < 6; ++k) {
+        if (!kind_used(s, k)) continue;
+        int64_t cnt = (int64_t)tab_count(s, side, k);
+        if (!cnt) continue;
+        int grid = (int)std::min<int64_t>(4096, (cnt + 255) / 256);
+        sub_inplace_kernel<<<grid, 256, 0, s->stream>>>(s->tab[side][k].p, s->snap[side][k].p, cnt);
+    }
+    if (r->GroupStart) NCCL_TRY(r->GroupStart());
+    for (int k = 0; k < 6; ++k) {
+        if (!kind_used(s, k)) continue;
+        size_t cnt = tab_count(s, side, k);
+        if (!cnt) continue;
+        NCCL_TRY(r->AllReduce(s->tab[side][k].p, s->tab[side][k].p, cnt, ncclFloat, ncclSum, s->comm, s->stream));
+    }
+    if (r->GroupEnd) NCCL_TRY(r->GroupEnd());
+    for (int k = 0; k < 6; ++k) {
+        if (!kind_used(s, k)) continue;
+        int64_t cnt = (int64_t)tab_count(s, side, k);
+        if (!cnt) continue;
+        int grid = (int)std::min<int64_t>(4096, (cnt + 255) / 256);
+        add_inplace_kernel<<<grid, 256, 0, s->stream>>>(s->tab[side][k].p, s->snap[side][k].p, cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    return LFM_OK;
+}
+
+extern "C" int lfm_comm_unique_id(char id[LFM_UNIQUE_ID_BYTES])
+{
+    Rccl *r = rccl();
+    if (!r) return fail(LFM_ECOMM, "librccl.so not available");
+    static_assert(sizeof(ncclUniqueId) == LFM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCL_TRY(r->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID_BYTES], int32_t rank,
+                                     int32_t nranks)
+{
+    if (!s || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(LFM_EINVAL, "bad comm arguments");
+    Rccl *r = rccl();
+    if (!r) return fail(LFM_ECOMM, "librccl.so not available");
+    HIP_TRY(hipSetDevice(s->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCL_TRY(r->CommInitRank(&s->comm, nranks, u, rank));
+    s->rank = rank;
+    s->nranks = nranks;
+    LFM_TRY(snapshot_side(s, 1));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->user_snap_valid = true;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_comm_merge_users(lfm_session *s)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (!s->comm) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->user_snap_valid) return fail(LFM_EINVAL, "no user-side snapshot");
+    LFM_TRY(merge_side(s, 1));
+    LFM_TRY(snapshot_side(s, 1));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_comm_barrier(lfm_session *s)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (!s->comm) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    NCCL_TRY(rccl()->AllReduce(s->flag.p, s->flag.p, 1, ncclInt32, ncclSum, s->comm, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LFM_OK;
+}
+
+// ------------------------------------------------------------------ epoch ---
+
+static void tile_geometry(int d, int want_rows, int *rows, int *stride)
+{
+    int ts = ((d + 1 + 3) / 4) * 4;  // bias in column d, rows 16-byte aligned
+    int budget_rows = (6 * 1024) / (ts * 4);
+    int r = std::min(want_rows, std::min(16, budget_rows));
+    r = std::max(r, 3);
+    *rows = r;
+    *stride = ts;
+}
+
+extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, double item_alpha,
+                                 double user_alpha, int32_t k, int32_t n_positives,
+                                 const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (loss < 0 || loss > 3) return fail(LFM_EINVAL, "unknown loss");
+    if (slot < 0 || slot >= (int)s->shuffles.size() || s->shuffles[slot]->n != (size_t)s->n)
+        return fail(LFM_EINVAL, "shuffle slot not uploaded");
+    const bool needs_rng = loss != LFM_LOSS_LOGISTIC;
+    if (needs_rng && (!seeds || n_seeds < 1)) return fail(LFM_EINVAL, "seeds required");
+    if (loss != LFM_LOSS_WARP_KOS && s->n && (!s->item_ids.p || !s->Y.p))
+        return fail(LFM_EINVAL, "item_ids / Y not uploaded");
+    if (needs_rng && !s->pos.indptr.p && s->pos.rows == 0 && s->n)
+        return fail(LFM_EINVAL, "positives lookup not uploaded");
+    if (loss == LFM_LOSS_WARP_KOS && (k < 1 || n_positives < 1)) return fail(LFM_EINVAL, "k and n must be positive");
+    if (s->max_sampled < 0) return fail(LFM_EINVAL, "max_sampled must not be negative");
+    lfm_opts local;
+    memset(&local, 0, sizeof(local));
+    if (!opts) opts = &local;
+    const bool serial = opts->mode == LFM_MODE_SERIAL;
+    HIP_TRY(hipSetDevice(s->device));
+
+    FitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.itf = s->itf.view();
+    a.usf = s->usf.view();
+    a.pos = s->pos.view();
+    a.m = s->dmodel();
+    a.user_ids = s->user_ids.p;
+    a.item_ids = s->item_ids.p;
+    a.Y = s->Y.p;
+    a.weight = s->weight_aliases_Y ? s->Y.p : s->weight.p;
+    a.shuffle = s->shuffles[slot]->p;
+    a.n = s->n;
+    a.item_alpha = item_alpha;
+    a.user_alpha = user_alpha;
+    a.serial = serial ? 1 : 0;
+    a.k = k;
+    a.n_pos = n_positives;
+    a.counters = s->counters.p;
+    a.scale_prod = s->scale_prod.p;
+
+    // WARP loss term per sampled count, evaluated with the HOST libm so the device
+    // never calls log(): PYX:881 / C_OMP:7446 (WARP), PYX:1039 / C_OMP:8452 (k-OS).
+    {
+        std::vector<double> lt((size_t)s->max_sampled + 1, 0.0);
+        int rows = s->itf.rows;
+        for (int q = 1; q <= s->max_sampled; ++q) {
+            double fl = floor((double)((long)(rows - 1) / (long)q));
+            lt[q] = (loss == LFM_LOSS_WARP_KOS) ? log(fl) : log(fl > 1.0 ? fl : 1.0);
+        }
+        LFM_TRY(s->logtab.upload(lt.data(), lt.size()));
+        a.logtab = s->logtab.p;
+    }
+    {
+        std::vector<uint32_t> sd(seeds ? seeds : nullptr, seeds ? seeds + n_seeds : nullptr);
+        if (sd.empty()) sd.push_back(0u);
+        LFM_TRY(s->seeds.upload(sd.data(), sd.size()));
+        a.seeds = s->seeds.p;
+    }
+    int want_rows = (loss == LFM_LOSS_WARP || loss == LFM_LOSS_WARP_KOS) ? s->max_sampled + 2 : 3;
+    if (loss == LFM_LOSS_WARP_KOS) want_rows = std::max(want_rows, std::min(n_positives, 15) + 1);
+    tile_geometry(s->d, want_rows, &a.tile_rows, &a.tile_stride);
+    a.first_batch = opts->first_batch > 0 ? opts->first_batch : 4;
+    a.first_batch = std::max(1, std::min(a.first_batch, a.tile_rows - 2));
+    a.pair_cap = (loss == LFM_LOSS_WARP_KOS) ? ((n_positives + 3) / 4) * 4 : 0;
+    size_t smem = sizeof(float) * ((size_t)WAVES_PER_BLOCK * a.tile_rows * a.tile_stride +
+                                   (size_t)WAVES_PER_BLOCK * 2 * a.pair_cap);
+    if (smem > 160 * 1024) return fail(LFM_EUNSUPPORTED, "k-OS n too large for the LDS pair buffer");
+
+    if (opts->neg_log) { LFM_TRY(s->neg_log.alloc((size_t)s->n)); a.neg_log = s->neg_log.p; }
+    if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
+    if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
+    if (a.sampled_log) HIP_TRY(hipMemsetAsync(a.sampled_log, 0, (size_t)s->n * 4, s->stream));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * sizeof(unsigned long long), s->stream));
+
+    if (s->comm) LFM_TRY(snapshot_side(s, 0));
+
+    const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    if (serial) {
+        int T = needs_rng ? n_seeds : 1;
+        for (int t = 0; t < T; ++t) {
+            static_chunk(s->n, T, t, &a.begin, &a.end);
+            a.seed_idx = t;
+            if (a.end > a.begin) HIP_TRY(launch_fit(loss, a, 1, WAVE, smem, s->stream));
+        }
+    } else {
+        int L = opts->launches_per_epoch;
+        if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
+        int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(smem, 1)));
+        int max_grid = s->cus * blocks_per_cu;
+        for (int l = 0; l < L; ++l) {
+            a.begin = s->n * l / L;
+            a.end = s->n * (l + 1) / L;
+            if (a.end <= a.begin) continue;
+            int64_t waves = a.end - a.begin;
+            int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream));
+            if (reg) {
+                HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
+                HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904
+            }
+        }
+    }
+    if (reg) HIP_TRY(launch_regularize(a.m, 1, s->stream));  // PYX:910-912 (no-op when scales are 1)
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    if (s->comm && s->nranks > 1) LFM_TRY(merge_side(s, 0));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    opts->kernel_ms = ms;
+    unsigned long long c[4];
+    LFM_TRY(s->counters.download(c));
+    for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
+    if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
+    if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_check_finite(lfm_session *s)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->flag.p, 0, sizeof(int), s->stream));
+    for (int side = 0; side < 2; ++side) {
+        HIP_TRY(launch_nonfinite(s->tab[side][0].p, (int64_t)tab_count(s, side, 0), s->flag.p, s->stream));
+        HIP_TRY(launch_nonfinite(s->tab[side][3].p, (int64_t)tab_count(s, side, 3), s->flag.p, s->stream));
+    }
+    int f = 0;
+    HIP_TRY(hipMemcpyAsync(&f, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return f ? 0 : 1;
+}
+
+extern "C" int lfm_session_sync_to_host(lfm_session *s, lfm_model *model)
+{
+    if (!s || !model) return fail(LFM_EINVAL, "null argument");
+    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
+        return fail(LFM_EINVAL, "model shape differs from the session's");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int side = 0; side < 2; ++side)
+        for (int k = 0; k < 6; ++k)
+            if (kind_used(s, k)) LFM_TRY(s->tab[side][k].download(host_tab(model, side, k)));
+    double sc[2];
+    LFM_TRY(s->scales.download(sc));
+    model->item_scale = sc[0];
+    model->user_scale = sc[1];
+    return LFM_OK;
+}
+
+// ---------------------------------------------------------------- predict ---
+
+extern "C" int lfm_session_predict(lfm_session *s, const int32_t *user_ids, const int32_t *item_ids,
+                                   float *predictions, int64_t n)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (n < 0) return fail(LFM_EINVAL, "negative count");
+    if (n == 0) return LFM_OK;
+    if (!user_ids || !item_ids || !predictions) return fail(LFM_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    DBuf<int32_t> du, di;
+    DBuf<float> dout;
+    LFM_TRY(du.upload(user_ids, (size_t)n));
+    LFM_TRY(di.upload(item_ids, (size_t)n));
+    LFM_TRY(dout.alloc((size_t)n));
+    PredictArgs a;
+    memset(&a, 0, sizeof(a));
+    a.itf = s->itf.view();
+    a.usf = s->usf.view();
+    a.m = s->dmodel();
+    a.uids = du.p;
+    a.iids = di.p;
+    a.out = dout.p;
+    a.n = n;
+    tile_geometry(s->d, 16, &a.tile_rows, &a.tile_stride);
+    a.tile_rows &= ~1;
+    if (a.tile_rows < 2) a.tile_rows = 2;
+    size_t smem = sizeof(float) * (size_t)WAVES_PER_BLOCK * a.tile_rows * a.tile_stride;
+    int64_t waves = (n + a.tile_rows / 2 - 1) / (a.tile_rows / 2);
+    int grid = (int)std::min<int64_t>((int64_t)s->cus * 8, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    HIP_TRY(launch_predict(a, std::max(grid, 1), smem, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return dout.download(predictions);
+}
+
+extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, const lfm_csr *train, float *ranks)
+{
+    if (!s || !ranks) return fail(LFM_EINVAL, "null argument");
+    LFM_TRY(validate_csr(test, "test_interactions"));
+    LFM_TRY(validate_csr(train, "train_interactions"));
+    if (test->rows > s->usf.rows || test->cols > s->itf.rows)
+        return fail(LFM_EINVAL, "interaction matrix larger than the feature matrices");
+    if (train->rows < test->rows) return fail(LFM_EINVAL, "train matrix has fewer rows than test");
+    if (test->nnz == 0) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DevCsr dtest, dtrain;
+    LFM_TRY(dtest.upload(test, false, false));
+    LFM_TRY(dtrain.upload(train, false, false));
+    int rs = ((s->d + 1 + 3) / 4) * 4;
+    DBuf<float> urep, irep, dranks;
+    DCsr usf = s->usf.view(), itf = s->itf.view();
+    usf.rows = test->rows;  // only users/items of the interaction matrix (PYX:1264, 1301)
+    itf.rows = test->cols;
+    LFM_TRY(urep.alloc((size_t)usf.rows * rs));
+    LFM_TRY(irep.alloc((size_t)itf.rows * rs));
+    LFM_TRY(dranks.upload(ranks, (size_t)test->nnz));
+    HIP_TRY(launch_rep_rows(usf, s->tab[1][0].p, s->tab[1][3].p, s->d, rs, urep.p, s->stream));
+    HIP_TRY(launch_rep_rows(itf, s->tab[0][0].p, s->tab[0][3].p, s->d, rs, irep.p, s->stream));
+    RanksArgs a;
+    a.user_rep = urep.p;
+    a.item_rep = irep.p;
+    a.rs = rs;
+    a.d = s->d;
+    a.test = dtest.view();
+    a.train = dtrain.view();
+    a.ranks = dranks.p;
+    HIP_TRY(launch_ranks(a, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return dranks.download(ranks);
+}
+
+// ---------------------------------------------------- one-shot entry points ---
+
+namespace {
+struct SessionHolder {
+    lfm_session *s = nullptr;
+    ~SessionHolder() { lfm_session_destroy(s); }
+};
+}  // namespace
+
+static int one_shot_fit(int loss, const lfm_csr *itf, const lfm_csr *usf, const lfm_csr *positives,
+                        const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                        const float *w, const int32_t *shuffle, int64_t n, lfm_model *model,
+                        double ia, double ua, int32_t k, int32_t npos, const uint32_t *seeds,
+                        int32_t n_seeds, lfm_opts *opts)
+{
+    if (n && !shuffle) return fail(LFM_EINVAL, "null shuffle_indices");
+    SessionHolder h;
+    LFM_TRY(lfm_session_create(&h.s, 0, model, itf, usf));
+    LFM_TRY(lfm_session_set_interactions(h.s, positives, user_ids, item_ids, Y, w, n));
+    LFM_TRY(lfm_session_upload_shuffle(h.s, 0, shuffle, n));
+    LFM_TRY(lfm_session_epoch(h.s, loss, 0, ia, ua, k, npos, seeds, n_seeds, opts));
+    return lfm_session_sync_to_host(h.s, model);
+}
+
+extern "C" int lfm_fit_warp(const lfm_csr *itf, const lfm_csr *usf, const lfm_csr *interactions,
+                            const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                            const float *sample_weight, const int32_t *shuffle, int64_t n,
+                            lfm_model *model, double item_alpha, double user_alpha,
+                            const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts)
+{
+    return one_shot_fit(LFM_LOSS_WARP, itf, usf, interactions, user_ids, item_ids, Y, sample_weight,
+                        shuffle, n, model, item_alpha, user_alpha, 0, 0, seeds, n_seeds, opts);
+}
+
+extern "C" int lfm_fit_bpr(const lfm_csr *itf, const lfm_csr *usf, const lfm_csr *interactions,
+                           const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                           const float *sample_weight, const int32_t *shuffle, int64_t n,
+                           lfm_model *model, double item_alpha, double user_alpha,
+                           const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts)
+{
+    return one_shot_fit(LFM_LOSS_BPR, itf, usf, interactions, user_ids, item_ids, Y, sample_weight,
+                        shuffle, n, model, item_alpha, user_alpha, 0, 0, seeds, n_seeds, opts);
+}
+
+extern "C" int lfm_fit_logistic(const lfm_csr *itf, const lfm_csr *usf, const int32_t *user_ids,
+                                const int32_t *item_ids, const float *Y, const float *sample_weight,
+                                const int32_t *shuffle, int64_t n, lfm_model *model,
+                                double item_alpha, double user_alpha, lfm_opts *opts)
+{
+    return one_shot_fit(LFM_LOSS_LOGISTIC, itf, usf, nullptr, user_ids, item_ids, Y, sample_weight,
+                        shuffle, n, model, item_alpha, user_alpha, 0, 0, nullptr, 0, opts);
+}
+
+extern "C" int lfm_fit_warp_kos(const lfm_csr *itf, const lfm_csr *usf, const lfm_csr *data,
+                                const int32_t *user_ids, const int32_t *shuffle, int64_t n,
+                                lfm_model *model, double item_alpha, double user_alpha, int32_t k,
+                                int32_t n_positives, const uint32_t *seeds, int32_t n_seeds,
+                                lfm_opts *opts)
+{
+    return one_shot_fit(LFM_LOSS_WARP_KOS, itf, usf, data, user_ids, nullptr, nullptr, nullptr, shuffle,
+                        n, model, item_alpha, user_alpha, k, n_positives, seeds, n_seeds, opts);
+}
+
+extern "C" int lfm_predict(const lfm_csr *itf, const lfm_csr *usf, const int32_t *user_ids,
+                           const int32_t *item_ids, float *predictions, int64_t n, const lfm_model *model)
+{
+    SessionHolder h;
+    LFM_TRY(lfm_session_create(&h.s, 0, model, itf, usf));
+    return lfm_session_predict(h.s, user_ids, item_ids, predictions, n);
+}
+
+extern "C" int lfm_predict_ranks(const lfm_csr *itf, const lfm_csr *usf, const lfm_csr *test,
+                                 const lfm_csr *train, float *ranks, const lfm_model *model)
+{
+    SessionHolder h;
+    LFM_TRY(lfm_session_create(&h.s, 0, model, itf, usf));
+    return lfm_session_predict_ranks(h.s, test, train, ranks);
+}
+
+extern "C" int lfm_auc_from_rank(const lfm_csr *ranks, const int32_t *num_train_positives,
+                                 float *rank_data, float *auc)
+{
+    LFM_TRY(validate_csr(ranks, "ranks"));
+    if (!num_train_positives || !auc || (ranks->nnz && !rank_data)) return fail(LFM_EINVAL, "null buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(LFM_ENODEV, "no HIP device available (the HIP backend has no CPU fallback)");
+    HIP_TRY(hipSetDevice(0));
+    DevCsr dr;
+    LFM_TRY(dr.upload(ranks, false, true));
+    DBuf<int32_t> dntp;
+    DBuf<float> drd, dauc;
+    LFM_TRY(dntp.upload(num_train_positives, (size_t)ranks->rows));
+    LFM_TRY(dauc.upload(auc, (size_t)ranks->rows));
+    DCsr v = dr.view();
+    float *rd = dr.data.p;  // the reference passes ranks.data as rank_data (evaluation.py:247-249)
+    if (rank_data != ranks->data) {
+        LFM_TRY(drd.upload(rank_data, (size_t)ranks->nnz));
+        rd = drd.p;
+    }
+    HIP_TRY(launch_auc(v, dntp.p, rd, dauc.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (ranks->nnz) HIP_TRY(hipMemcpy(rank_data, rd, (size_t)ranks->nnz * sizeof(float), hipMemcpyDeviceToHost));
+    return dauc.download(auc);
+}
+
+__global__ void in_positives_kernel(DCsr m, int row, int col, int *out)
+{
+    bool r = in_positives(m, col, row, lane_id());
+    if (threadIdx.x == 0) *out = r ? 1 : 0;
+}
+
+extern "C" int lfm_in_positives(int32_t row, int32_t col, const lfm_csr *mat)
+{
+    LFM_TRY(validate_csr(mat, "mat"));
+    if (row < 0 || row >= mat->rows) return fail(LFM_EINVAL, "row out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(LFM_ENODEV, "no HIP device available (the HIP backend has no CPU fallback)");
+    HIP_TRY(hipSetDevice(0));
+    DevCsr dm;
+    LFM_TRY(dm.upload(mat, false, false));
+    DBuf<int> out;
+    LFM_TRY(out.alloc(1));
+    in_positives_kernel<<<1, WAVE>>>(dm.view(), row, col, out.p);
+    HIP_TRY(hipGetLastError());
+    int r = 0;
+    HIP_TRY(hipMemcpy(&r, out.p, sizeof(int), hipMemcpyDeviceToHost));
+    return r;
+}

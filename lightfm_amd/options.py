@@ -1,0 +1,36 @@
+"""Execution options of the HIP backend (not part of the reference's API).
+
+mode               "parallel" (default): Hogwild over thousands of wavefronts, one PRNG
+                   stream per shuffled position.  "serial": one wavefront in the
+                   reference's order with its rand_r streams -- bit-exact, for parity tests.
+launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
+first_batch        negatives scored speculatively in the first batch (0 = auto).
+log_samples        record (negative, sampled) per shuffled position into last_logs.
+device_shuffle     LightFM.fit_partial only: see lightfm.py.
+
+Environment: LIGHTFM_AMD_MODE, LIGHTFM_AMD_LAUNCHES, LIGHTFM_AMD_FIRST_BATCH.
+"""
+import os
+
+
+class _Options(object):
+    def __init__(self):
+        self.mode = os.environ.get("LIGHTFM_AMD_MODE", "parallel")
+        self.launches_per_epoch = int(os.environ.get("LIGHTFM_AMD_LAUNCHES", "0"))
+        self.first_batch = int(os.environ.get("LIGHTFM_AMD_FIRST_BATCH", "0"))
+        self.log_samples = False
+        self.last_counters = None
+        self.last_kernel_ms = None
+        self.last_logs = None
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise ValueError("unknown option %r" % k)
+            setattr(self, k, v)
+        if self.mode not in ("parallel", "serial"):
+            raise ValueError("mode must be 'parallel' or 'serial'")
+        return self
+
+
+options = _Options()
