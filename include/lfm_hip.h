@@ -68,7 +68,8 @@ typedef struct lfm_opts {
     int32_t launches_per_epoch; /* parallel mode: kernel launches per epoch (a launch
                                    boundary is a device-wide release/acquire); 0 = auto */
     int32_t first_batch;        /* negatives scored speculatively in the first batch; 0 = auto */
-    int32_t reserved;
+    int32_t max_waves;          /* parallel mode: cap on wavefronts (= interactions) in flight;
+                                   0 = auto (staleness)                 */
     int32_t *neg_log;           /* host [n] or NULL: chosen negative per shuffled position, -1 = none */
     int32_t *sampled_log;       /* host [n] or NULL: draws consumed per shuffled position */
     int64_t counters[4];        /* out: positives visited, draws, updates, in_positives probes */

@@ -54,7 +54,7 @@ class FastLightFM(object):
                   user_features, user_feature_gradients, user_feature_momentum,
                   user_biases, user_bias_gradients, user_bias_momentum)
         for name, a in zip(self._names, arrays):
-            setattr(self, name, N.require(a, np.float32, 2 if "features" in name else 1, name))
+            setattr(self, name, N.require(a, np.float32, 2 if "feature" in name else 1, name))
         self.no_components = int(no_components)
         self.adadelta = int(adadelta)
         self.learning_rate = float(learning_rate)
@@ -82,6 +82,7 @@ def make_opts(n=0, want_log=False):
     o.mode = N.MODE_SERIAL if options.mode == "serial" else N.MODE_PARALLEL
     o.launches_per_epoch = int(options.launches_per_epoch)
     o.first_batch = int(options.first_batch)
+    o.max_waves = int(options.max_waves)
     logs = None
     if want_log:
         logs = (np.full(n, -1, np.int32), np.zeros(n, np.int32))

@@ -42,7 +42,7 @@ class LfmModel(C.Structure):
 
 class LfmOpts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("launches_per_epoch", C.c_int32),
-                ("first_batch", C.c_int32), ("reserved", C.c_int32),
+                ("first_batch", C.c_int32), ("max_waves", C.c_int32),
                 ("neg_log", I32P), ("sampled_log", I32P),
                 ("counters", C.c_int64 * 4), ("kernel_ms", C.c_float)]
 

@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void fit_warp_kernel(FitArgs a)
     Scales sc;
     wave_begin(a, w, sc, smem);
     const int lane = w.lane, d = a.m.d, TS = w.TS;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t state = a.serial ? a.seeds[a.seed_idx] : 0u;
     const uint32_t base_seed = a.seeds[0];
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void fit_bpr_kernel(FitArgs a)
     Scales sc;
     wave_begin(a, w, sc, smem);
     const int lane = w.lane, d = a.m.d, TS = w.TS;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t state = a.serial ? a.seeds[a.seed_idx] : 0u;
     const uint32_t base_seed = a.seeds[0];
     const uint32_t n_examples = (uint32_t)a.n;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void fit_logistic_kernel(FitArgs a)
     Scales sc;
     wave_begin(a, w, sc, smem);
     const int lane = w.lane, d = a.m.d, TS = w.TS;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {
         int row = uni(a.shuffle[i]);
         int user = uni(a.user_ids[row]), item = uni(a.item_ids[row]);
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
                        (size_t)wib * 2 * a.pair_cap;
     int *pair_idx = reinterpret_cast<int *>(pair_base);
     float *pair_val = pair_base + a.pair_cap;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wib;
-    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t state = a.serial ? a.seeds[a.seed_idx] : 0u;
     const uint32_t base_seed = a.seeds[0];
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {

@@ -594,6 +594,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
         int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(smem, 1)));
         int max_grid = s->cus * blocks_per_cu;
+        // Staleness bound: every wavefront in flight is one interaction computed against
+        // weights that the others are changing.  Auto: at most one in-flight interaction
+        // per 4 user rows (DESIGN.md "Hogwild at GPU width").
+        int64_t max_waves = opts->max_waves > 0 ? opts->max_waves
+                                                : std::max<int64_t>(16, (int64_t)s->usf.rows / 4);
+        max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / WAVES_PER_BLOCK));
         for (int l = 0; l < L; ++l) {
             a.begin = s->n * l / L;
             a.end = s->n * (l + 1) / L;

@@ -1,0 +1,459 @@
+"""`LightFM` estimator with the reference's public API (lightfm/lightfm.py, "LFM"
+below) whose epochs run on the MI355X.
+
+Everything a caller can observe is kept: constructor arguments and assertions
+(LFM:189-241), the 12 weight attributes and their initialisation order
+(LFM:245-312), input coercion and the exceptions raised for bad input
+(LFM:314-420, 617-652, 819-849), the consumption of `random_state` (one
+`shuffle` then one `randint(size=num_threads)` per epoch, LFM:689-690 +
+_lightfm_fast.pyx.template:812-814), pickling, `fit_partial` resuming, sklearn
+`get_params/set_params`.
+
+What changes is below the boundary: instead of handing host arrays to the Cython
+extension once per epoch, `fit_partial` opens ONE device-resident session
+(include/lfm_hip.h: lfm_session_*), uploads weights / feature CSRs / the COO once,
+runs every epoch on the GPU (only the shuffled index list and the seeds travel
+per epoch), checks finiteness on device and copies the weights back at the end.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _native as N
+from ._lightfm_fast import CSRMatrix, FastLightFM, make_opts, predict_lightfm, predict_ranks
+from .options import options
+
+__all__ = ["LightFM"]
+
+CYTHON_DTYPE = np.float32
+
+_WEIGHTS = ("item_embeddings", "item_embedding_gradients", "item_embedding_momentum",
+            "item_biases", "item_bias_gradients", "item_bias_momentum",
+            "user_embeddings", "user_embedding_gradients", "user_embedding_momentum",
+            "user_biases", "user_bias_gradients", "user_bias_momentum")
+
+_NOT_FINITE = ("Not all estimated parameters are finite, your model may have diverged. "
+               "Try decreasing the learning rate or normalising feature values and sample weights")
+
+
+class _Session(object):
+    """RAII wrapper of lfm_session (include/lfm_hip.h)."""
+
+    def __init__(self, model_struct, item_features, user_features, device=0):
+        self.handle = C.c_void_p()
+        self._keep = (model_struct, item_features, user_features)
+        N.check(N.lib().lfm_session_create(C.byref(self.handle), device, model_struct.byref(),
+                                           item_features.byref(), user_features.byref()))
+
+    def set_interactions(self, positives, rows, cols, data, weight):
+        n = len(rows)
+        N.check(N.lib().lfm_session_set_interactions(
+            self.handle, positives.byref() if positives is not None else None, N.i32p(rows),
+            N.i32p(cols), N.f32p(data), N.f32p(weight), C.c_int64(n)))
+
+    def upload_shuffle(self, shuffle, slot=0):
+        N.check(N.lib().lfm_session_upload_shuffle(self.handle, slot, N.i32p(shuffle),
+                                                   C.c_int64(len(shuffle))))
+
+    def epoch(self, loss, item_alpha, user_alpha, k, n, seeds, opts, slot=0):
+        N.check(N.lib().lfm_session_epoch(
+            self.handle, N.LOSS_IDS[loss], slot, C.c_double(item_alpha), C.c_double(user_alpha),
+            C.c_int32(k), C.c_int32(n), N.u32p(seeds), 0 if seeds is None else len(seeds),
+            C.byref(opts)))
+
+    def check_finite(self):
+        return bool(N.check(N.lib().lfm_session_check_finite(self.handle)))
+
+    def sync_to_host(self, model_struct):
+        N.check(N.lib().lfm_session_sync_to_host(self.handle, model_struct.byref()))
+
+    def comm_init(self, unique_id, rank, nranks):
+        N.check(N.lib().lfm_session_comm_init(self.handle, unique_id, rank, nranks))
+
+    def comm_merge_users(self):
+        N.check(N.lib().lfm_session_comm_merge_users(self.handle))
+
+    def comm_barrier(self):
+        N.check(N.lib().lfm_session_comm_barrier(self.handle))
+
+    def close(self):
+        if self.handle:
+            N.lib().lfm_session_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LightFM(object):
+    """Hybrid latent-representation recommender (API of LFM:24-1107).
+
+    Parameters are those of the reference: no_components, k, n, learning_schedule
+    ('adagrad' | 'adadelta'), loss ('logistic' | 'bpr' | 'warp' | 'warp-kos'),
+    learning_rate, rho, epsilon, item_alpha, user_alpha, max_sampled, random_state.
+    """
+
+    def __init__(self, no_components=10, k=5, n=10, learning_schedule="adagrad", loss="logistic",
+                 learning_rate=0.05, rho=0.95, epsilon=1e-6, item_alpha=0.0, user_alpha=0.0,
+                 max_sampled=10, random_state=None):
+        # LFM:205-216
+        assert item_alpha >= 0.0
+        assert user_alpha >= 0.0
+        assert no_components > 0
+        assert k > 0
+        assert n > 0
+        assert 0 < rho < 1
+        assert epsilon >= 0
+        assert learning_schedule in ("adagrad", "adadelta")
+        assert loss in ("logistic", "warp", "bpr", "warp-kos")
+        if max_sampled < 1:
+            raise ValueError("max_sampled must be a positive integer")
+
+        self.loss = loss
+        self.learning_schedule = learning_schedule
+        self.no_components = no_components
+        self.learning_rate = learning_rate
+        self.k = int(k)
+        self.n = int(n)
+        self.rho = rho
+        self.epsilon = epsilon
+        self.max_sampled = max_sampled
+        self.item_alpha = item_alpha
+        self.user_alpha = user_alpha
+
+        if random_state is None:
+            self.random_state = np.random.RandomState()
+        elif isinstance(random_state, np.random.RandomState):
+            self.random_state = random_state
+        else:
+            self.random_state = np.random.RandomState(random_state)
+
+        self._reset_state()
+
+    # ------------------------------------------------------------------ state
+
+    def _reset_state(self):
+        for name in _WEIGHTS:
+            setattr(self, name, None)
+
+    def _check_initialized(self):
+        if any(getattr(self, name) is None for name in _WEIGHTS):
+            raise ValueError("You must fit the model before trying to obtain predictions.")
+
+    def _initialize(self, no_components, no_item_features, no_user_features):
+        """LFM:281-312 -- item table drawn first, then the user table."""
+        for side, rows in (("item", no_item_features), ("user", no_user_features)):
+            emb = ((self.random_state.rand(rows, no_components) - 0.5) / no_components).astype(
+                np.float32)
+            setattr(self, side + "_embeddings", emb)
+            setattr(self, side + "_embedding_gradients", np.zeros_like(emb))
+            setattr(self, side + "_embedding_momentum", np.zeros_like(emb))
+            setattr(self, side + "_biases", np.zeros(rows, dtype=np.float32))
+            setattr(self, side + "_bias_gradients", np.zeros(rows, dtype=np.float32))
+            setattr(self, side + "_bias_momentum", np.zeros(rows, dtype=np.float32))
+        if self.learning_schedule == "adagrad":
+            for side in ("item", "user"):
+                getattr(self, side + "_embedding_gradients")[...] += 1
+                getattr(self, side + "_bias_gradients")[...] += 1
+
+    def _construct_feature_matrices(self, n_users, n_items, user_features, item_features):
+        """LFM:314-363."""
+        if user_features is None:
+            user_features = sp.identity(n_users, dtype=CYTHON_DTYPE, format="csr")
+        else:
+            user_features = user_features.tocsr()
+        if item_features is None:
+            item_features = sp.identity(n_items, dtype=CYTHON_DTYPE, format="csr")
+        else:
+            item_features = item_features.tocsr()
+
+        if n_users > user_features.shape[0]:
+            raise Exception("Number of user feature rows does not equal the number of users")
+        if n_items > item_features.shape[0]:
+            raise Exception("Number of item feature rows does not equal the number of items")
+
+        # with existing embeddings, every supplied feature must have one
+        if self.user_embeddings is not None:
+            if not self.user_embeddings.shape[0] >= user_features.shape[1]:
+                raise ValueError(
+                    "The user feature matrix specifies more features than there are estimated "
+                    "feature embeddings: {} vs {}.".format(self.user_embeddings.shape[0],
+                                                           user_features.shape[1]))
+        if self.item_embeddings is not None:
+            if not self.item_embeddings.shape[0] >= item_features.shape[1]:
+                raise ValueError(
+                    "The item feature matrix specifies more features than there are estimated "
+                    "feature embeddings: {} vs {}.".format(self.item_embeddings.shape[0],
+                                                           item_features.shape[1]))
+
+        return self._to_cython_dtype(user_features), self._to_cython_dtype(item_features)
+
+    def _get_positives_lookup_matrix(self, interactions):
+        """LFM:365-372."""
+        mat = interactions.tocsr()
+        if not mat.has_sorted_indices:
+            return mat.sorted_indices()
+        return mat
+
+    def _to_cython_dtype(self, mat):
+        if mat.dtype != CYTHON_DTYPE:
+            return mat.astype(CYTHON_DTYPE)
+        return mat
+
+    def _process_sample_weight(self, interactions, sample_weight):
+        """LFM:381-420."""
+        if sample_weight is None:
+            if np.array_equiv(interactions.data, 1.0):
+                return interactions.data  # aliases Y, like the reference
+            return np.ones_like(interactions.data, dtype=CYTHON_DTYPE)
+
+        if self.loss == "warp-kos":
+            raise NotImplementedError("k-OS loss with sample weights not implemented.")
+        if not isinstance(sample_weight, sp.coo_matrix):
+            raise ValueError("Sample_weight must be a COO matrix.")
+        if sample_weight.shape != interactions.shape:
+            raise ValueError("Sample weight and interactions matrices must be the same shape")
+        if not (np.array_equal(interactions.row, sample_weight.row)
+                and np.array_equal(interactions.col, sample_weight.col)):
+            raise ValueError("Sample weight and interaction matrix entries must be in the same order")
+        if sample_weight.data.dtype != CYTHON_DTYPE:
+            return sample_weight.data.astype(CYTHON_DTYPE)
+        return sample_weight.data
+
+    def _get_lightfm_data(self):
+        """LFM:422-445."""
+        return FastLightFM(*[getattr(self, name) for name in _WEIGHTS], self.no_components,
+                           int(self.learning_schedule == "adadelta"), self.learning_rate, self.rho,
+                           self.epsilon, self.max_sampled)
+
+    def _check_finite(self):
+        """LFM:447-464 (host version; fit_partial uses the on-device check)."""
+        for parameter in (self.item_embeddings, self.item_biases, self.user_embeddings,
+                          self.user_biases):
+            if not np.isfinite(np.sum(parameter)):
+                raise ValueError(_NOT_FINITE)
+
+    def _check_input_finite(self, data):
+        if not np.isfinite(np.sum(data)):
+            raise ValueError("Not all input values are finite. "
+                             "Check the input for NaNs and infinite values.")
+
+    @staticmethod
+    def _progress(n, verbose):
+        """LFM:474-492."""
+        if not verbose:
+            return range(n)
+        try:
+            from tqdm import trange
+            return trange(n, desc="Epoch")
+        except ImportError:
+            def verbose_range():
+                for i in range(n):
+                    print("Epoch {}".format(i))
+                    yield i
+            return verbose_range()
+
+    # -------------------------------------------------------------------- fit
+
+    def fit(self, interactions, user_features=None, item_features=None, sample_weight=None,
+            epochs=1, num_threads=1, verbose=False):
+        """Fit from scratch (LFM:494-558).  Arguments as in the reference; `num_threads`
+        only sets how many seeds are drawn from `random_state` per epoch."""
+        self._reset_state()
+        return self.fit_partial(interactions, user_features=user_features,
+                                item_features=item_features, sample_weight=sample_weight,
+                                epochs=epochs, num_threads=num_threads, verbose=verbose)
+
+    def fit_partial(self, interactions, user_features=None, item_features=None,
+                    sample_weight=None, epochs=1, num_threads=1, verbose=False):
+        """Resume training from the current state (LFM:560-666)."""
+        interactions = interactions.tocoo()
+        if interactions.dtype != CYTHON_DTYPE:
+            interactions.data = interactions.data.astype(CYTHON_DTYPE)
+        sample_weight_data = self._process_sample_weight(interactions, sample_weight)
+
+        n_users, n_items = interactions.shape
+        user_features, item_features = self._construct_feature_matrices(
+            n_users, n_items, user_features, item_features)
+
+        for input_data in (user_features.data, item_features.data, interactions.data,
+                           sample_weight_data):
+            self._check_input_finite(input_data)
+
+        if self.item_embeddings is None:
+            self._initialize(self.no_components, item_features.shape[1], user_features.shape[1])
+
+        if not item_features.shape[1] == self.item_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in item_features")
+        if not user_features.shape[1] == self.user_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in user_features")
+        if num_threads < 1:
+            raise ValueError("Number of threads must be 1 or larger.")
+
+        self._run_epochs(item_features, user_features, interactions, sample_weight_data,
+                         num_threads, epochs, verbose)
+        return self
+
+    def _run_epochs(self, item_features, user_features, interactions, sample_weight, num_threads,
+                    epochs, verbose):
+        """The epoch loop of LFM:654-664 + _run_epoch (LFM:668-759) on one device session."""
+        if epochs <= 0:
+            return
+        loss = self.loss
+        positives = None
+        if loss in ("warp", "bpr", "warp-kos"):
+            # built before the shuffle indices, as in LFM:682-690
+            positives = CSRMatrix(self._get_positives_lookup_matrix(interactions))
+        rows = np.ascontiguousarray(interactions.row, dtype=np.int32)
+        cols = np.ascontiguousarray(interactions.col, dtype=np.int32)
+        data = interactions.data
+        n = len(data)
+
+        model = self._get_lightfm_data()
+        session = _Session(model, CSRMatrix(item_features), CSRMatrix(user_features))
+        try:
+            if loss == "warp-kos":
+                session.set_interactions(positives, rows, None, None, None)
+            else:
+                session.set_interactions(positives, rows, cols, data, sample_weight)
+            self._last_epoch_stats = []
+            for _ in self._progress(epochs, verbose=verbose):
+                shuffle_indices = np.arange(n, dtype=np.int32)
+                self.random_state.shuffle(shuffle_indices)
+                seeds = None
+                if loss != "logistic":  # _lightfm_fast.pyx.template:812-814
+                    seeds = np.ascontiguousarray(self.random_state.randint(
+                        0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
+                session.upload_shuffle(shuffle_indices)
+                opts, _ = make_opts()
+                session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts)
+                self._last_epoch_stats.append({"kernel_ms": float(opts.kernel_ms),
+                                               "counters": list(opts.counters)})
+                if not session.check_finite():  # LFM:664
+                    session.sync_to_host(model)
+                    raise ValueError(_NOT_FINITE)
+            session.sync_to_host(model)
+        finally:
+            session.close()
+
+    # ---------------------------------------------------------------- predict
+
+    def predict(self, user_ids, item_ids, item_features=None, user_features=None, num_threads=1):
+        """Scores for (user, item) PAIRS (LFM:761-872)."""
+        self._check_initialized()
+
+        if isinstance(user_ids, int):
+            user_ids = np.repeat(np.int32(user_ids), len(item_ids))
+        if isinstance(user_ids, (list, tuple)):
+            user_ids = np.array(user_ids, dtype=np.int32)
+        if isinstance(item_ids, (list, tuple)):
+            item_ids = np.array(item_ids, dtype=np.int32)
+
+        if len(user_ids) != len(item_ids):
+            raise ValueError(
+                f"Expected the number of user IDs ({len(user_ids)}) to equal the number"
+                f" of item IDs ({len(item_ids)})")
+
+        if user_ids.dtype != np.int32:
+            user_ids = user_ids.astype(np.int32)
+        if item_ids.dtype != np.int32:
+            item_ids = item_ids.astype(np.int32)
+        if num_threads < 1:
+            raise ValueError("Number of threads must be 1 or larger.")
+        if user_ids.min() < 0 or item_ids.min() < 0:
+            raise ValueError("User or item ids cannot be negative. Check your inputs for negative "
+                             "numbers or very large numbers that can overflow.")
+
+        n_users = user_ids.max() + 1
+        n_items = item_ids.max() + 1
+        user_features, item_features = self._construct_feature_matrices(
+            n_users, n_items, user_features, item_features)
+
+        predictions = np.empty(len(user_ids), dtype=np.float32)
+        predict_lightfm(CSRMatrix(item_features), CSRMatrix(user_features),
+                        np.ascontiguousarray(user_ids), np.ascontiguousarray(item_ids),
+                        predictions, self._get_lightfm_data(), num_threads)
+        return predictions
+
+    def _check_test_train_intersections(self, test_mat, train_mat):
+        if train_mat is not None:
+            n_intersections = test_mat.multiply(train_mat).nnz
+            if n_intersections:
+                raise ValueError(
+                    "Test interactions matrix and train interactions matrix share %d "
+                    "interactions. This will cause incorrect evaluation, check your data split."
+                    % n_intersections)
+
+    def predict_rank(self, test_interactions, train_interactions=None, item_features=None,
+                     user_features=None, num_threads=1, check_intersections=True):
+        """Rank of every test interaction among all items, 0 = best (LFM:884-989)."""
+        self._check_initialized()
+        if num_threads < 1:
+            raise ValueError("Number of threads must be 1 or larger.")
+        if check_intersections:
+            self._check_test_train_intersections(test_interactions, train_interactions)
+
+        n_users, n_items = test_interactions.shape
+        user_features, item_features = self._construct_feature_matrices(
+            n_users, n_items, user_features, item_features)
+        if not item_features.shape[1] == self.item_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in item_features")
+        if not user_features.shape[1] == self.user_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in user_features")
+
+        test_interactions = self._to_cython_dtype(test_interactions.tocsr())
+        if train_interactions is None:
+            train_interactions = sp.csr_matrix((n_users, n_items), dtype=CYTHON_DTYPE)
+        else:
+            train_interactions = self._to_cython_dtype(train_interactions.tocsr())
+
+        ranks = sp.csr_matrix((np.zeros_like(test_interactions.data), test_interactions.indices,
+                               test_interactions.indptr), shape=test_interactions.shape)
+        predict_ranks(CSRMatrix(item_features), CSRMatrix(user_features),
+                      CSRMatrix(test_interactions), CSRMatrix(train_interactions), ranks.data,
+                      self._get_lightfm_data(), num_threads)
+        return ranks
+
+    # -------------------------------------------------------- representations
+
+    def get_item_representations(self, features=None):
+        """(biases, embeddings) of items, optionally through a feature matrix (LFM:991-1018)."""
+        self._check_initialized()
+        if features is None:
+            return self.item_biases, self.item_embeddings
+        features = sp.csr_matrix(features, dtype=CYTHON_DTYPE)
+        return features * self.item_biases, features * self.item_embeddings
+
+    def get_user_representations(self, features=None):
+        """(biases, embeddings) of users (LFM:1020-1047)."""
+        self._check_initialized()
+        if features is None:
+            return self.user_biases, self.user_embeddings
+        features = sp.csr_matrix(features, dtype=CYTHON_DTYPE)
+        return features * self.user_biases, features * self.user_embeddings
+
+    # ---------------------------------------------------------------- sklearn
+
+    def get_params(self, deep=True):
+        """LFM:1049-1080."""
+        return {"loss": self.loss, "learning_schedule": self.learning_schedule,
+                "no_components": self.no_components, "learning_rate": self.learning_rate,
+                "k": self.k, "n": self.n, "rho": self.rho, "epsilon": self.epsilon,
+                "max_sampled": self.max_sampled, "item_alpha": self.item_alpha,
+                "user_alpha": self.user_alpha, "random_state": self.random_state}
+
+    def set_params(self, **params):
+        """LFM:1082-1107."""
+        valid_params = self.get_params()
+        for key, value in params.items():
+            if key not in valid_params:
+                raise ValueError(
+                    "Invalid parameter %s for estimator %s. Check the list of available "
+                    "parameters with `estimator.get_params().keys()`."
+                    % (key, self.__class__.__name__))
+            setattr(self, key, value)
+        return self

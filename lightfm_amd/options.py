@@ -5,6 +5,7 @@ mode               "parallel" (default): Hogwild over thousands of wavefronts, o
                    reference's order with its rand_r streams -- bit-exact, for parity tests.
 launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
 first_batch        negatives scored speculatively in the first batch (0 = auto).
+max_waves          cap on wavefronts (interactions) in flight, parallel mode (0 = auto).
 log_samples        record (negative, sampled) per shuffled position into last_logs.
 device_shuffle     LightFM.fit_partial only: see lightfm.py.
 
@@ -18,6 +19,7 @@ class _Options(object):
         self.mode = os.environ.get("LIGHTFM_AMD_MODE", "parallel")
         self.launches_per_epoch = int(os.environ.get("LIGHTFM_AMD_LAUNCHES", "0"))
         self.first_batch = int(os.environ.get("LIGHTFM_AMD_FIRST_BATCH", "0"))
+        self.max_waves = int(os.environ.get("LIGHTFM_AMD_MAX_WAVES", "0"))
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None

@@ -1,0 +1,65 @@
+"""precision@10 of the HIP backend vs the reference CPU path on the same synthetic
+data, across in-flight-wave caps (staleness study).  Runs on the GPU box.
+
+    python tools/quality.py [dataset] [epochs] [d]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from lightfm_amd import LightFM, options, synthetic
+from lightfm_amd.evaluation import precision_at_k
+from oracle.ref_model import RefLightFM
+
+name = sys.argv[1] if len(sys.argv) > 1 else "ml-100k"
+epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+loss = sys.argv[4] if len(sys.argv) > 4 else "warp"
+caps = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0, 64, 256, 1024, 8192]
+
+if name in synthetic.SHAPES:
+    data = synthetic.named(name)
+else:
+    nu, ni, nnz = [int(x) for x in name.split("x")]
+    data = synthetic.make_interactions(nu, ni, nnz)
+train, test = synthetic.train_test_split(data, 0.1, seed=1)
+print("data", name, data.shape, "train", train.nnz, "test", test.nnz, flush=True)
+
+
+def evaluate(m):
+    ptr = precision_at_k(m, train, k=10).mean()
+    pte = precision_at_k(m, test, train_interactions=train, k=10).mean()
+    return ptr, pte
+
+
+for threads in (1, os.cpu_count()):
+    res = []
+    for seed in (1, 2, 3):
+        m = RefLightFM(no_components=d, loss=loss, random_state=seed)
+        t = time.time()
+        m.fit(train, epochs=epochs, num_threads=threads)
+        dt = time.time() - t
+        res.append(evaluate(m) + (dt,))
+    r = np.array(res)
+    print("ref threads=%-3d p@10 train %.4f test %.4f (std %.4f)  %.2fs/fit  %.3g inter/s" % (
+        threads, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 2].mean(),
+        train.nnz * epochs / r[:, 2].mean()), flush=True)
+
+for cap in caps:
+    res = []
+    for seed in (1, 2, 3):
+        options.set(mode="parallel", max_waves=cap)
+        m = LightFM(no_components=d, loss=loss, random_state=seed)
+        m.fit(train, epochs=epochs, num_threads=1)
+        ms = sum(s["kernel_ms"] for s in m._last_epoch_stats)
+        draws = sum(s["counters"][1] for s in m._last_epoch_stats)
+        upd = sum(s["counters"][2] for s in m._last_epoch_stats)
+        res.append(evaluate(m) + (ms, draws, upd))
+    r = np.array(res)
+    print("hip max_waves=%-5d p@10 train %.4f test %.4f (std %.4f)  kernel %.2f ms/epoch  %.3g inter/s  draws/inter %.2f upd/inter %.2f" % (
+        cap, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 2].mean() / epochs,
+        train.nnz * epochs / (r[:, 2].mean() / 1e3), r[:, 3].mean() / (train.nnz * epochs),
+        r[:, 4].mean() / (train.nnz * epochs)), flush=True)
