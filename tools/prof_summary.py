@@ -1,0 +1,76 @@
+"""Turn rocprofv3's rocpd sqlite outputs (gpurun_out/prof_<tag>/...) into the small
+text/JSON summaries committed under profiles/.
+
+    python tools/prof_summary.py <tag>
+"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+lines = []
+trace = os.path.join(src, "trace", "trace_results.db")
+if os.path.exists(trace):
+    rows = q(trace, "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+                    "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
+                    "from kernels group by name order by sum(duration) desc")
+    tot = sum(r[2] for r in rows) or 1
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py   (tag %s)" % tag)
+    lines.append("%-60s %6s %12s %12s %12s %12s %6s %5s %5s %7s %9s" % (
+        "kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct", "vgpr", "sgpr", "lds_B", "grid"))
+    for r in rows:
+        lines.append("%-60s %6d %12.3f %12.1f %12.1f %12.1f %6.2f %5d %5d %7d %9d" % (
+            r[0][:60], r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot,
+            r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
+    bj = os.path.join(src, "bench_trace.json")
+    if os.path.exists(bj):
+        lines.append("")
+        lines.append("# bench.py JSON line of the same (profiled) run:")
+        lines.append(open(bj).read().strip())
+    open(os.path.join(dst, "%s_kernel_stats.txt" % tag), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+
+pmc = {}
+for sub in sorted(os.listdir(src)):
+    db = os.path.join(src, sub, "pmc_results.db")
+    if not os.path.exists(db):
+        continue
+    rows = q(db, "select k.name, p.counter_name, count(*), sum(p.counter_value) from pmc_events p "
+                 "join kernels k on k.dispatch_id = p.dispatch_id "
+                 "group by k.name, p.counter_name order by k.name")
+    for name, cname, cnt, val in rows:
+        if "fit_" not in name:
+            continue
+        pmc.setdefault(name, {})[cname] = {"dispatches": cnt, "sum": val, "per_launch": val / cnt}
+summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --pmc <counter(s)> -- python bench.py --steps 2 "
+                                  "--warmup 1 --no-cpu-baseline (one pass per counter group)",
+           "kernels": pmc}
+for name, c in pmc.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3); on gfx950 FETCH_SIZE counts
+        # 128-B requests at 64 B (MI355X_MICROARCH.md "HBM"): the x2 correction applies to wide
+        # coalesced streams; this kernel's reads are 4 B/lane row gathers (256-B rows), so both
+        # the raw and the x2-corrected figures are recorded.
+        f, w = c["FETCH_SIZE"]["per_launch"] * 1024.0, c["WRITE_SIZE"]["per_launch"] * 1024.0
+        summary["hbm_bytes_per_launch_raw"] = f + w
+        summary["hbm_bytes_per_launch"] = 2 * f + w
+        summary["fetch_bytes_per_launch_raw"] = f
+        summary["write_bytes_per_launch"] = w
+json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True)[:3000])
