@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 20M interactions (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves"):
+        ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +124,11 @@ def main():
     from lightfm_amd.lightfm import LightFM, _Session
     import scipy.sparse as sp
 
+    from lightfm_amd import options
+    tuned = {k: getattr(args, k) for k in ("update_mode", "occupancy", "first_batch",
+                                           "launches_per_epoch", "max_waves")
+             if getattr(args, k) is not None}
+    options.set(**tuned)
     if N.device_count() <= local_rank:
         raise SystemExit("no HIP device for local rank %d" % local_rank)
     dev_name, cus, hbm = N.device_info(local_rank)
@@ -239,6 +246,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if tuned:
+            out["config"]["non_default_options"] = tuned
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out), flush=True)

@@ -74,6 +74,12 @@ typedef struct lfm_opts {
     int32_t *sampled_log;       /* host [n] or NULL: draws consumed per shuffled position */
     int64_t counters[4];        /* out: positives visited, draws, updates, in_positives probes */
     float kernel_ms;            /* out: device time of the epoch's kernels (HIP events)   */
+    int32_t update_mode;        /* parallel mode: 0 = publish deltas with global_atomic_add_f32
+                                   (default), 1 = plain load/store Hogwild (lost updates
+                                   possible), 2 = compute but do not write (profiling ablation) */
+    int32_t occupancy;          /* wavefronts per SIMD the identity-feature WARP kernel is
+                                   compiled for: 0 = auto, 4, 6 or 8                           */
+    int32_t pad_[2];
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -83,6 +83,8 @@ def make_opts(n=0, want_log=False):
     o.launches_per_epoch = int(options.launches_per_epoch)
     o.first_batch = int(options.first_batch)
     o.max_waves = int(options.max_waves)
+    o.update_mode = int(options.update_mode)
+    o.occupancy = int(options.occupancy)
     logs = None
     if want_log:
         logs = (np.full(n, -1, np.int32), np.zeros(n, np.int32))

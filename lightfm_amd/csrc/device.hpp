@@ -56,6 +56,7 @@ struct FitArgs {
     int32_t seed_idx;      // serial mode: which per-thread stream this launch continues
     const double *logtab;  // [max_sampled+1] log term of the WARP loss, host libm
     int32_t serial;
+    int32_t update_mode;   // 0 atomic deltas, 1 plain stores, 2 no writes (ablation)
     int32_t tile_rows, tile_stride, first_batch;
     int32_t k, n_pos;      // k-OS
     int32_t pair_cap;      // k-OS: LDS pair slots per wave
@@ -144,9 +145,9 @@ __device__ __forceinline__ float ldw(const float *p)
 
 // PYX:270-284 as a 64-ary search: each round the wave probes 64 evenly spaced
 // entries of the sorted row, so rows up to 4096 long need 2 dependent loads.
-__device__ __forceinline__ bool in_positives(const DCsr &p, int item, int user, int lane)
+// [lo, hi) = indptr[user], indptr[user+1] (callers prefetch them).
+__device__ __forceinline__ bool in_positives_range(const DCsr &p, int item, int lo, int hi, int lane)
 {
-    int lo = uni(p.indptr[user]), hi = uni(p.indptr[user + 1]);
     while (hi - lo > WAVE) {
         int step = (hi - lo + WAVE - 1) >> 6;
         int idx = lo + lane * step;
@@ -163,6 +164,11 @@ __device__ __forceinline__ bool in_positives(const DCsr &p, int item, int user, 
     return __ballot(hit) != 0ull;
 }
 
+__device__ __forceinline__ bool in_positives(const DCsr &p, int item, int user, int lane)
+{
+    return in_positives_range(p, item, uni(p.indptr[user]), uni(p.indptr[user + 1]), lane);
+}
+
 template <int NC>
 struct Rep {
     float v[NC];  // component lane+64q
@@ -171,12 +177,12 @@ struct Rep {
 
 // compute_representation, PYX:287-317 (w = (float)((double)data*scale), C_OMP:4896;
 // float32 multiply then add, features in CSR order).
-template <int NC>
+template <int NC, bool IDENT = false>
 __device__ __forceinline__ void load_rep(const DCsr &f, const float *W, const float *b, int d,
                                          int row, double scale, int lane, Rep<NC> &r)
 {
-    if (f.identity) {
-        float w = (float)(1.0 * scale);
+    if (IDENT || f.identity) {
+        float w = IDENT ? 1.0f : (float)(1.0 * scale);
         const float *wr = W + (size_t)row * d;
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
@@ -261,17 +267,14 @@ struct Hyper {
     float lr, rho, eps;
 };
 
-// One optimizer cell: PYX:416-449 with the float64 promotions of C_OMP:5340-5560.
-// `atomic`: publish new-old with global_atomic_add_f32 (exactly the new value when
-// nobody else touched the cell); otherwise plain stores (serial mode).
-__device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, double w, double g,
-                                              const Hyper &h, double alpha, bool atomic)
+// One optimizer cell: PYX:416-449 with the float64 promotions of C_OMP:5340-5560,
+// as a pure function of the old (W, G, M) values.
+__device__ __forceinline__ void cell_math(float oW, float oG, float oM, double w, double g,
+                                          const Hyper &h, double alpha, float &nW, float &nG,
+                                          float &nM, double &lr)
 {
-    float oW = ldw(Wp), oG = ldw(Gp);
-    float nW, nG;
-    double lr;
+    nM = oM;
     if (h.adadelta) {
-        float oM = ldw(Mp);
         float rg = __fmul_rn(h.rho, oG);
         double wg = w * g;
         nG = (float)((double)rg + (1.0 - (double)h.rho) * (wg * wg));
@@ -279,14 +282,8 @@ __device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, d
         lr = sqrt((double)me) / sqrt((double)ge);
         double upd = (lr * g) * w;
         float rm = __fmul_rn(h.rho, oM);
-        float nM = (float)((double)rm + (1.0 - (double)h.rho) * (upd * upd));
+        nM = (float)((double)rm + (1.0 - (double)h.rho) * (upd * upd));
         nW = (float)((double)oW - upd);
-        if (atomic) {
-            float dM = __fsub_rn(nM, oM);
-            if (dM != 0.0f) atomicAdd(Mp, dM);
-        } else {
-            *Mp = nM;
-        }
     } else {
         lr = (double)h.lr / sqrt((double)oG);
         nW = (float)((double)oW - (lr * w) * g);
@@ -294,13 +291,37 @@ __device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, d
         nG = (float)((double)oG + gw * gw);
     }
     nW = (float)((double)nW * (1.0 + alpha * lr));
+}
+
+// Publish new-old with global_atomic_add_f32: exactly the new value when nobody else
+// touched the cell in between (Hogwild otherwise).
+__device__ __forceinline__ void publish(float *p, float nv, float ov, int mode = 0)
+{
+    if (mode == 0) {
+        float dlt = __fsub_rn(nv, ov);
+        if (dlt != 0.0f) atomicAdd(p, dlt);
+    } else if (mode == 1) {
+        if (nv != ov) *p = nv;
+    }
+}
+
+// Load-compute-store of one cell.  `atomic`: publish deltas; otherwise plain stores
+// (serial mode).
+__device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, double w, double g,
+                                              const Hyper &h, double alpha, bool atomic)
+{
+    float oW = ldw(Wp), oG = ldw(Gp), oM = h.adadelta ? ldw(Mp) : 0.0f;
+    float nW, nG, nM;
+    double lr;
+    cell_math(oW, oG, oM, w, g, h, alpha, nW, nG, nM, lr);
     if (atomic) {
-        float dW = __fsub_rn(nW, oW), dG = __fsub_rn(nG, oG);
-        if (dW != 0.0f) atomicAdd(Wp, dW);
-        if (dG != 0.0f) atomicAdd(Gp, dG);
+        publish(Wp, nW, oW);
+        publish(Gp, nG, oG);
+        if (h.adadelta) publish(Mp, nM, oM);
     } else {
         *Wp = nW;
         *Gp = nG;
+        if (h.adadelta) *Mp = nM;
     }
     return lr;
 }
@@ -450,6 +471,72 @@ __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int u
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
         avg /= (double)cells;
         apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
+    }
+}
+
+// warp_update for identity features on both sides with alpha == 0 (so every
+// representation IS the embedding row), parallel mode: all loads are issued first
+// (three G rows + the three bias cells, one per lane 0..2), then the maths, then the
+// atomics -- one memory round trip instead of six.  Same arithmetic as warp_update.
+template <int NC>
+__device__ __forceinline__ void warp_update_identity(double loss, const FitArgs &a, int user,
+                                                     int pos, int neg, const Rep<NC> &U,
+                                                     const Rep<NC> &P, const Rep<NC> &N, int lane)
+{
+    const Hyper h{a.m.adadelta, a.m.lr, a.m.rho, a.m.eps};
+    const int d = a.m.d, um = a.update_mode;
+    const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu = (size_t)user * d;
+    float *Wi = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
+    float *Wu = a.m.W[1], *Gu = a.m.G[1], *Mu = a.m.M[1];
+    float gP[NC], gN[NC], gU[NC], mP[NC], mN[NC], mU[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        int c = lane + WAVE * q;
+        bool ok = c < d;
+        gP[q] = ok ? ldw(Gi + bp + c) : 1.0f;
+        gN[q] = ok ? ldw(Gi + bn + c) : 1.0f;
+        gU[q] = ok ? ldw(Gu + bu + c) : 1.0f;
+        mP[q] = (ok && h.adadelta) ? ldw(Mi + bp + c) : 0.0f;
+        mN[q] = (ok && h.adadelta) ? ldw(Mi + bn + c) : 0.0f;
+        mU[q] = (ok && h.adadelta) ? ldw(Mu + bu + c) : 0.0f;
+    }
+    // bias cells: lane 0 = positive item (g = -loss), 1 = negative item, 2 = user (PYX:571-599)
+    const int side = lane == 2 ? 1 : 0;
+    const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
+    float *bW = a.m.b[side] + brow, *bG = a.m.bG[side] + brow, *bM = a.m.bM[side] + brow;
+    float obW = 0.0f, obG = 1.0f, obM = 0.0f;
+    if (lane < 3) {
+        obW = ldw(bW);
+        obG = ldw(bG);
+        if (h.adadelta) obM = ldw(bM);
+    }
+    float nW, nG, nM;
+    double lr;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        int c = lane + WAVE * q;
+        if (c < d) {
+            double u = (double)U.v[q];
+            cell_math(P.v[q], gP[q], mP[q], 1.0, -loss * u, h, 0.0, nW, nG, nM, lr);
+            publish(Wi + bp + c, nW, P.v[q], um);
+            publish(Gi + bp + c, nG, gP[q], um);
+            if (h.adadelta) publish(Mi + bp + c, nM, mP[q], um);
+            cell_math(N.v[q], gN[q], mN[q], 1.0, loss * u, h, 0.0, nW, nG, nM, lr);
+            publish(Wi + bn + c, nW, N.v[q], um);
+            publish(Gi + bn + c, nG, gN[q], um);
+            if (h.adadelta) publish(Mi + bn + c, nM, mN[q], um);
+            double df = (double)__fsub_rn(N.v[q], P.v[q]);
+            cell_math(U.v[q], gU[q], mU[q], 1.0, loss * df, h, 0.0, nW, nG, nM, lr);
+            publish(Wu + bu + c, nW, U.v[q], um);
+            publish(Gu + bu + c, nG, gU[q], um);
+            if (h.adadelta) publish(Mu + bu + c, nM, mU[q], um);
+        }
+    }
+    if (lane < 3) {
+        cell_math(obW, obG, obM, 1.0, lane == 0 ? -loss : loss, h, 0.0, nW, nG, nM, lr);
+        publish(bW, nW, obW, um);
+        publish(bG, nG, obG, um);
+        if (h.adadelta) publish(bM, nM, obM, um);
     }
 }
 

@@ -103,11 +103,11 @@ __device__ __forceinline__ void wave_end(const FitArgs &a, WaveCtx &w, Scales &s
 // interaction the weights do not change between draws, so taking the first
 // violator of a batch is identical to the sequential loop; the PRNG is advanced by
 // exactly the number of draws the sequential loop would have made.
-template <int NC>
+template <int NC, bool FAST>
 __device__ __forceinline__ void warp_negatives(const FitArgs &a, WaveCtx &w, Scales &sc, int64_t i,
                                                int user, int pos, double pp, float weight,
                                                bool kos, uint32_t &state, const Rep<NC> &U,
-                                               const Rep<NC> &P)
+                                               const Rep<NC> &P, int pos_lo, int pos_hi)
 {
     const int lane = w.lane, d = a.m.d, TS = w.TS;
     const int max_sampled = a.m.max_sampled;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void warp_negatives(const FitArgs &a, WaveCtx &w, Sca
         for (int k = 0; k < nb; ++k) {
             int neg = read_lane(myneg, k);
             Rep<NC> N;
-            load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, neg, sc.item, lane, N);
+            load_rep<NC, FAST>(a.itf, a.m.W[0], a.m.b[0], d, neg, sc.item, lane, N);
             rep_to_tile<NC>(w.tile + (size_t)(2 + k) * TS, N, d, lane);
         }
         wave_sync();
@@ -139,7 +139,7 @@ __device__ __forceinline__ void warp_negatives(const FitArgs &a, WaveCtx &w, Sca
             mask &= mask - 1;
             int neg = read_lane(myneg, slot - 2);
             w.c3++;
-            if (in_positives(a.pos, neg, user, lane)) continue;  // PYX:878-879, draw counted
+            if (in_positives_range(a.pos, neg, pos_lo, pos_hi, lane)) continue;  // PYX:878-879, draw counted
             chosen = neg;
             chosen_slot = slot;
             used = slot - 1;
@@ -157,7 +157,10 @@ __device__ __forceinline__ void warp_negatives(const FitArgs &a, WaveCtx &w, Sca
         Rep<NC> N;
         rep_from_tile<NC>(w.tile + (size_t)chosen_slot * TS, d, lane, N);
         wave_sync();
-        warp_update<NC>(loss, a, user, pos, chosen, U, P, N, sc, lane);
+        if constexpr (FAST)
+            warp_update_identity<NC>(loss, a, user, pos, chosen, U, P, N, lane);
+        else
+            warp_update<NC>(loss, a, user, pos, chosen, U, P, N, sc, lane);
         w.c2++;
     }
     log_pos(a, i, chosen, sampled, lane);
@@ -167,41 +170,81 @@ __device__ __forceinline__ void warp_negatives(const FitArgs &a, WaveCtx &w, Sca
 
 // ------------------------------------------------------------------ WARP ---
 
-template <int NC>
-__global__ __launch_bounds__(256) void fit_warp_kernel(FitArgs a)
+// One interaction of fit_warp (PYX:826-904); its COO fields arrive prefetched.
+template <int NC, bool FAST>
+__device__ __forceinline__ void warp_example(const FitArgs &a, WaveCtx &w, Scales &sc, int64_t i,
+                                             int user, int pos, float y, float weight,
+                                             uint32_t &state, uint32_t base_seed)
+{
+    const int lane = w.lane, d = a.m.d, TS = w.TS;
+    if (!(y > 0.0f)) {  // PYX:831-832, before any RNG use
+        log_pos(a, i, -1, 0, lane);
+        return;
+    }
+    if (FAST || !a.serial) state = position_seed(base_seed, (uint64_t)i);
+    w.c0++;
+    // issued together with the row gathers; consumed by in_positives after the dots
+    int pos_lo = a.pos.indptr[user], pos_hi = a.pos.indptr[user + 1];
+    Rep<NC> U, P;
+    load_rep<NC, FAST>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
+    load_rep<NC, FAST>(a.itf, a.m.W[0], a.m.b[0], d, pos, sc.item, lane, P);
+    rep_to_tile<NC>(w.tile, U, d, lane);
+    rep_to_tile<NC>(w.tile + TS, P, d, lane);
+    wave_sync();
+    float ps = 0.0f;
+    if (lane == 1) ps = tile_dot(w.tile, w.tile + TS, d);
+    double pp = (double)read_lanef(ps, 1);
+    warp_negatives<NC, FAST>(a, w, sc, i, user, pos, pp, weight, false, state, U, P, uni(pos_lo),
+                             uni(pos_hi));
+    if constexpr (!FAST) after_example(a, sc, lane);
+}
+
+// FAST: parallel mode, identity features on both sides, no regularisation (the
+// representations ARE embedding rows; BASELINE configs C2/C4).  Otherwise generic.
+template <int NC, bool FAST, int OCC>
+__global__ __launch_bounds__(256, OCC) void fit_warp_kernel(FitArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     WaveCtx w;
     Scales sc;
     wave_begin(a, w, sc, smem);
-    const int lane = w.lane, d = a.m.d, TS = w.TS;
+    const int lane = w.lane;
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    uint32_t state = a.serial ? a.seeds[a.seed_idx] : 0u;
+    uint32_t state = (!FAST && a.serial) ? a.seeds[a.seed_idx] : 0u;
     const uint32_t base_seed = a.seeds[0];
-    for (int64_t i = a.begin + gw; i < a.end; i += nw) {
-        int row = uni(a.shuffle[i]);
-        if (!(a.Y[row] > 0.0f)) {  // PYX:831-832
-            log_pos(a, i, -1, 0, lane);
-            continue;
-        }
-        int user = uni(a.user_ids[row]), pos = uni(a.item_ids[row]);
-        float weight = unif(a.weight[row]);
-        if (!a.serial) state = position_seed(base_seed, (uint64_t)i);
-        w.c0++;
-        Rep<NC> U, P;
-        load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
-        load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, pos, sc.item, lane, P);
-        rep_to_tile<NC>(w.tile, U, d, lane);
-        rep_to_tile<NC>(w.tile + TS, P, d, lane);
-        wave_sync();
-        float ps = 0.0f;
-        if (lane == 1) ps = tile_dot(w.tile, w.tile + TS, d);
-        double pp = (double)read_lanef(ps, 1);
-        warp_negatives<NC>(a, w, sc, i, user, pos, pp, weight, false, state, U, P);
-        after_example(a, sc, lane);
+    // two-deep software pipeline over the COO: while interaction i is processed, the
+    // (user, item, y, weight) of i+nw and the shuffle entry of i+2nw are in flight
+    int64_t i = a.begin + gw;
+    int row1 = 0, c_user = 0, c_pos = 0;
+    float c_y = 0.0f, c_w = 0.0f;
+    if (i < a.end) {
+        int row0 = a.shuffle[i];
+        c_user = a.user_ids[row0];
+        c_pos = a.item_ids[row0];
+        c_y = a.Y[row0];
+        c_w = a.weight[row0];
     }
-    if (a.serial && lane == 0) const_cast<uint32_t *>(a.seeds)[a.seed_idx] = state;
+    if (i + nw < a.end) row1 = a.shuffle[i + nw];
+    for (; i < a.end; i += nw) {
+        int row2 = 0, n_user = 0, n_pos = 0;
+        float n_y = 0.0f, n_w = 0.0f;
+        if (i + 2 * nw < a.end) row2 = a.shuffle[i + 2 * nw];
+        if (i + nw < a.end) {
+            n_user = a.user_ids[row1];
+            n_pos = a.item_ids[row1];
+            n_y = a.Y[row1];
+            n_w = a.weight[row1];
+        }
+        warp_example<NC, FAST>(a, w, sc, i, uni(c_user), uni(c_pos), unif(c_y), unif(c_w), state,
+                               base_seed);
+        row1 = row2;
+        c_user = n_user;
+        c_pos = n_pos;
+        c_y = n_y;
+        c_w = n_w;
+    }
+    if (!FAST && a.serial && lane == 0) const_cast<uint32_t *>(a.seeds)[a.seed_idx] = state;
     wave_end(a, w, sc);
 }
 
@@ -375,7 +418,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
         load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, pos, sc.item, lane, P);
         rep_to_tile<NC>(w.tile + TS, P, d, lane);
         wave_sync();
-        warp_negatives<NC>(a, w, sc, i, user, pos, pp, 1.0f, true, state, U, P);
+        warp_negatives<NC, false>(a, w, sc, i, user, pos, pp, 1.0f, true, state, U, P, start, stop);
         after_example(a, sc, lane);
     }
     if (a.serial && lane == 0) const_cast<uint32_t *>(a.seeds)[a.seed_idx] = state;
@@ -435,13 +478,38 @@ __global__ void nonfinite_kernel(const float *x, int64_t n, int *flag)
 
 // ---------------------------------------------------------------- launch ---
 
+// Launch with the grid capped at what is actually resident (blocks/CU from the
+// occupancy query x CUs): every wavefront then runs its grid-stride loop from the
+// start of the launch instead of queueing behind a first wave of blocks.
+template <typename K>
+static hipError_t launch_resident(K kernel, const FitArgs &a, int grid, int block, size_t smem,
+                                  hipStream_t st, int cus)
+{
+    if (cus > 0 && block == 256) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) == hipSuccess &&
+            per_cu > 0)
+            grid = std::min(grid, per_cu * cus);
+    }
+    kernel<<<grid, block, smem, st>>>(a);
+    return hipGetLastError();
+}
+
 template <int NC>
 static hipError_t launch_nc(int loss, const FitArgs &a, int grid, int block, size_t smem,
-                            hipStream_t st)
+                            hipStream_t st, int occupancy, int cus)
 {
     switch (loss) {
     case 0: fit_logistic_kernel<NC><<<grid, block, smem, st>>>(a); break;
-    case 1: fit_warp_kernel<NC><<<grid, block, smem, st>>>(a); break;
+    case 1:
+        if (!a.serial && a.itf.identity && a.usf.identity && a.item_alpha == 0.0 && a.user_alpha == 0.0) {
+            if constexpr (NC <= 2) {
+                if (occupancy == 8) return launch_resident(fit_warp_kernel<NC, true, 8>, a, grid, block, smem, st, cus);
+                if (occupancy == 6) return launch_resident(fit_warp_kernel<NC, true, 6>, a, grid, block, smem, st, cus);
+            }
+            return launch_resident(fit_warp_kernel<NC, true, 1>, a, grid, block, smem, st, cus);
+        }
+        return launch_resident(fit_warp_kernel<NC, false, 1>, a, grid, block, smem, st, cus);
     case 2: fit_bpr_kernel<NC><<<grid, block, smem, st>>>(a); break;
     case 3: fit_warp_kos_kernel<NC><<<grid, block, smem, st>>>(a); break;
     default: return hipErrorInvalidValue;
@@ -449,13 +517,14 @@ static hipError_t launch_nc(int loss, const FitArgs &a, int grid, int block, siz
     return hipGetLastError();
 }
 
-hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st)
+hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
+                      int occupancy, int cus)
 {
     int d = a.m.d;
-    if (d <= 64) return launch_nc<1>(loss, a, grid, block, smem, st);
-    if (d <= 128) return launch_nc<2>(loss, a, grid, block, smem, st);
-    if (d <= 256) return launch_nc<4>(loss, a, grid, block, smem, st);
-    if (d <= 512) return launch_nc<8>(loss, a, grid, block, smem, st);
+    if (d <= 64) return launch_nc<1>(loss, a, grid, block, smem, st, occupancy, cus);
+    if (d <= 128) return launch_nc<2>(loss, a, grid, block, smem, st, occupancy, cus);
+    if (d <= 256) return launch_nc<4>(loss, a, grid, block, smem, st, occupancy, cus);
+    if (d <= 512) return launch_nc<8>(loss, a, grid, block, smem, st, occupancy, cus);
     return hipErrorInvalidValue;
 }
 

@@ -22,7 +22,8 @@ struct RanksArgs {
     float *ranks;           // aligned with test.data
 };
 
-hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st);
+hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
+                      int occupancy = 0, int cus = 0);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
 hipError_t launch_regularize(const DModel &m, int force, hipStream_t st);
 hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);

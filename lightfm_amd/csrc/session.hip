@@ -539,6 +539,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     a.item_alpha = item_alpha;
     a.user_alpha = user_alpha;
     a.serial = serial ? 1 : 0;
+    a.update_mode = serial ? 0 : opts->update_mode;
+    const int occupancy = opts->occupancy;
     a.k = k;
     a.n_pos = n_positives;
     a.counters = s->counters.p;
@@ -565,7 +567,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     int want_rows = (loss == LFM_LOSS_WARP || loss == LFM_LOSS_WARP_KOS) ? s->max_sampled + 2 : 3;
     if (loss == LFM_LOSS_WARP_KOS) want_rows = std::max(want_rows, std::min(n_positives, 15) + 1);
     tile_geometry(s->d, want_rows, &a.tile_rows, &a.tile_stride);
-    a.first_batch = opts->first_batch > 0 ? opts->first_batch : 4;
+    a.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;  // auto: score every allowed draw in one batch
     a.first_batch = std::max(1, std::min(a.first_batch, a.tile_rows - 2));
     a.pair_cap = (loss == LFM_LOSS_WARP_KOS) ? ((n_positives + 3) / 4) * 4 : 0;
     size_t smem = sizeof(float) * ((size_t)WAVES_PER_BLOCK * a.tile_rows * a.tile_stride +
@@ -606,7 +608,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (a.end <= a.begin) continue;
             int64_t waves = a.end - a.begin;
             int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream));
+            HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
                 HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904

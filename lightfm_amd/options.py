@@ -6,6 +6,8 @@ mode               "parallel" (default): Hogwild over thousands of wavefronts, o
 launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
 first_batch        negatives scored speculatively in the first batch (0 = auto).
 max_waves          cap on wavefronts (interactions) in flight, parallel mode (0 = auto).
+update_mode        0 atomic deltas (default), 1 plain load/store, 2 no writes (profiling).
+occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
 log_samples        record (negative, sampled) per shuffled position into last_logs.
 device_shuffle     LightFM.fit_partial only: see lightfm.py.
 
@@ -20,6 +22,8 @@ class _Options(object):
         self.launches_per_epoch = int(os.environ.get("LIGHTFM_AMD_LAUNCHES", "0"))
         self.first_batch = int(os.environ.get("LIGHTFM_AMD_FIRST_BATCH", "0"))
         self.max_waves = int(os.environ.get("LIGHTFM_AMD_MAX_WAVES", "0"))
+        self.update_mode = int(os.environ.get("LIGHTFM_AMD_UPDATE_MODE", "0"))
+        self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None
