@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 20M interactions (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves"):
+    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel"):
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
 
@@ -124,9 +124,9 @@ def main():
     from lightfm_amd.lightfm import LightFM, _Session
     import scipy.sparse as sp
 
-    from lightfm_amd import options
+    from lightfm_amd.options import options
     tuned = {k: getattr(args, k) for k in ("update_mode", "occupancy", "first_batch",
-                                           "launches_per_epoch", "max_waves")
+                                           "launches_per_epoch", "max_waves", "warp_kernel")
              if getattr(args, k) is not None}
     options.set(**tuned)
     if N.device_count() <= local_rank:
@@ -202,14 +202,16 @@ def main():
     else:
         total_pos = float(sum(s.counters[0] for s in stats))
 
-    # roofline of the dominant kernel (fit_warp_kernel<1>), this rank
+    # roofline of the dominant kernel (the WARP epoch kernel), this rank
     kernel_s = sum(s.kernel_ms for s in stats) / 1e3
     lens = np.diff(positives.indptr)[train.row]
     mean_probe = float(np.mean(8 + 4 * np.ceil(np.log2(lens + 1.0))))
     alg = algorithmic_bytes(sum(s.counters[0] for s in stats), sum(s.counters[1] for s in stats),
                             sum(s.counters[2] for s in stats), sum(s.counters[3] for s in stats),
                             D, 1, 1, mean_probe)
-    launches = max(1, min(64, (train.nnz + (1 << 20) - 1) >> 20)) * args.steps
+    per_epoch = options.launches_per_epoch or max(1, min(64, (train.nnz + (1 << 20) - 1) >> 20))
+    launches = per_epoch * args.steps
+    kernel_name = "fit_warp_kernel<1, true, 1>" if options.warp_kernel == 1 else "fit_warp_tile_kernel<16>"
     achieved = alg / kernel_s / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -220,7 +222,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "fit_warp_kernel<1>", "algorithmic_bytes_per_launch": alg / launches,
+                "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches // args.steps,
                 "draws_per_interaction": sum(s.counters[1] for s in stats) / max(1.0, sum(s.counters[0] for s in stats)),
                 "updates_per_interaction": sum(s.counters[2] for s in stats) / max(1.0, sum(s.counters[0] for s in stats))}

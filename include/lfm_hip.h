@@ -79,7 +79,11 @@ typedef struct lfm_opts {
                                    possible), 2 = compute but do not write (profiling ablation) */
     int32_t occupancy;          /* wavefronts per SIMD the identity-feature WARP kernel is
                                    compiled for: 0 = auto, 4, 6 or 8                           */
-    int32_t pad_[2];
+    int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
+                                   regularisation: 0 = auto (the lane-group tile kernel,
+                                   csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
+                                   1 = force the generic one-interaction-per-wavefront kernel */
+    int32_t pad_;
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "liblfm_hip.so")
-SOURCES = ["fit_kernels.hip", "predict_kernels.hip", "session.hip"]
+SOURCES = ["fit_kernels.hip", "warp_tile.hip", "predict_kernels.hip", "session.hip"]
 HEADERS = ["device.hpp", "kernels.hpp", os.path.join("..", "..", "include", "lfm_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

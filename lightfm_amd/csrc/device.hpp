@@ -58,6 +58,7 @@ struct FitArgs {
     int32_t serial;
     int32_t update_mode;   // 0 atomic deltas, 1 plain stores, 2 no writes (ablation)
     int32_t tile_rows, tile_stride, first_batch;
+    uint32_t n_items_magic;  // floor(2^32 / n_items) + 1 (warp_tile.hip: fast_mod)
     int32_t k, n_pos;      // k-OS
     int32_t pair_cap;      // k-OS: LDS pair slots per wave
     int32_t *neg_log, *sampled_log;

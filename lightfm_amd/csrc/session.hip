@@ -574,6 +574,26 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                    (size_t)WAVES_PER_BLOCK * 2 * a.pair_cap);
     if (smem > 160 * 1024) return fail(LFM_EUNSUPPORTED, "k-OS n too large for the LDS pair buffer");
 
+    // Parallel WARP over identity features without regularisation (BASELINE configs C2/C4):
+    // the lane-group tile kernel of warp_tile.hip, NG interactions per wavefront pass.
+    bool use_tile = false;
+    int tile_ng = 1;
+    if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
+        s->usf.identity && item_alpha == 0.0 && user_alpha == 0.0 && s->itf.rows >= 2) {
+        int trows = 0, tstride = 0;
+        size_t tsmem = warp_tile_geometry(s->d, s->max_sampled, &trows, &tstride);
+        if (tsmem > 0) {
+            use_tile = true;
+            smem = tsmem;
+            a.tile_rows = trows;
+            a.tile_stride = tstride;
+            a.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
+            a.first_batch = std::max(1, std::min(a.first_batch, trows - 1));
+            a.n_items_magic = (uint32_t)((1ull << 32) / (uint64_t)s->itf.rows) + 1u;
+            tile_ng = s->d <= 64 ? 4 : 2;
+        }
+    }
+
     if (opts->neg_log) { LFM_TRY(s->neg_log.alloc((size_t)s->n)); a.neg_log = s->neg_log.p; }
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
     if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
@@ -601,14 +621,15 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         // per 4 user rows (DESIGN.md "Hogwild at GPU width").
         int64_t max_waves = opts->max_waves > 0 ? opts->max_waves
                                                 : std::max<int64_t>(16, (int64_t)s->usf.rows / 4);
-        max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / WAVES_PER_BLOCK));
+        max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / (WAVES_PER_BLOCK * tile_ng)));
         for (int l = 0; l < L; ++l) {
             a.begin = s->n * l / L;
             a.end = s->n * (l + 1) / L;
             if (a.end <= a.begin) continue;
-            int64_t waves = a.end - a.begin;
+            int64_t waves = (a.end - a.begin + tile_ng - 1) / tile_ng;
             int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
+            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, grid, smem, s->stream, s->cus));
+            else HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
                 HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904

@@ -1,0 +1,411 @@
+// warp_tile.hip -- the production WARP epoch kernel (fit_warp, PYX:784-912) for the
+// layout every BASELINE throughput configuration uses: identity user and item
+// features, no L2 regularisation, parallel (Hogwild) mode.
+// PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
+//
+// Work mapping (wave64).  A wavefront is split into NG = 64/LPR lane groups of LPR
+// lanes (LPR = 16 for d <= 64, 32 for d <= 128); each group owns ONE interaction
+// per pass, so a wave retires NG interactions per pass.
+//
+//   gather   an embedding row is d*4 bytes = LPR lanes x 16 bytes: ONE
+//            global_load_dwordx4 per wave fetches one row for each of the NG
+//            interactions (1 KiB per instruction, fully coalesced per row).  User
+//            row, positive row and the rows of ALL candidate negatives of the
+//            batch (max_sampled of them) are requested back to back before the
+//            first is consumed, then staged in a wave-private LDS tile.
+//   score    lane r of a group computes the reference's SEQUENTIAL float32 dot
+//            (PYX:320-334: (b_u + b_i) + u0*v0 + u1*v1 ...) of tile row r with the
+//            group's user row: the positive (r = 0) and every candidate negative
+//            (r = 1..nb) of all NG interactions are scored in one 16/32-step pass
+//            of ds_read_b128 -- the summation order, hence every margin test and
+//            every sample count, is the reference's.
+//   sample   within one interaction the weights do not change between draws
+//            (PYX:857-899 updates once, after the loop), so the first violator of
+//            the speculatively scored batch IS the sequential loop's choice; the
+//            PRNG stream of the position is advanced by exactly `sampled` draws.
+//   lookup   in_positives (PYX:270-284) as an LPR-ary search run by the group.
+//   update   groups with a violator are handed, one after the other, to the WHOLE
+//            wave: lane c owns coordinate c (Adagrad/Adadelta are per-coordinate,
+//            PYX:416-449), reads its cell of the three rows from the LDS tile, the
+//            accumulators from memory, evaluates the reference's float64 cell
+//            arithmetic and publishes new-old with global_atomic_add_f32.
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace lfm {
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// x % n for x < 2^31, 2 <= n < 2^31, with magic = floor(2^32 / n) + 1:
+// floor(x*magic / 2^32) is floor(x/n) or one more (x*magic/2^32 lies in (x/n, x/n + 1/2)).
+__device__ __forceinline__ int fast_mod(uint32_t x, uint32_t n, uint32_t magic)
+{
+    uint32_t q = __umulhi(x, magic);
+    int r = (int)(x - q * n);
+    return r < 0 ? r + (int)n : r;
+}
+
+// Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
+__device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi)
+{
+    float acc = __fadd_rn(bu, bi);
+    int c = 0;
+    // 8 ds_read_b128 in flight per 16 coordinates: the LDS latency is paid once per block
+    for (; c + 16 <= d; c += 16) {
+        float4 a[4], x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = ld4(u + c + 4 * j);
+            x[j] = ld4(v + c + 4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __fadd_rn(acc, __fmul_rn(a[j].x, x[j].x));
+            acc = __fadd_rn(acc, __fmul_rn(a[j].y, x[j].y));
+            acc = __fadd_rn(acc, __fmul_rn(a[j].z, x[j].z));
+            acc = __fadd_rn(acc, __fmul_rn(a[j].w, x[j].w));
+        }
+    }
+    for (; c < d; c += 4) {
+        float4 a = ld4(u + c);
+        float4 x = ld4(v + c);
+        acc = __fadd_rn(acc, __fmul_rn(a.x, x.x));
+        acc = __fadd_rn(acc, __fmul_rn(a.y, x.y));
+        acc = __fadd_rn(acc, __fmul_rn(a.z, x.z));
+        acc = __fadd_rn(acc, __fmul_rn(a.w, x.w));
+    }
+    return acc;
+}
+
+// in_positives (PYX:270-284) for NG lane groups at once: every participating group
+// searches its own sorted row [lo, hi) for its own item with an LPR-ary search.
+template <int LPR>
+__device__ __forceinline__ bool group_in_positives(const int32_t *indices, int item, int lo, int hi,
+                                                   bool part, int gbase, int p)
+{
+    constexpr uint32_t GM = LPR == 32 ? 0xffffffffu : ((1u << LPR) - 1u);
+    constexpr int SH = LPR == 32 ? 5 : 4;
+    bool dead = !part;  // group already knows the answer is "absent"
+    while (true) {
+        bool wide = !dead && (hi - lo > LPR);
+        if (__ballot(wide) == 0ull) break;
+        int step = (hi - lo + LPR - 1) >> SH;
+        int idx = lo + p * step;
+        bool ok = wide && idx < hi;
+        int v = ok ? indices[idx] : 0x7fffffff;
+        unsigned long long m = __ballot(ok && v <= item);
+        int cnt = __popc((uint32_t)(m >> gbase) & GM);
+        if (wide) {
+            if (cnt == 0) dead = true;  // item below the row's first entry
+            else {
+                lo = lo + (cnt - 1) * step;
+                hi = min(hi, lo + step);
+            }
+        }
+    }
+    int idx = lo + p;
+    bool hit = !dead && idx < hi && indices[idx] == item;
+    unsigned long long m = __ballot(hit);
+    return ((uint32_t)(m >> gbase) & GM) != 0u;
+}
+
+}  // namespace
+
+template <int LPR>
+__global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
+{
+    constexpr int NG = WAVE / LPR;        // interactions per wave pass
+    constexpr int NC = (LPR * 4) / WAVE;  // coordinates per lane in the update phase
+    constexpr uint32_t GM = LPR == 32 ? 0xffffffffu : ((1u << LPR) - 1u);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), wib = threadIdx.x >> 6;
+    const int g = lane / LPR, p = lane % LPR, gbase = g * LPR;
+    const int d = a.m.d, TS = a.tile_stride, RG = a.tile_rows;
+    // wave-private tile: NG*RG item rows (row 0 of a group = the positive) + NG user rows
+    float *tile = smem + (size_t)wib * (NG * RG + NG) * TS;
+    float *vrows = tile + (size_t)g * RG * TS;
+    float *urow = tile + (size_t)(NG * RG + g) * TS;
+    const bool pc = 4 * p < d;  // this lane carries a 16-byte piece of every gathered row
+    const float *Wi = a.m.W[0], *Wu = a.m.W[1];
+    const float *bi_tab = a.m.b[0], *bu_tab = a.m.b[1];
+    const int max_sampled = a.m.max_sampled;
+    const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
+    const uint32_t base_seed = a.seeds[0];
+    const Hyper h{a.m.adadelta, a.m.lr, a.m.rho, a.m.eps};
+    const int um = a.update_mode;
+
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
+
+    // software pipeline over the COO: the (user, item, y, weight) of the next pass and the
+    // shuffle entry of the one after are in flight while this pass is processed
+    int64_t ib = a.begin + gw * NG;
+    int row1 = 0, c_user = 0, c_pos = 0;
+    float c_y = 0.0f, c_w = 0.0f;
+    if (ib + g < a.end) {
+        int row0 = a.shuffle[ib + g];
+        c_user = a.user_ids[row0];
+        c_pos = a.item_ids[row0];
+        c_y = a.Y[row0];
+        c_w = a.weight[row0];
+    }
+    if (ib + stride + g < a.end) row1 = a.shuffle[ib + stride + g];
+
+    for (; ib < a.end; ib += stride) {
+        const int64_t i = ib + g;
+        const bool in = i < a.end;
+        int row2 = 0, n_user = 0, n_pos = 0;
+        float n_y = 0.0f, n_w = 0.0f;
+        if (i + 2 * stride < a.end) row2 = a.shuffle[i + 2 * stride];
+        if (i + stride < a.end) {
+            n_user = a.user_ids[row1];
+            n_pos = a.item_ids[row1];
+            n_y = a.Y[row1];
+            n_w = a.weight[row1];
+        }
+        const bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
+        int sampled = 0, chosen = -1, chosen_r = 0;
+
+        if (__ballot(act) != 0ull) {
+            int pos_lo = 0, pos_hi = 0;
+            float bu = 0.0f;
+            // lanes without a piece read the table's first 16 bytes instead of branching
+            const bool gl = act && pc;
+            const float4 u4 = ld4(gl ? Wu + (size_t)c_user * d + 4 * p : Wu);
+            const float4 p4 = ld4(gl ? Wi + (size_t)c_pos * d + 4 * p : Wi);
+            if (act) {
+                pos_lo = a.pos.indptr[c_user];
+                pos_hi = a.pos.indptr[c_user + 1];
+                bu = bu_tab[c_user];
+            }
+            uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
+            if (gl) {
+                st4(urow + 4 * p, u4);
+                st4(vrows + 4 * p, p4);
+            }
+            double pp = 0.0;
+            int done = 0;  // draws consumed by every group that is still looking (wave-uniform)
+            while (done < max_sampled) {
+                const bool need = act && chosen < 0;
+                if (__ballot(need) == 0ull) break;
+                const int nb = min(max_sampled - done, done == 0 ? a.first_batch : RG - 1);
+                // lane p holds the stream after min(p, nb) further steps: draw #(done + p)
+                uint32_t s = state;
+                for (int j = 0; j < nb; ++j)
+                    if (j < p) s = lcg(s);
+                const int myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);  // PYX:860-861
+                const bool rowlane = need && p <= nb && (p > 0 || done == 0);
+                float bi = 0.0f;
+                if (rowlane) bi = bi_tab[myitem];
+                for (int k0 = 1; k0 <= nb; k0 += 5) {
+                    float4 v[5];
+                    int kk[5], negs[5];
+                    const bool gl = need && pc;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        kk[j] = min(k0 + j, nb);
+                        negs[j] = __shfl(myitem, gbase + kk[j], WAVE);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) v[j] = ld4(gl ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
+                    // only groups still looking restage: a finished group's chosen row must survive
+                    if (gl) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) st4(vrows + (size_t)kk[j] * TS + 4 * p, v[j]);
+                    }
+                }
+                wave_sync();
+                float score = 0.0f;
+                if (rowlane) score = row_dot(urow, vrows + (size_t)p * TS, d, bu, bi);
+                if (done == 0) pp = (double)__shfl(score, gbase, WAVE);
+                // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
+                const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
+                uint32_t vm = (uint32_t)(__ballot(viol) >> gbase) & GM;
+                int used = nb;
+                while (true) {
+                    const bool part = need && chosen < 0 && vm != 0u;
+                    if (__ballot(part) == 0ull) break;
+                    const int r = part ? (__ffs((int)vm) - 1) : 0;
+                    if (part) vm &= vm - 1u;
+                    const int cand = __shfl(myitem, gbase + r, WAVE);
+                    const bool found = group_in_positives<LPR>(a.pos.indices, cand, pos_lo, pos_hi,
+                                                               part, gbase, p);
+                    if (part) {
+                        c3++;  // PYX:878-879: the draw still counts
+                        if (!found) {
+                            chosen = cand;
+                            chosen_r = r;
+                            used = r;
+                        }
+                    }
+                }
+                const uint32_t ns = (uint32_t)__shfl((int)s, gbase + used, WAVE);
+                if (need) {
+                    sampled += used;
+                    state = ns;
+                }
+                wave_sync();
+                done += nb;
+            }
+            if (act) {
+                c0++;
+                c1 += (unsigned long long)sampled;
+                if (chosen >= 0) c2++;
+            }
+
+            // ---- updates: one group at a time, the whole wave on its three rows ----
+            double lossd = 0.0;
+            if (act && chosen >= 0) {
+                lossd = (double)c_w * a.logtab[sampled];  // PYX:881-885, log from host libm
+                if (lossd > MAX_LOSS) lossd = MAX_LOSS;
+            }
+            const unsigned long long upd = __ballot(act && chosen >= 0 && p == 0);
+            if (upd != 0ull) {
+                float *WiW = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
+                float *WuW = a.m.W[1], *Gu = a.m.G[1], *Mu = a.m.M[1];
+                float gP[NG][NC], gN[NG][NC], gU[NG][NC], mP[NG][NC], mN[NG][NC], mU[NG][NC];
+                float obW[NG], obG[NG], obM[NG];
+                // phase 1: every updating group's accumulator rows and bias cells are requested
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    if ((upd >> (gg * LPR)) & 1ull) {
+                        const int user = __builtin_amdgcn_readlane(c_user, gg * LPR);
+                        const int pos = __builtin_amdgcn_readlane(c_pos, gg * LPR);
+                        const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
+                        const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const int c = lane + WAVE * q;
+                            const bool ok = c < d;
+                            gP[gg][q] = ok ? ldw(Gi + bp + c) : 1.0f;
+                            gN[gg][q] = ok ? ldw(Gi + bn + c) : 1.0f;
+                            gU[gg][q] = ok ? ldw(Gu + bu_ + c) : 1.0f;
+                            mP[gg][q] = (ok && h.adadelta) ? ldw(Mi + bp + c) : 0.0f;
+                            mN[gg][q] = (ok && h.adadelta) ? ldw(Mi + bn + c) : 0.0f;
+                            mU[gg][q] = (ok && h.adadelta) ? ldw(Mu + bu_ + c) : 0.0f;
+                        }
+                        // bias cells: lane 0 = positive item, 1 = negative item, 2 = user (PYX:571-599)
+                        const int side = lane == 2 ? 1 : 0;
+                        const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
+                        obW[gg] = 0.0f;
+                        obG[gg] = 1.0f;
+                        obM[gg] = 0.0f;
+                        if (lane < 3) {
+                            obW[gg] = ldw(a.m.b[side] + brow);
+                            obG[gg] = ldw(a.m.bG[side] + brow);
+                            if (h.adadelta) obM[gg] = ldw(a.m.bM[side] + brow);
+                        }
+                    }
+                }
+                // phase 2: cell arithmetic (PYX:416-449 in float64) and atomic publication
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    if ((upd >> (gg * LPR)) & 1ull) {
+                        const int user = __builtin_amdgcn_readlane(c_user, gg * LPR);
+                        const int pos = __builtin_amdgcn_readlane(c_pos, gg * LPR);
+                        const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
+                        const int cr = __builtin_amdgcn_readlane(chosen_r, gg * LPR);
+                        const double loss = read_laned(lossd, gg * LPR);
+                        const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+                        const float *tu = tile + (size_t)(NG * RG + gg) * TS;
+                        const float *tp = tile + (size_t)(gg * RG) * TS;
+                        const float *tn = tile + (size_t)(gg * RG + cr) * TS;
+                        float nW, nG, nM;
+                        double lr;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const int c = lane + WAVE * q;
+                            if (c < d) {
+                                const float Uc = tu[c], Pc = tp[c], Nc = tn[c];
+                                const double u = (double)Uc;
+                                cell_math(Pc, gP[gg][q], mP[gg][q], 1.0, -loss * u, h, 0.0, nW, nG, nM, lr);
+                                publish(WiW + bp + c, nW, Pc, um);
+                                publish(Gi + bp + c, nG, gP[gg][q], um);
+                                if (h.adadelta) publish(Mi + bp + c, nM, mP[gg][q], um);
+                                cell_math(Nc, gN[gg][q], mN[gg][q], 1.0, loss * u, h, 0.0, nW, nG, nM, lr);
+                                publish(WiW + bn + c, nW, Nc, um);
+                                publish(Gi + bn + c, nG, gN[gg][q], um);
+                                if (h.adadelta) publish(Mi + bn + c, nM, mN[gg][q], um);
+                                const double df = (double)__fsub_rn(Nc, Pc);  // float32 subtraction, PYX:634-635
+                                cell_math(Uc, gU[gg][q], mU[gg][q], 1.0, loss * df, h, 0.0, nW, nG, nM, lr);
+                                publish(WuW + bu_ + c, nW, Uc, um);
+                                publish(Gu + bu_ + c, nG, gU[gg][q], um);
+                                if (h.adadelta) publish(Mu + bu_ + c, nM, mU[gg][q], um);
+                            }
+                        }
+                        if (lane < 3) {
+                            const int side = lane == 2 ? 1 : 0;
+                            const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
+                            cell_math(obW[gg], obG[gg], obM[gg], 1.0, lane == 0 ? -loss : loss, h, 0.0, nW,
+                                      nG, nM, lr);
+                            publish(a.m.b[side] + brow, nW, obW[gg], um);
+                            publish(a.m.bG[side] + brow, nG, obG[gg], um);
+                            if (h.adadelta) publish(a.m.bM[side] + brow, nM, obM[gg], um);
+                        }
+                    }
+                }
+                wave_sync();  // the tile is rewritten by the next pass
+            }
+        }
+        if (in && p == 0) {
+            if (a.neg_log) a.neg_log[i] = chosen;
+            if (a.sampled_log) a.sampled_log[i] = sampled;
+        }
+        row1 = row2;
+        c_user = n_user;
+        c_pos = n_pos;
+        c_y = n_y;
+        c_w = n_w;
+    }
+
+    // counters: sum over the group leaders, one atomic per wave and counter
+    if (p != 0) c0 = c1 = c2 = c3 = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        c0 += __shfl_xor(c0, off, WAVE);
+        c1 += __shfl_xor(c1, off, WAVE);
+        c2 += __shfl_xor(c2, off, WAVE);
+        c3 += __shfl_xor(c3, off, WAVE);
+    }
+    if (lane == 0) {
+        if (c0) atomicAdd(a.counters + 0, c0);
+        if (c1) atomicAdd(a.counters + 1, c1);
+        if (c2) atomicAdd(a.counters + 2, c2);
+        if (c3) atomicAdd(a.counters + 3, c3);
+    }
+}
+
+// LDS bytes per 256-thread workgroup of the tile kernel, or 0 if (d, max_sampled) is
+// outside what it supports.  rows/stride are the tile geometry it must be launched with.
+size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride)
+{
+    if (d < 4 || d > 128 || (d & 3) != 0 || max_sampled < 1) return 0;
+    const int lpr = d <= 64 ? 16 : 32, ng = WAVE / lpr;
+    const int ts = d + 4;  // 16-byte aligned rows, rows 4 dwords apart in bank phase
+    int rg = std::min(max_sampled, lpr - 1) + 1;
+    // keep three workgroups per CU resident (160 KiB LDS): <= 52 KiB per workgroup
+    while (rg > 2 && (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float) > 52 * 1024) --rg;
+    *rows = rg;
+    *stride = ts;
+    return (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float);
+}
+
+hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus)
+{
+    const bool small = a.m.d <= 64;
+    auto kernel = small ? fit_warp_tile_kernel<16> : fit_warp_tile_kernel<32>;
+    if (cus > 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) == hipSuccess &&
+            per_cu > 0)
+            grid = std::min(grid, per_cu * cus);
+    }
+    kernel<<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace lfm

@@ -8,6 +8,8 @@ first_batch        negatives scored speculatively in the first batch (0 = auto).
 max_waves          cap on wavefronts (interactions) in flight, parallel mode (0 = auto).
 update_mode        0 atomic deltas (default), 1 plain load/store, 2 no writes (profiling).
 occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
+warp_kernel        0 auto (lane-group tile kernel where it applies), 1 force the generic
+                   one-interaction-per-wavefront WARP kernel.
 log_samples        record (negative, sampled) per shuffled position into last_logs.
 device_shuffle     LightFM.fit_partial only: see lightfm.py.
 
@@ -24,6 +26,7 @@ class _Options(object):
         self.max_waves = int(os.environ.get("LIGHTFM_AMD_MAX_WAVES", "0"))
         self.update_mode = int(os.environ.get("LIGHTFM_AMD_UPDATE_MODE", "0"))
         self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
+        self.warp_kernel = int(os.environ.get("LIGHTFM_AMD_WARP_KERNEL", "0"))
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None

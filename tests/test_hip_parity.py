@@ -34,9 +34,11 @@ def fast():
 @pytest.fixture(autouse=True)
 def _reset_options():
     from lightfm_amd.options import options
-    options.set(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0, log_samples=False)
+    options.set(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0, log_samples=False,
+                warp_kernel=0)
     yield
-    options.set(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0, log_samples=False)
+    options.set(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0, log_samples=False,
+                warp_kernel=0)
 
 
 def _hip_struct(fast, st):

@@ -1,0 +1,223 @@
+"""GPU parity tests of the lane-group WARP tile kernel (lightfm_amd/csrc/warp_tile.hip),
+the kernel bench.py measures: parallel mode, identity features, no regularisation.
+
+Bars (all through the C ABI's Python binding, against the CPU oracle with one PRNG
+stream per shuffled position -- the rule both sides share):
+  * frozen weights (sample_weight = 0, the reference's own trick,
+    tests/test_movielens.py:517-533): chosen negative and sample count of EVERY
+    position exact, totals of draws / updates / in_positives probes exact, weights
+    untouched -- for every supported d, single- and multi-batch max_sampled, skipped
+    (Y <= 0) rows and positives rows long enough for several search rounds;
+  * one interaction per launch (launches_per_epoch = n): the parallel kernel is then
+    sequential, and weights, biases and accumulators must be BIT-EXACT;
+  * four concurrent interactions per launch that share no row (checked in numpy from
+    the shared PRNG rule): BIT-EXACT as well -- every lane group's update path;
+  * the generic one-interaction-per-wavefront kernel gives the same logs.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fast():
+    import lightfm_amd._lightfm_fast as f
+    from lightfm_amd import _native
+    assert _native.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return f
+
+
+_DEFAULTS = dict(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0,
+                 log_samples=False, warp_kernel=0, update_mode=0)
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    from lightfm_amd.options import options
+    options.set(**_DEFAULTS)
+    yield
+    options.set(**_DEFAULTS)
+
+
+def _hip_warp(fast, coo, st, shuffle, seeds, weight):
+    Cm = fast.CSRMatrix
+    nu, ni = coo.shape
+    fl = fast.FastLightFM(*st.arrays(), st.d, int(st.schedule == "adadelta"), st.lr, st.rho, st.eps,
+                          st.max_sampled)
+    fast.fit_warp(Cm(H.identity_features(ni)), Cm(H.identity_features(nu)), Cm(H.positives_csr(coo)),
+                  coo.row, coo.col, coo.data, weight, shuffle, fl, 0.05, 0.0, 0.0, len(seeds),
+                  H.FixedRandom(seeds))
+
+
+def _orc_warp(coo, st, shuffle, seeds, weight):
+    nu, ni = coo.shape
+    o = oracle.Opts(len(shuffle), rng_mode=1, log=True)
+    oracle.fit_warp(H.identity_features(ni), H.identity_features(nu), H.positives_csr(coo), coo.row,
+                    coo.col, coo.data, weight, shuffle, st, 0.0, 0.0, seeds, o)
+    return o
+
+
+def _spread(st):
+    """Scale the freshly initialised embeddings so that scores have a standard deviation
+    of about 3: the margin test (PYX:875) then sees both outcomes and sample counts
+    cover the whole 1..max_sampled range."""
+    a = 3.0 / st.d ** 0.25
+    st.item_embeddings *= 2 * st.d * a
+    st.user_embeddings *= 2 * st.d * a
+
+
+FROZEN = [
+    # (id, n_users, n_items, nnz, d, max_sampled, first_batch, ratings)
+    ("d64-ms10", 300, 200, 6000, 64, 10, 0, False),
+    ("d64-ms10-fb3", 300, 200, 6000, 64, 10, 3, True),
+    ("d64-ms1", 120, 90, 1500, 64, 1, 0, False),
+    ("d64-ms40-multibatch", 200, 150, 5000, 64, 40, 0, True),
+    ("d8-ms7", 60, 40, 500, 8, 7, 0, True),
+    ("d32-ms15", 150, 400, 3000, 32, 15, 0, False),
+    ("d48-ms12", 90, 70, 1200, 48, 12, 5, False),
+    ("d100-ms10", 200, 120, 4000, 100, 10, 0, True),
+    ("d128-ms35-multibatch", 100, 300, 3000, 128, 35, 0, False),
+    ("longrows", 12, 6000, 30000, 64, 10, 0, False),
+    ("two-items", 50, 2, 60, 64, 10, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", FROZEN, ids=[c[0] for c in FROZEN])
+@pytest.mark.parametrize("kernel", [0, 1], ids=["tile", "generic"])
+def test_frozen_weights_samples_exact(fast, case, kernel):
+    from lightfm_amd.options import options
+    _, nu, ni, nnz, d, ms, fb, ratings = case
+    coo = H.make_interactions(nu, ni, nnz, seed=17, ratings=ratings, zipf=0.6)
+    rng = np.random.RandomState(9)
+    st = oracle.State(ni, nu, d, rng, max_sampled=ms)
+    _spread(st)
+    st.item_biases[:] = rng.randn(ni).astype(np.float32) * 0.3
+    st.user_biases[:] = rng.randn(nu).astype(np.float32) * 0.3
+    a, b = st.copy(), st.copy()
+    zeros = np.zeros_like(coo.data)
+    shuffle, seeds = H.epoch_inputs(coo, rng)
+    options.set(log_samples=True, launches_per_epoch=3, first_batch=fb, warp_kernel=kernel)
+    _hip_warp(fast, coo, a, shuffle, seeds, zeros)
+    o = _orc_warp(coo, b, shuffle, seeds, zeros)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled), "sample counts differ"
+    assert np.array_equal(neg, o.neg), "negative (rank) indices differ"
+    assert options.last_counters == o.counters
+    assert o.counters[2] > 0 or ni <= 2, "no violator found: the case does not exercise the update path"
+    H.assert_states_equal(a, st, exact=True)
+
+
+SEQ = [("d64-adagrad", 64, "adagrad", 10), ("d32-adadelta", 32, "adadelta", 6),
+       ("d128-adagrad", 128, "adagrad", 10), ("d20-adagrad", 20, "adagrad", 20)]
+
+
+@pytest.mark.parametrize("case", SEQ, ids=[c[0] for c in SEQ])
+@pytest.mark.parametrize("update_mode", [1, 0], ids=["store", "atomic"])
+def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode):
+    """launches_per_epoch = n makes the Hogwild kernel sequential: the sample logs must then
+    equal the oracle's (same per-position streams) exactly and, two epochs later, every
+    array bit for bit when the kernel stores the new cell values (update_mode 1).  The
+    default mode publishes new - old with global_atomic_add_f32: old + fl32(new - old)
+    reproduces `new` except where the subtraction is inexact (a weight crossing zero), so
+    there the bar is one float32 ulp of the largest weight."""
+    from lightfm_amd.options import options
+    _, d, sched, ms = case
+    coo = H.make_interactions(40, 30, 260, seed=3, ratings=True)
+    rng = np.random.RandomState(4)
+    st = oracle.State(30, 40, d, rng, schedule=sched, max_sampled=ms)
+    _spread(st)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=len(coo.data), update_mode=update_mode)
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+        o = _orc_warp(coo, b, shuffle, seeds, coo.data)
+        neg, sampled = options.last_logs
+        assert np.array_equal(sampled, o.sampled)
+        assert np.array_equal(neg, o.neg)
+        assert options.last_counters == o.counters
+    assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    if update_mode == 1:
+        H.assert_states_equal(a, b, exact=True)
+    else:
+        H.assert_states_equal(a, b, exact=False, rtol=1e-6, atol=1e-6)
+
+
+def _candidates(base_seed, positions, max_sampled, n_items):
+    """All draws position i may make (numpy restatement of the shared PRNG rule)."""
+    out = np.empty((len(positions), max_sampled), np.int64)
+    for j, i in enumerate(positions):
+        s = oracle.position_seed(int(base_seed), int(i))
+        draws, _ = oracle.rand_r_stream(s, max_sampled)
+        out[j] = draws % n_items
+    return out
+
+
+@pytest.mark.parametrize("d,group", [(64, 4), (128, 2)])
+def test_concurrent_disjoint_groups_bit_exact(fast, d, group):
+    """`group` interactions per launch = one per lane group of ONE wavefront.  When no
+    interaction of a launch reads or writes a row another one writes, the concurrent
+    result equals the sequential one bit for bit."""
+    from lightfm_amd.options import options
+    nu, ni, n, ms = 400, 40000, 160, 10
+    rng = np.random.RandomState(11)
+    found = None
+    for attempt in range(50):
+        users = rng.permutation(nu)[:n].astype(np.int32)
+        items = rng.permutation(ni)[:n].astype(np.int32)
+        coo = sp.coo_matrix((np.ones(n, np.float32), (users, items)), shape=(nu, ni), dtype=np.float32)
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        cands = _candidates(seeds[0], np.arange(n), ms, ni)
+        ok = True
+        for l0 in range(0, n, group):
+            rows = [set(cands[j].tolist()) | {int(coo.col[shuffle[j]])} for j in range(l0, l0 + group)]
+            if len(set().union(*rows)) != sum(len(r) for r in rows):
+                ok = False
+                break
+        if ok:
+            found = (coo, shuffle, seeds)
+            break
+    assert found is not None, "no conflict-free arrangement found"
+    coo, shuffle, seeds = found
+    st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
+    _spread(st)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=n // group, update_mode=1)
+    _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+    o = _orc_warp(coo, b, shuffle, seeds, coo.data)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled)
+    assert np.array_equal(neg, o.neg)
+    assert o.counters[2] > n // 4
+    H.assert_states_equal(a, b, exact=True)
+
+
+def test_tile_training_learns_like_the_oracle(fast):
+    """Full Hogwild training with the tile kernel: fit quality within a few percent of the
+    sequential oracle's after 5 epochs (neither side is order-deterministic in general)."""
+    coo = H.make_interactions(2000, 1500, 80000, seed=21)
+    rng = np.random.RandomState(5)
+    st = oracle.State(1500, 2000, 64, rng)
+    a, b = st.copy(), st.copy()
+    for _ in range(5):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+        _orc_warp(coo, b, shuffle, seeds, coo.data)
+    item_f, user_f = H.identity_features(1500), H.identity_features(2000)
+
+    def margin(s):
+        r = np.random.RandomState(0)
+        pos = oracle.predict(item_f, user_f, coo.row, coo.col, s)
+        neg = oracle.predict(item_f, user_f, coo.row,
+                             r.randint(0, 1500, size=len(coo.row)).astype(np.int32), s)
+        return float(np.mean(pos - neg)), float(np.mean(pos > neg))
+
+    (ma, aa), (mb, ab) = margin(a), margin(b)
+    assert ab > 0.8
+    assert abs(aa - ab) < 0.03, (aa, ab)
+    assert abs(ma - mb) / abs(mb) < 0.15, (ma, mb)
