@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 20M interactions (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-no-shuffle", action="store_true", help="experiment: identity shuffle")
+    ap.add_argument("--debug-empty-positives", action="store_true", help="experiment: no in_positives probes")
     for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel"):
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
@@ -150,13 +152,18 @@ def main():
     positives = model._get_positives_lookup_matrix(train)
     fl = model._get_lightfm_data()
     session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f), device=local_rank)
-    session.set_interactions(CSRMatrix(positives), np.ascontiguousarray(train.row),
+    lookup = positives
+    if args.debug_empty_positives:
+        lookup = sp.csr_matrix(positives.shape, dtype=np.float32)
+    session.set_interactions(CSRMatrix(lookup), np.ascontiguousarray(train.row),
                              np.ascontiguousarray(train.col), train.data, train.data)
     total = args.warmup + args.steps
     seeds = []
     for e in range(total):  # lightfm.py:689-690 + _lightfm_fast.pyx.template:812-814
         shuffle = np.arange(train.nnz, dtype=np.int32)
         model.random_state.shuffle(shuffle)
+        if args.debug_no_shuffle:
+            shuffle = np.arange(train.nnz, dtype=np.int32)
         seeds.append(np.ascontiguousarray(model.random_state.randint(
             0, np.iinfo(np.int32).max, size=1).astype(np.uint32)))
         session.upload_shuffle(shuffle, slot=e)
@@ -227,6 +234,12 @@ def main():
                 "draws_per_interaction": sum(s.counters[1] for s in stats) / max(1.0, sum(s.counters[0] for s in stats)),
                 "updates_per_interaction": sum(s.counters[2] for s in stats) / max(1.0, sum(s.counters[0] for s in stats))}
 
+    if options.warp_kernel == 2:  # profiling build: per-phase shader cycles per wavefront pass
+        ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
+        passes = sum(s.counters[0] for s in stats) / 4.0
+        roofline["phase_cycles_per_pass"] = dict(zip(
+            ("head", "gather", "score", "lookup", "acc_loads", "update", "tail", "unused"),
+            [round(float(x) / passes, 1) for x in ph]))
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(train, log)

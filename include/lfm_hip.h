@@ -82,8 +82,13 @@ typedef struct lfm_opts {
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
                                    regularisation: 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
-                                   1 = force the generic one-interaction-per-wavefront kernel */
+                                   1 = force the generic one-interaction-per-wavefront kernel,
+                                   2 = tile kernel instrumented with per-phase cycle counters */
     int32_t pad_;
+    int64_t phase_cycles[8];    /* out, warp_kernel = 2 (profiling build of the tile kernel): shader
+                                   cycles summed over wavefronts per phase of a pass -- 0 loop
+                                   head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator
+                                   loads, 5 cell arithmetic + atomics, 6 tail */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -26,7 +26,8 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
                       int occupancy = 0, int cus = 0);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)
 size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride);
-hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus);
+hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus,
+                                bool timed = false);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
 hipError_t launch_regularize(const DModel &m, int force, hipStream_t st);
 hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);

@@ -325,7 +325,7 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     double sc[2] = {model->item_scale, model->user_scale}, one[2] = {1.0, 1.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
     if (rc == LFM_OK) guard(s->scale_prod.upload(one, 2));
-    if (rc == LFM_OK) guard(s->counters.alloc(4));
+    if (rc == LFM_OK) guard(s->counters.alloc(12));
     if (rc == LFM_OK) guard(s->flag.alloc(1));
     if (rc == LFM_OK) guard(s->itf.upload(item_features, true, true));
     if (rc == LFM_OK) guard(s->usf.upload(user_features, true, true));
@@ -598,7 +598,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
     if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
     if (a.sampled_log) HIP_TRY(hipMemsetAsync(a.sampled_log, 0, (size_t)s->n * 4, s->stream));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 12 * sizeof(unsigned long long), s->stream));
 
     if (s->comm) LFM_TRY(snapshot_side(s, 0));
 
@@ -628,7 +628,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (a.end <= a.begin) continue;
             int64_t waves = (a.end - a.begin + tile_ng - 1) / tile_ng;
             int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, grid, smem, s->stream, s->cus));
+            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, grid, smem, s->stream, s->cus, opts->warp_kernel == 2));
             else HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
@@ -643,9 +643,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     opts->kernel_ms = ms;
-    unsigned long long c[4];
+    unsigned long long c[12];
     LFM_TRY(s->counters.download(c));
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
+    for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     return LFM_OK;

@@ -114,9 +114,21 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 
 }  // namespace
 
-template <int LPR>
+// TIMED (profiling builds of the same kernel, lfm_opts.warp_kernel = 2): every wave
+// accumulates s_memtime deltas per phase of a pass into a.counters[4..11].
+template <int LPR, bool TIMED, bool ADADELTA>
 __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
 {
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TIMED) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            unsigned long long t = __builtin_readcyclecounter();
+            ph[k] += t - tprev;
+            tprev = t;
+        }
+    };
+    if constexpr (TIMED) tprev = __builtin_readcyclecounter();
     constexpr int NG = WAVE / LPR;        // interactions per wave pass
     constexpr int NC = (LPR * 4) / WAVE;  // coordinates per lane in the update phase
     constexpr uint32_t GM = LPR == 32 ? 0xffffffffu : ((1u << LPR) - 1u);
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
     const int max_sampled = a.m.max_sampled;
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
-    const Hyper h{a.m.adadelta, a.m.lr, a.m.rho, a.m.eps};
+    const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
 
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
         }
         const bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
         int sampled = 0, chosen = -1, chosen_r = 0;
+        stamp(0);  // loop overhead + COO prefetch issue (+ drain of the previous pass's atomics)
 
         if (__ballot(act) != 0ull) {
             int pos_lo = 0, pos_hi = 0;
@@ -201,24 +214,37 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
-                for (int k0 = 1; k0 <= nb; k0 += 5) {
-                    float4 v[5];
-                    int kk[5], negs[5];
+                // up to 10 candidate rows per round, ALL requested before the first is staged
+                for (int k0 = 1; k0 <= nb; k0 += 10) {
+                    float4 v[10];
+                    int kk[10];
                     const bool gl = need && pc;
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        kk[j] = min(k0 + j, nb);
-                        negs[j] = __shfl(myitem, gbase + kk[j], WAVE);
+                    for (int c5 = 0; c5 < 10; c5 += 5) {
+                        if (k0 + c5 <= nb) {  // wave-uniform
+                            int negs[5];
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                kk[c5 + j] = min(k0 + c5 + j, nb);
+                                negs[j] = __shfl(myitem, gbase + kk[c5 + j], WAVE);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 5; ++j)
+                                v[c5 + j] = ld4(gl ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
+                        }
                     }
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) v[j] = ld4(gl ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
                     // only groups still looking restage: a finished group's chosen row must survive
-                    if (gl) {
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) st4(vrows + (size_t)kk[j] * TS + 4 * p, v[j]);
+                    for (int c5 = 0; c5 < 10; c5 += 5) {
+                        if (k0 + c5 <= nb && gl) {
+#pragma unroll
+                            for (int j = 0; j < 5; ++j)
+                                st4(vrows + (size_t)kk[c5 + j] * TS + 4 * p, v[c5 + j]);
+                        }
                     }
                 }
                 wave_sync();
+                stamp(1);  // gathers landed and staged
                 float score = 0.0f;
                 if (rowlane) score = row_dot(urow, vrows + (size_t)p * TS, d, bu, bi);
                 if (done == 0) pp = (double)__shfl(score, gbase, WAVE);
@@ -226,6 +252,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
                 uint32_t vm = (uint32_t)(__ballot(viol) >> gbase) & GM;
                 int used = nb;
+                stamp(2);  // scoring pass
                 while (true) {
                     const bool part = need && chosen < 0 && vm != 0u;
                     if (__ballot(part) == 0ull) break;
@@ -250,6 +277,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 }
                 wave_sync();
                 done += nb;
+                stamp(3);  // in_positives searches
             }
             if (act) {
                 c0++;
@@ -279,28 +307,32 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                         const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
+                            // plain loads, lanes past d re-read coordinate 0: no exec-masked
+                            // branches, so all rows of all groups are in flight together
                             const int c = lane + WAVE * q;
-                            const bool ok = c < d;
-                            gP[gg][q] = ok ? ldw(Gi + bp + c) : 1.0f;
-                            gN[gg][q] = ok ? ldw(Gi + bn + c) : 1.0f;
-                            gU[gg][q] = ok ? ldw(Gu + bu_ + c) : 1.0f;
-                            mP[gg][q] = (ok && h.adadelta) ? ldw(Mi + bp + c) : 0.0f;
-                            mN[gg][q] = (ok && h.adadelta) ? ldw(Mi + bn + c) : 0.0f;
-                            mU[gg][q] = (ok && h.adadelta) ? ldw(Mu + bu_ + c) : 0.0f;
+                            const int cc = c < d ? c : 0;
+                            gP[gg][q] = Gi[bp + cc];
+                            gN[gg][q] = Gi[bn + cc];
+                            gU[gg][q] = Gu[bu_ + cc];
+                            if (h.adadelta) {
+                                mP[gg][q] = Mi[bp + cc];
+                                mN[gg][q] = Mi[bn + cc];
+                                mU[gg][q] = Mu[bu_ + cc];
+                            } else {
+                                mP[gg][q] = mN[gg][q] = mU[gg][q] = 0.0f;
+                            }
                         }
-                        // bias cells: lane 0 = positive item, 1 = negative item, 2 = user (PYX:571-599)
-                        const int side = lane == 2 ? 1 : 0;
+                        // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
                         const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-                        obW[gg] = 0.0f;
-                        obG[gg] = 1.0f;
-                        obM[gg] = 0.0f;
-                        if (lane < 3) {
-                            obW[gg] = ldw(a.m.b[side] + brow);
-                            obG[gg] = ldw(a.m.bG[side] + brow);
-                            if (h.adadelta) obM[gg] = ldw(a.m.bM[side] + brow);
-                        }
+                        const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
+                        const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
+                        const float *bMp = lane >= 2 ? a.m.bM[1] : a.m.bM[0];
+                        obW[gg] = bWp[brow];
+                        obG[gg] = bGp[brow];
+                        obM[gg] = h.adadelta ? bMp[brow] : 0.0f;
                     }
                 }
+                stamp(4);  // accumulator rows landed
                 // phase 2: cell arithmetic (PYX:416-449 in float64) and atomic publication
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
@@ -338,19 +370,23 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                             }
                         }
                         if (lane < 3) {
-                            const int side = lane == 2 ? 1 : 0;
                             const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
+                            float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
+                            float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
+                            float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
                             cell_math(obW[gg], obG[gg], obM[gg], 1.0, lane == 0 ? -loss : loss, h, 0.0, nW,
                                       nG, nM, lr);
-                            publish(a.m.b[side] + brow, nW, obW[gg], um);
-                            publish(a.m.bG[side] + brow, nG, obG[gg], um);
-                            if (h.adadelta) publish(a.m.bM[side] + brow, nM, obM[gg], um);
+                            publish(bWp + brow, nW, obW[gg], um);
+                            publish(bGp + brow, nG, obG[gg], um);
+                            if (h.adadelta) publish(bMp + brow, nM, obM[gg], um);
                         }
                     }
                 }
                 wave_sync();  // the tile is rewritten by the next pass
+                stamp(5);  // cell arithmetic, atomics issued and acknowledged
             }
         }
+        stamp(6);
         if (in && p == 0) {
             if (a.neg_log) a.neg_log[i] = chosen;
             if (a.sampled_log) a.sampled_log[i] = sampled;
@@ -370,6 +406,10 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
         c1 += __shfl_xor(c1, off, WAVE);
         c2 += __shfl_xor(c2, off, WAVE);
         c3 += __shfl_xor(c3, off, WAVE);
+    }
+    if constexpr (TIMED) {
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(a.counters + 4 + k, ph[k]);
     }
     if (lane == 0) {
         if (c0) atomicAdd(a.counters + 0, c0);
@@ -394,10 +434,17 @@ size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride)
     return (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float);
 }
 
-hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus)
+hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus,
+                                bool timed)
 {
     const bool small = a.m.d <= 64;
-    auto kernel = small ? fit_warp_tile_kernel<16> : fit_warp_tile_kernel<32>;
+    void (*kernel)(FitArgs);
+    if (a.m.adadelta)
+        kernel = small ? fit_warp_tile_kernel<16, false, true> : fit_warp_tile_kernel<32, false, true>;
+    else if (timed)
+        kernel = small ? fit_warp_tile_kernel<16, true, false> : fit_warp_tile_kernel<32, true, false>;
+    else
+        kernel = small ? fit_warp_tile_kernel<16, false, false> : fit_warp_tile_kernel<32, false, false>;
     if (cus > 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) == hipSuccess &&

@@ -30,6 +30,7 @@ class _Options(object):
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None
+        self.last_phase_cycles = None
         self.last_logs = None
 
     def set(self, **kw):
