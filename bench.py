@@ -98,9 +98,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 20M interactions (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-zipf", type=float, default=None, help="experiment: item popularity exponent")
     ap.add_argument("--debug-no-shuffle", action="store_true", help="experiment: identity shuffle")
     ap.add_argument("--debug-empty-positives", action="store_true", help="experiment: no in_positives probes")
-    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel"):
+    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "debug"):
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
 
@@ -128,7 +129,7 @@ def main():
 
     from lightfm_amd.options import options
     tuned = {k: getattr(args, k) for k in ("update_mode", "occupancy", "first_batch",
-                                           "launches_per_epoch", "max_waves", "warp_kernel")
+                                           "launches_per_epoch", "max_waves", "warp_kernel", "debug")
              if getattr(args, k) is not None}
     options.set(**tuned)
     if N.device_count() <= local_rank:
@@ -137,7 +138,8 @@ def main():
 
     t0 = time.time()
     n_users, n_items, nnz = synthetic.SHAPES["ml-20m"]
-    train = synthetic.make_interactions(n_users, n_items, int(nnz * args.scale), seed=42 + rank)
+    extra = {} if args.debug_zipf is None else {"zipf": args.debug_zipf}
+    train = synthetic.make_interactions(n_users, n_items, int(nnz * args.scale), seed=42 + rank, **extra)
     log("generated %d interactions in %.1fs" % (train.nnz, time.time() - t0))
 
     model = LightFM(no_components=D, loss="warp", random_state=10 + rank, max_sampled=MAX_SAMPLED)

@@ -68,15 +68,24 @@ typedef struct lfm_opts {
     int32_t launches_per_epoch; /* parallel mode: kernel launches per epoch (a launch
                                    boundary is a device-wide release/acquire); 0 = auto */
     int32_t first_batch;        /* negatives scored speculatively in the first batch; 0 = auto */
-    int32_t max_waves;          /* parallel mode: cap on wavefronts (= interactions) in flight;
-                                   0 = auto (staleness)                 */
+    int32_t max_waves;          /* parallel mode: cap on interactions in flight (between reading
+                                   the weights and publishing the update); 0 = auto =
+                                   min(n_users, n_items) / 6, the bound under which
+                                   precision@10 stays within 0.002 of the reference
+                                   (DESIGN.md "Hogwild at GPU width")                   */
     int32_t *neg_log;           /* host [n] or NULL: chosen negative per shuffled position, -1 = none */
     int32_t *sampled_log;       /* host [n] or NULL: draws consumed per shuffled position */
     int64_t counters[4];        /* out: positives visited, draws, updates, in_positives probes */
     float kernel_ms;            /* out: device time of the epoch's kernels (HIP events)   */
-    int32_t update_mode;        /* parallel mode: 0 = publish deltas with global_atomic_add_f32
-                                   (default), 1 = plain load/store Hogwild (lost updates
-                                   possible), 2 = compute but do not write (profiling ablation) */
+    int32_t update_mode;        /* parallel mode, how a cell update reaches memory:
+                                   0 = auto = 3;
+                                   1 = plain load / store (the literal Hogwild of the reference's
+                                       OpenMP loop; on a GPU, whose L2s are neither coherent
+                                       with each other nor write-through, whole updates are
+                                       lost -- kept for experiments and the bit-exactness tests);
+                                   2 = compute but do not write (profiling ablation);
+                                   3 = publish new - old with global_atomic_add_f32: no update
+                                       is lost (DESIGN.md "Hogwild at GPU width")              */
     int32_t occupancy;          /* wavefronts per SIMD the identity-feature WARP kernel is
                                    compiled for: 0 = auto, 4, 6 or 8                           */
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
@@ -84,7 +93,7 @@ typedef struct lfm_opts {
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
                                    1 = force the generic one-interaction-per-wavefront kernel,
                                    2 = tile kernel instrumented with per-phase cycle counters */
-    int32_t pad_;
+    int32_t debug;              /* reserved for kernel experiments; 0 */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 (profiling build of the tile kernel): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator

@@ -86,6 +86,7 @@ def make_opts(n=0, want_log=False):
     o.update_mode = int(options.update_mode)
     o.occupancy = int(options.occupancy)
     o.warp_kernel = int(options.warp_kernel)
+    o.debug = int(options.debug)
     logs = None
     if want_log:
         logs = (np.full(n, -1, np.int32), np.zeros(n, np.int32))

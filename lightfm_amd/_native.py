@@ -45,7 +45,7 @@ class LfmOpts(C.Structure):
                 ("first_batch", C.c_int32), ("max_waves", C.c_int32),
                 ("neg_log", I32P), ("sampled_log", I32P),
                 ("counters", C.c_int64 * 4), ("kernel_ms", C.c_float),
-                ("update_mode", C.c_int32), ("occupancy", C.c_int32), ("warp_kernel", C.c_int32), ("pad_", C.c_int32),
+                ("update_mode", C.c_int32), ("occupancy", C.c_int32), ("warp_kernel", C.c_int32), ("debug", C.c_int32),
                 ("phase_cycles", C.c_int64 * 8)]
 
 

@@ -49,6 +49,7 @@ struct FitArgs {
     const int32_t *user_ids, *item_ids;
     const float *Y, *weight;
     const int32_t *shuffle;
+    const int4 *recs;    // warp_tile.hip: (user, item, Y bits, weight bits) per example, AoS
     int64_t n;           // all examples (BPR modulo, PYX:1124)
     int64_t begin, end;  // shuffled positions of this launch
     double item_alpha, user_alpha;
@@ -58,6 +59,7 @@ struct FitArgs {
     int32_t serial;
     int32_t update_mode;   // 0 atomic deltas, 1 plain stores, 2 no writes (ablation)
     int32_t tile_rows, tile_stride, first_batch;
+    int32_t debug;           // lfm_opts.debug
     uint32_t n_items_magic;  // floor(2^32 / n_items) + 1 (warp_tile.hip: fast_mod)
     int32_t k, n_pos;      // k-OS
     int32_t pair_cap;      // k-OS: LDS pair slots per wave
@@ -440,7 +442,7 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
                                             int neg, const Rep<NC> &U, const Rep<NC> &P,
                                             const Rep<NC> &N, Scales &sc, int lane)
 {
-    const bool atomic = !a.serial;
+    const bool atomic = !a.serial && a.update_mode == 0;
     double lrb[3], lrc[3][NC];
     float diff[NC];
 #pragma unroll
@@ -463,7 +465,7 @@ template <int NC>
 __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int user, int item,
                                             const Rep<NC> &U, const Rep<NC> &I, Scales &sc, int lane)
 {
-    const bool atomic = !a.serial;
+    const bool atomic = !a.serial && a.update_mode == 0;
     double lrb[3] = {0.0, 0.0, 0.0}, lrc[3][NC];
     update_row<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
     update_row<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);

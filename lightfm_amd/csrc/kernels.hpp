@@ -28,6 +28,8 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
 size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride);
 hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus,
                                 bool timed = false);
+hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                               const float *weight, int64_t n, void *out, hipStream_t st);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
 hipError_t launch_regularize(const DModel &m, int force, hipStream_t st);
 hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMED) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (a.debug & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain: pure phases
             unsigned long long t = __builtin_readcyclecounter();
             ph[k] += t - tprev;
             tprev = t;
@@ -152,54 +152,89 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
+    const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
+    float *WiW = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
+    float *WuW = a.m.W[1], *Gu = a.m.G[1], *Mu = a.m.M[1];
 
-    // software pipeline over the COO: the (user, item, y, weight) of the next pass and the
-    // shuffle entry of the one after are in flight while this pass is processed
+    // Software pipeline over the interaction records, three passes deep: while pass t is
+    // processed, the bounds of pass t+1's positives row, the (user, item, y, weight) record
+    // of pass t+2 and the shuffle entry of pass t+3 are in flight.
     int64_t ib = a.begin + gw * NG;
-    int row1 = 0, c_user = 0, c_pos = 0;
-    float c_y = 0.0f, c_w = 0.0f;
+    int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
+    int c_lo = 0, c_hi = 0, row2 = 0;
     if (ib + g < a.end) {
-        int row0 = a.shuffle[ib + g];
-        c_user = a.user_ids[row0];
-        c_pos = a.item_ids[row0];
-        c_y = a.Y[row0];
-        c_w = a.weight[row0];
+        cur = a.recs[a.shuffle[ib + g]];
+        c_lo = indptr[cur.x];
+        c_hi = indptr[cur.x + 1];
     }
-    if (ib + stride + g < a.end) row1 = a.shuffle[ib + stride + g];
+    if (ib + stride + g < a.end) nxt = a.recs[a.shuffle[ib + stride + g]];
+    if (ib + 2 * stride + g < a.end) row2 = a.shuffle[ib + 2 * stride + g];
 
     for (; ib < a.end; ib += stride) {
         const int64_t i = ib + g;
         const bool in = i < a.end;
-        int row2 = 0, n_user = 0, n_pos = 0;
-        float n_y = 0.0f, n_w = 0.0f;
-        if (i + 2 * stride < a.end) row2 = a.shuffle[i + 2 * stride];
+        int n_lo = 0, n_hi = 0, row3 = 0;
+        int4 rec2 = make_int4(0, 0, 0, 0);
         if (i + stride < a.end) {
-            n_user = a.user_ids[row1];
-            n_pos = a.item_ids[row1];
-            n_y = a.Y[row1];
-            n_w = a.weight[row1];
+            n_lo = indptr[nxt.x];
+            n_hi = indptr[nxt.x + 1];
         }
+        if (i + 2 * stride < a.end) rec2 = a.recs[row2];
+        if (i + 3 * stride < a.end) row3 = a.shuffle[i + 3 * stride];
+        const int c_user = cur.x, c_pos = cur.y;
+        const float c_y = __int_as_float(cur.z), c_w = __int_as_float(cur.w);
         const bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
         int sampled = 0, chosen = -1, chosen_r = 0;
-        stamp(0);  // loop overhead + COO prefetch issue (+ drain of the previous pass's atomics)
+        stamp(0);
 
         if (__ballot(act) != 0ull) {
-            int pos_lo = 0, pos_hi = 0;
-            float bu = 0.0f;
-            // lanes without a piece read the table's first 16 bytes instead of branching
+            // ---- gather: user row, positive row, user bias
             const bool gl = act && pc;
+            // lanes without a piece read the table's first 16 bytes instead of branching
             const float4 u4 = ld4(gl ? Wu + (size_t)c_user * d + 4 * p : Wu);
             const float4 p4 = ld4(gl ? Wi + (size_t)c_pos * d + 4 * p : Wi);
-            if (act) {
-                pos_lo = a.pos.indptr[c_user];
-                pos_hi = a.pos.indptr[c_user + 1];
-                bu = bu_tab[c_user];
-            }
+            float bu = 0.0f;
+            if (act) bu = bu_tab[c_user];
             uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
             if (gl) {
                 st4(urow + 4 * p, u4);
                 st4(vrows + 4 * p, p4);
             }
+            // accumulator rows / bias cells of the groups that will (probably) update
+            float gP[NG][NC], gN[NG][NC], gU[NG][NC], mP[NG][NC], mN[NG][NC], mU[NG][NC];
+            float obW[NG], obG[NG], obM[NG];
+            unsigned long long specm = 0ull;  // groups whose accumulators were requested early
+            int spec_cand = -1;               // ... for this candidate negative
+            auto load_rows = [&](int gg, int user, int pos, int neg, bool only_neg) {
+                const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    // plain loads, lanes past d re-read coordinate 0: no exec-masked branches,
+                    // so all rows of all groups are in flight together
+                    const int c = lane + WAVE * q;
+                    const int cc = c < d ? c : 0;
+                    gN[gg][q] = Gi[bn + cc];
+                    if (ADADELTA) mN[gg][q] = Mi[bn + cc];
+                    if (!only_neg) {
+                        gP[gg][q] = Gi[bp + cc];
+                        gU[gg][q] = Gu[bu_ + cc];
+                        if (ADADELTA) {
+                            mP[gg][q] = Mi[bp + cc];
+                            mU[gg][q] = Mu[bu_ + cc];
+                        }
+                    }
+                }
+                // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
+                const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
+                const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
+                const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
+                const float *bMp = lane >= 2 ? a.m.bM[1] : a.m.bM[0];
+                if (!only_neg || lane == 1) {
+                    obW[gg] = bWp[brow];
+                    obG[gg] = bGp[brow];
+                    if (ADADELTA) obM[gg] = bMp[brow];
+                }
+            };
             double pp = 0.0;
             int done = 0;  // draws consumed by every group that is still looking (wave-uniform)
             while (done < max_sampled) {
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 for (int k0 = 1; k0 <= nb; k0 += 10) {
                     float4 v[10];
                     int kk[10];
-                    const bool gl = need && pc;
+                    const bool gln = need && pc;
 #pragma unroll
                     for (int c5 = 0; c5 < 10; c5 += 5) {
                         if (k0 + c5 <= nb) {  // wave-uniform
@@ -230,13 +265,13 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                             }
 #pragma unroll
                             for (int j = 0; j < 5; ++j)
-                                v[c5 + j] = ld4(gl ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
+                                v[c5 + j] = ld4(gln ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
                         }
                     }
                     // only groups still looking restage: a finished group's chosen row must survive
 #pragma unroll
                     for (int c5 = 0; c5 < 10; c5 += 5) {
-                        if (k0 + c5 <= nb && gl) {
+                        if (k0 + c5 <= nb && gln) {
 #pragma unroll
                             for (int j = 0; j < 5; ++j)
                                 st4(vrows + (size_t)kk[c5 + j] * TS + 4 * p, v[c5 + j]);
@@ -253,14 +288,28 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 uint32_t vm = (uint32_t)(__ballot(viol) >> gbase) & GM;
                 int used = nb;
                 stamp(2);  // scoring pass
+                if (done == 0) {
+                    // The first violator is almost always the choice (a uniformly drawn item is
+                    // rarely one of the user's positives): request the accumulator rows of its
+                    // update now, so they travel while in_positives confirms it.
+                    const int r1 = vm != 0u ? (__ffs((int)vm) - 1) : 0;
+                    spec_cand = __shfl(myitem, gbase + r1, WAVE);
+                    specm = __ballot(need && vm != 0u && p == 0);
+#pragma unroll
+                    for (int gg = 0; gg < NG; ++gg) {
+                        if ((specm >> (gg * LPR)) & 1ull)
+                            load_rows(gg, __builtin_amdgcn_readlane(c_user, gg * LPR),
+                                      __builtin_amdgcn_readlane(c_pos, gg * LPR),
+                                      __builtin_amdgcn_readlane(spec_cand, gg * LPR), false);
+                    }
+                }
                 while (true) {
                     const bool part = need && chosen < 0 && vm != 0u;
                     if (__ballot(part) == 0ull) break;
                     const int r = part ? (__ffs((int)vm) - 1) : 0;
                     if (part) vm &= vm - 1u;
                     const int cand = __shfl(myitem, gbase + r, WAVE);
-                    const bool found = group_in_positives<LPR>(a.pos.indices, cand, pos_lo, pos_hi,
-                                                               part, gbase, p);
+                    const bool found = group_in_positives<LPR>(indices, cand, c_lo, c_hi, part, gbase, p);
                     if (part) {
                         c3++;  // PYX:878-879: the draw still counts
                         if (!found) {
@@ -293,47 +342,39 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
             }
             const unsigned long long upd = __ballot(act && chosen >= 0 && p == 0);
             if (upd != 0ull) {
-                float *WiW = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
-                float *WuW = a.m.W[1], *Gu = a.m.G[1], *Mu = a.m.M[1];
-                float gP[NG][NC], gN[NG][NC], gU[NG][NC], mP[NG][NC], mN[NG][NC], mU[NG][NC];
-                float obW[NG], obG[NG], obM[NG];
-                // phase 1: every updating group's accumulator rows and bias cells are requested
+                // accumulators not requested early (violator found in a later batch), or requested
+                // for a candidate that turned out to be a positive
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
                     if ((upd >> (gg * LPR)) & 1ull) {
-                        const int user = __builtin_amdgcn_readlane(c_user, gg * LPR);
-                        const int pos = __builtin_amdgcn_readlane(c_pos, gg * LPR);
                         const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
-                        const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+                        const bool early = (specm >> (gg * LPR)) & 1ull;
+                        if (!early || neg != __builtin_amdgcn_readlane(spec_cand, gg * LPR))
+                            load_rows(gg, __builtin_amdgcn_readlane(c_user, gg * LPR),
+                                      __builtin_amdgcn_readlane(c_pos, gg * LPR), neg, early);
+                    }
+                }
+                // The prefetched records must be in registers BEFORE the atomics are issued:
+                // the next pass then starts without draining the atomics' acknowledgements
+                // (vmcnt is in order) ahead of its own gathers.
+                asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y),
+                             "+v"(rec2.z), "+v"(rec2.w));
+                // ... and so must every accumulator: a wait for one of them placed after the first
+                // atomic would also wait for that atomic's acknowledgement.
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    if ((upd >> (gg * LPR)) & 1ull) {
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
-                            // plain loads, lanes past d re-read coordinate 0: no exec-masked
-                            // branches, so all rows of all groups are in flight together
-                            const int c = lane + WAVE * q;
-                            const int cc = c < d ? c : 0;
-                            gP[gg][q] = Gi[bp + cc];
-                            gN[gg][q] = Gi[bn + cc];
-                            gU[gg][q] = Gu[bu_ + cc];
-                            if (h.adadelta) {
-                                mP[gg][q] = Mi[bp + cc];
-                                mN[gg][q] = Mi[bn + cc];
-                                mU[gg][q] = Mu[bu_ + cc];
-                            } else {
-                                mP[gg][q] = mN[gg][q] = mU[gg][q] = 0.0f;
-                            }
+                            asm volatile("" : "+v"(gP[gg][q]), "+v"(gN[gg][q]), "+v"(gU[gg][q]));
+                            if (ADADELTA) asm volatile("" : "+v"(mP[gg][q]), "+v"(mN[gg][q]), "+v"(mU[gg][q]));
                         }
-                        // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
-                        const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-                        const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
-                        const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
-                        const float *bMp = lane >= 2 ? a.m.bM[1] : a.m.bM[0];
-                        obW[gg] = bWp[brow];
-                        obG[gg] = bGp[brow];
-                        obM[gg] = h.adadelta ? bMp[brow] : 0.0f;
+                        asm volatile("" : "+v"(obW[gg]), "+v"(obG[gg]));
+                        if (ADADELTA) asm volatile("" : "+v"(obM[gg]));
                     }
                 }
                 stamp(4);  // accumulator rows landed
-                // phase 2: cell arithmetic (PYX:416-449 in float64) and atomic publication
+                // cell arithmetic (PYX:416-449 in float64) and atomic publication
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
                     if ((upd >> (gg * LPR)) & 1ull) {
@@ -346,27 +387,52 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                         const float *tu = tile + (size_t)(NG * RG + gg) * TS;
                         const float *tp = tile + (size_t)(gg * RG) * TS;
                         const float *tn = tile + (size_t)(gg * RG + cr) * TS;
-                        float nW, nG, nM;
+                        // All cell arithmetic of the group first, as ONE straight-line block (the
+                        // 3*NC row cells and the bias cell are independent float64 dependency
+                        // chains the scheduler interleaves), then every publication.
+                        float oWr[NC][3], nWr[NC][3], nGr[NC][3], nMr[NC][3];
                         double lr;
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
                             const int c = lane + WAVE * q;
+                            const int cc = c < d ? c : 0;
+                            const float Uc = tu[cc], Pc = tp[cc], Nc = tn[cc];
+                            const double u = (double)Uc;
+                            const double df = (double)__fsub_rn(Nc, Pc);  // float32 subtraction, PYX:634-635
+                            oWr[q][0] = Pc;
+                            oWr[q][1] = Nc;
+                            oWr[q][2] = Uc;
+                            cell_math(Pc, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, 0.0,
+                                      nWr[q][0], nGr[q][0], nMr[q][0], lr);
+                            cell_math(Nc, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, 0.0,
+                                      nWr[q][1], nGr[q][1], nMr[q][1], lr);
+                            cell_math(Uc, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, 0.0,
+                                      nWr[q][2], nGr[q][2], nMr[q][2], lr);
+                        }
+                        float bnW, bnG, bnM;
+                        const float ooM = ADADELTA ? obM[gg] : 0.0f;
+                        cell_math(obW[gg], obG[gg], ooM, 1.0, lane == 0 ? -loss : loss, h, 0.0, bnW, bnG, bnM, lr);
+                        // keep the arithmetic above one block: nothing of it may sink below a publication
+#pragma unroll
+                        for (int q = 0; q < NC; ++q)
+                            asm volatile("" : "+v"(nWr[q][0]), "+v"(nWr[q][1]), "+v"(nWr[q][2]), "+v"(nGr[q][0]),
+                                         "+v"(nGr[q][1]), "+v"(nGr[q][2]));
+                        asm volatile("" : "+v"(bnW), "+v"(bnG));
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const int c = lane + WAVE * q;
                             if (c < d) {
-                                const float Uc = tu[c], Pc = tp[c], Nc = tn[c];
-                                const double u = (double)Uc;
-                                cell_math(Pc, gP[gg][q], mP[gg][q], 1.0, -loss * u, h, 0.0, nW, nG, nM, lr);
-                                publish(WiW + bp + c, nW, Pc, um);
-                                publish(Gi + bp + c, nG, gP[gg][q], um);
-                                if (h.adadelta) publish(Mi + bp + c, nM, mP[gg][q], um);
-                                cell_math(Nc, gN[gg][q], mN[gg][q], 1.0, loss * u, h, 0.0, nW, nG, nM, lr);
-                                publish(WiW + bn + c, nW, Nc, um);
-                                publish(Gi + bn + c, nG, gN[gg][q], um);
-                                if (h.adadelta) publish(Mi + bn + c, nM, mN[gg][q], um);
-                                const double df = (double)__fsub_rn(Nc, Pc);  // float32 subtraction, PYX:634-635
-                                cell_math(Uc, gU[gg][q], mU[gg][q], 1.0, loss * df, h, 0.0, nW, nG, nM, lr);
-                                publish(WuW + bu_ + c, nW, Uc, um);
-                                publish(Gu + bu_ + c, nG, gU[gg][q], um);
-                                if (h.adadelta) publish(Mu + bu_ + c, nM, mU[gg][q], um);
+                                publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
+                                publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
+                                publish(WiW + bn + c, nWr[q][1], oWr[q][1], um);
+                                publish(Gi + bn + c, nGr[q][1], gN[gg][q], um);
+                                publish(WuW + bu_ + c, nWr[q][2], oWr[q][2], um);
+                                publish(Gu + bu_ + c, nGr[q][2], gU[gg][q], um);
+                                if (ADADELTA) {
+                                    publish(Mi + bp + c, nMr[q][0], mP[gg][q], um);
+                                    publish(Mi + bn + c, nMr[q][1], mN[gg][q], um);
+                                    publish(Mu + bu_ + c, nMr[q][2], mU[gg][q], um);
+                                }
                             }
                         }
                         if (lane < 3) {
@@ -374,16 +440,14 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                             float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
                             float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
                             float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
-                            cell_math(obW[gg], obG[gg], obM[gg], 1.0, lane == 0 ? -loss : loss, h, 0.0, nW,
-                                      nG, nM, lr);
-                            publish(bWp + brow, nW, obW[gg], um);
-                            publish(bGp + brow, nG, obG[gg], um);
-                            if (h.adadelta) publish(bMp + brow, nM, obM[gg], um);
+                            publish(bWp + brow, bnW, obW[gg], um);
+                            publish(bGp + brow, bnG, obG[gg], um);
+                            if (ADADELTA) publish(bMp + brow, bnM, ooM, um);
                         }
                     }
                 }
                 wave_sync();  // the tile is rewritten by the next pass
-                stamp(5);  // cell arithmetic, atomics issued and acknowledged
+                stamp(5);  // cell arithmetic, atomics issued (acknowledged, in the timed build)
             }
         }
         stamp(6);
@@ -391,11 +455,11 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
             if (a.neg_log) a.neg_log[i] = chosen;
             if (a.sampled_log) a.sampled_log[i] = sampled;
         }
-        row1 = row2;
-        c_user = n_user;
-        c_pos = n_pos;
-        c_y = n_y;
-        c_w = n_w;
+        cur = nxt;
+        c_lo = n_lo;
+        c_hi = n_hi;
+        nxt = rec2;
+        row2 = row3;
     }
 
     // counters: sum over the group leaders, one atomic per wave and counter
@@ -417,6 +481,25 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
         if (c2) atomicAdd(a.counters + 2, c2);
         if (c3) atomicAdd(a.counters + 3, c3);
     }
+}
+
+// One 16-byte record per example instead of four 4-byte arrays: the epoch kernel then makes
+// one random access per interaction into the (shuffled) COO instead of four.
+__global__ void pack_records_kernel(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                                    const float *weight, int64_t n, int4 *out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st)
+        out[j] = make_int4(user_ids[j], item_ids[j], __float_as_int(Y[j]), __float_as_int(weight[j]));
+}
+
+hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
+                               const float *weight, int64_t n, void *out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int grid = (int)std::min<int64_t>(8192, (n + 255) / 256);
+    pack_records_kernel<<<grid, 256, 0, st>>>(user_ids, item_ids, Y, weight, n, (int4 *)out);
+    return hipGetLastError();
 }
 
 // LDS bytes per 256-thread workgroup of the tile kernel, or 0 if (d, max_sampled) is

@@ -5,8 +5,10 @@ mode               "parallel" (default): Hogwild over thousands of wavefronts, o
                    reference's order with its rand_r streams -- bit-exact, for parity tests.
 launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
 first_batch        negatives scored speculatively in the first batch (0 = auto).
-max_waves          cap on wavefronts (interactions) in flight, parallel mode (0 = auto).
-update_mode        0 atomic deltas (default), 1 plain load/store, 2 no writes (profiling).
+max_waves          cap on interactions in flight, parallel mode (0 = auto = min(n_users,
+                   n_items) / 6).
+update_mode        0 auto (= 3), 1 plain load/store Hogwild, 2 no writes (profiling),
+                   3 atomic deltas (global_atomic_add_f32, the default).
 occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
 warp_kernel        0 auto (lane-group tile kernel where it applies), 1 force the generic
                    one-interaction-per-wavefront WARP kernel.
@@ -27,6 +29,7 @@ class _Options(object):
         self.update_mode = int(os.environ.get("LIGHTFM_AMD_UPDATE_MODE", "0"))
         self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
         self.warp_kernel = int(os.environ.get("LIGHTFM_AMD_WARP_KERNEL", "0"))
+        self.debug = int(os.environ.get("LIGHTFM_AMD_DEBUG", "0"))
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None

@@ -117,14 +117,14 @@ SEQ = [("d64-adagrad", 64, "adagrad", 10), ("d32-adadelta", 32, "adadelta", 6),
 
 
 @pytest.mark.parametrize("case", SEQ, ids=[c[0] for c in SEQ])
-@pytest.mark.parametrize("update_mode", [1, 0], ids=["store", "atomic"])
+@pytest.mark.parametrize("update_mode", [1, 3], ids=["store", "atomic"])
 def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode):
     """launches_per_epoch = n makes the Hogwild kernel sequential: the sample logs must then
     equal the oracle's (same per-position streams) exactly and, two epochs later, every
-    array bit for bit when the kernel stores the new cell values (update_mode 1).  The
-    default mode publishes new - old with global_atomic_add_f32: old + fl32(new - old)
-    reproduces `new` except where the subtraction is inexact (a weight crossing zero), so
-    there the bar is one float32 ulp of the largest weight."""
+    array bit for bit with the default plain-store Hogwild update (update_mode 1).  Mode 3
+    publishes new - old with global_atomic_add_f32: old + fl32(new - old) reproduces `new`
+    except where the subtraction is inexact (a weight crossing zero), so there the bar is
+    one float32 ulp of the largest weight."""
     from lightfm_amd.options import options
     _, d, sched, ms = case
     coo = H.make_interactions(40, 30, 260, seed=3, ratings=True)
