@@ -32,6 +32,8 @@
 #include "device.hpp"
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace lfm {
 
 namespace {
@@ -46,6 +48,18 @@ __device__ __forceinline__ int fast_mod(uint32_t x, uint32_t n, uint32_t magic)
     uint32_t q = __umulhi(x, magic);
     int r = (int)(x - q * n);
     return r < 0 ? r + (int)n : r;
+}
+
+// Lane (k & 15) of every 16-lane DPP row, broadcast to the row (v_mov_b32 row_newbcast).
+__device__ __forceinline__ int row_bcast(int v, int k)
+{
+    switch (k & 15) {
+#define LFM_RB(K) case K: return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+        LFM_RB(0) LFM_RB(1) LFM_RB(2) LFM_RB(3) LFM_RB(4) LFM_RB(5) LFM_RB(6) LFM_RB(7)
+        LFM_RB(8) LFM_RB(9) LFM_RB(10) LFM_RB(11) LFM_RB(12) LFM_RB(13) LFM_RB(14) LFM_RB(15)
+#undef LFM_RB
+    }
+    return v;
 }
 
 // Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
@@ -117,7 +131,7 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 // TIMED (profiling builds of the same kernel, lfm_opts.warp_kernel = 2): every wave
 // accumulates s_memtime deltas per phase of a pass into a.counters[4..11].
 template <int LPR, bool TIMED, bool ADADELTA>
-__global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
+__global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
 {
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
@@ -250,31 +264,61 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
                 // up to 10 candidate rows per round, ALL requested before the first is staged
-                for (int k0 = 1; k0 <= nb; k0 += 10) {
-                    float4 v[10];
-                    int kk[10];
-                    const bool gln = need && pc;
+                const bool gln = need && pc;
+                if constexpr (LPR == 16) {
+                    // a lane group is a DPP row: row_newbcast:k hands lane k's item to its 16
+                    // lanes in one VALU instruction (no LDS round trip per candidate)
+                    auto round = [&](auto K0) {
+                        constexpr int k0 = decltype(K0)::value;
+                        float4 v[10];
 #pragma unroll
-                    for (int c5 = 0; c5 < 10; c5 += 5) {
-                        if (k0 + c5 <= nb) {  // wave-uniform
-                            int negs[5];
+                        for (int c5 = 0; c5 < 10; c5 += 5) {
+                            if (k0 + c5 <= nb) {  // wave-uniform
 #pragma unroll
-                            for (int j = 0; j < 5; ++j) {
-                                kk[c5 + j] = min(k0 + c5 + j, nb);
-                                negs[j] = __shfl(myitem, gbase + kk[c5 + j], WAVE);
+                                for (int j = 0; j < 5; ++j) {
+                                    // lanes past nb hold draw nb again: row nb is simply restaged
+                                    const int neg = row_bcast(myitem, k0 + c5 + j);
+                                    v[c5 + j] = ld4(gln ? Wi + (size_t)neg * d + 4 * p : Wi);
+                                }
                             }
-#pragma unroll
-                            for (int j = 0; j < 5; ++j)
-                                v[c5 + j] = ld4(gln ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
                         }
-                    }
-                    // only groups still looking restage: a finished group's chosen row must survive
+                        // only groups still looking restage: a finished group's chosen row must survive
 #pragma unroll
-                    for (int c5 = 0; c5 < 10; c5 += 5) {
-                        if (k0 + c5 <= nb && gln) {
+                        for (int c5 = 0; c5 < 10; c5 += 5) {
+                            if (k0 + c5 <= nb && gln) {
 #pragma unroll
-                            for (int j = 0; j < 5; ++j)
-                                st4(vrows + (size_t)kk[c5 + j] * TS + 4 * p, v[c5 + j]);
+                                for (int j = 0; j < 5; ++j)
+                                    st4(vrows + (size_t)min(k0 + c5 + j, nb) * TS + 4 * p, v[c5 + j]);
+                            }
+                        }
+                    };
+                    round(std::integral_constant<int, 1>());
+                    if (nb > 10) round(std::integral_constant<int, 11>());
+                } else {
+                    for (int k0 = 1; k0 <= nb; k0 += 10) {
+                        float4 v[10];
+                        int kk[10];
+#pragma unroll
+                        for (int c5 = 0; c5 < 10; c5 += 5) {
+                            if (k0 + c5 <= nb) {  // wave-uniform
+                                int negs[5];
+#pragma unroll
+                                for (int j = 0; j < 5; ++j) {
+                                    kk[c5 + j] = min(k0 + c5 + j, nb);
+                                    negs[j] = __shfl(myitem, gbase + kk[c5 + j], WAVE);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 5; ++j)
+                                    v[c5 + j] = ld4(gln ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
+                            }
+                        }
+#pragma unroll
+                        for (int c5 = 0; c5 < 10; c5 += 5) {
+                            if (k0 + c5 <= nb && gln) {
+#pragma unroll
+                                for (int j = 0; j < 5; ++j)
+                                    st4(vrows + (size_t)kk[c5 + j] * TS + 4 * p, v[c5 + j]);
+                            }
                         }
                     }
                 }
@@ -335,6 +379,11 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
             }
 
             // ---- updates: one group at a time, the whole wave on its three rows ----
+            // The prefetched records are forced into registers on EVERY path before any atomic
+            // is issued: the next pass then never waits for them behind the atomics'
+            // acknowledgements.
+            asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y), "+v"(rec2.z),
+                         "+v"(rec2.w));
             double lossd = 0.0;
             if (act && chosen >= 0) {
                 lossd = (double)c_w * a.logtab[sampled];  // PYX:881-885, log from host libm
@@ -354,13 +403,9 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                                       __builtin_amdgcn_readlane(c_pos, gg * LPR), neg, early);
                     }
                 }
-                // The prefetched records must be in registers BEFORE the atomics are issued:
-                // the next pass then starts without draining the atomics' acknowledgements
-                // (vmcnt is in order) ahead of its own gathers.
-                asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y),
-                             "+v"(rec2.z), "+v"(rec2.w));
-                // ... and so must every accumulator: a wait for one of them placed after the first
-                // atomic would also wait for that atomic's acknowledgement.
+                // Every accumulator must be in registers before the first atomic is issued: a wait for
+                // one of them placed later would also wait for that atomic's acknowledgement
+                // (vmcnt is an in-order counter).
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
                     if ((upd >> (gg * LPR)) & 1ull) {
@@ -449,6 +494,10 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_kernel(FitArgs a)
                 wave_sync();  // the tile is rewritten by the next pass
                 stamp(5);  // cell arithmetic, atomics issued (acknowledged, in the timed build)
             }
+        }
+        else {
+            asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y), "+v"(rec2.z),
+                         "+v"(rec2.w));
         }
         stamp(6);
         if (in && p == 0) {
