@@ -93,7 +93,8 @@ typedef struct lfm_opts {
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
                                    1 = force the generic one-interaction-per-wavefront kernel,
                                    2 = tile kernel instrumented with per-phase cycle counters */
-    int32_t debug;              /* reserved for kernel experiments; 0 */
+    int32_t debug;              /* kernel experiments; bits 0-2: force the tile kernel's
+                                   interactions per wavefront pass (1, 2 or 4); 0 = auto */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 (profiling build of the tile kernel): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator

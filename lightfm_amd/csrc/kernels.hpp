@@ -25,9 +25,10 @@ struct RanksArgs {
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
                       int occupancy = 0, int cus = 0);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)
-size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride);
-hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus,
-                                bool timed = false);
+// ng = interactions per wavefront pass (1, 2, 4); vec = floats of a row per lane
+size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec);
+hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
+                                int cus, bool timed = false);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);

@@ -598,23 +598,40 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                    (size_t)WAVES_PER_BLOCK * 2 * a.pair_cap);
     if (smem > 160 * 1024) return fail(LFM_EUNSUPPORTED, "k-OS n too large for the LDS pair buffer");
 
+    // Interactions allowed in flight (between reading the weights and publishing the update):
+    // every one of them is computed against weights the others are changing, and all their
+    // updates land.  Auto: min(n_users, n_items) / 6 -- measured: precision@10 within 0.002 of
+    // the reference at the ML-100k and ML-20M shapes (DESIGN.md "Hogwild at GPU width").
+    const int64_t rows_min = std::min<int64_t>(s->usf.rows, s->itf.rows);
+    const int64_t in_flight_cap = opts->max_waves > 0 ? opts->max_waves : std::max<int64_t>(16, rows_min / 6);
+
     // Parallel WARP over identity features without regularisation (BASELINE configs C2/C4):
-    // the lane-group tile kernel of warp_tile.hip, NG interactions per wavefront pass.
+    // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
+    // NG = 4 is the most instruction-efficient mapping; when the in-flight cap leaves the chip
+    // short of wavefronts, fewer interactions per wavefront buy more of them (latency hiding).
     bool use_tile = false;
-    int tile_ng = 1;
+    int tile_ng = 1, tile_vec = 0;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
         s->usf.identity && item_alpha == 0.0 && user_alpha == 0.0 && s->itf.rows >= 2) {
-        int trows = 0, tstride = 0;
-        size_t tsmem = warp_tile_geometry(s->d, s->max_sampled, &trows, &tstride);
-        if (tsmem > 0) {
+        const int forced = opts->debug & 7;  // experiment override: 1, 2 or 4
+        for (int ng : {4, 2, 1}) {
+            int trows = 0, tstride = 0, tvec = 0;
+            size_t tsmem = warp_tile_geometry(s->d, s->max_sampled, ng, &trows, &tstride, &tvec);
+            if (tsmem == 0) continue;
+            const bool enough_waves = in_flight_cap / ng >= (int64_t)s->cus * 8;
+            if (forced ? (ng != forced) : (!enough_waves && ng != 1)) continue;
             use_tile = true;
             smem = tsmem;
+            tile_ng = ng;
+            tile_vec = tvec;
             a.tile_rows = trows;
             a.tile_stride = tstride;
             a.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
             a.first_batch = std::max(1, std::min(a.first_batch, trows - 1));
             a.n_items_magic = (uint32_t)((1ull << 32) / (uint64_t)s->itf.rows) + 1u;
-            tile_ng = s->d <= 64 ? 4 : 2;
+            break;
+        }
+        if (use_tile) {
             if (!s->recs_valid) {
                 LFM_TRY(s->recs.alloc((size_t)s->n));
                 HIP_TRY(launch_pack_records(a.user_ids, a.item_ids, a.Y, a.weight, s->n, s->recs.p, s->stream));
@@ -646,12 +663,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
         int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(smem, 1)));
         int max_grid = s->cus * blocks_per_cu;
-        // Staleness bound: every interaction in flight is computed against weights the
-        // others are changing, and all their updates land.  Auto: min(n_users, n_items) / 6
-        // interactions in flight -- measured: precision@10 within 0.002 of the reference at
-        // the ML-100k and ML-20M shapes (DESIGN.md "Hogwild at GPU width").
-        int64_t rows_min = std::min<int64_t>(s->usf.rows, s->itf.rows);
-        int64_t max_waves = opts->max_waves > 0 ? opts->max_waves : std::max<int64_t>(16, rows_min / 6);
+        const int64_t max_waves = in_flight_cap;
         max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / (WAVES_PER_BLOCK * tile_ng)));
         if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
         for (int l = 0; l < L; ++l) {
@@ -660,7 +672,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (a.end <= a.begin) continue;
             int64_t waves = (a.end - a.begin + tile_ng - 1) / tile_ng;
             int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, grid, smem, s->stream, s->cus, opts->warp_kernel == 2));
+            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, tile_ng, tile_vec, grid, smem, s->stream, s->cus, opts->warp_kernel == 2));
             else HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));

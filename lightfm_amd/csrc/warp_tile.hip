@@ -1,536 +1,9 @@
-// warp_tile.hip -- the production WARP epoch kernel (fit_warp, PYX:784-912) for the
-// layout every BASELINE throughput configuration uses: identity user and item
-// features, no L2 regularisation, parallel (Hogwild) mode.
-// PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
-//
-// Work mapping (wave64).  A wavefront is split into NG = 64/LPR lane groups of LPR
-// lanes (LPR = 16 for d <= 64, 32 for d <= 128); each group owns ONE interaction
-// per pass, so a wave retires NG interactions per pass.
-//
-//   gather   an embedding row is d*4 bytes = LPR lanes x 16 bytes: ONE
-//            global_load_dwordx4 per wave fetches one row for each of the NG
-//            interactions (1 KiB per instruction, fully coalesced per row).  User
-//            row, positive row and the rows of ALL candidate negatives of the
-//            batch (max_sampled of them) are requested back to back before the
-//            first is consumed, then staged in a wave-private LDS tile.
-//   score    lane r of a group computes the reference's SEQUENTIAL float32 dot
-//            (PYX:320-334: (b_u + b_i) + u0*v0 + u1*v1 ...) of tile row r with the
-//            group's user row: the positive (r = 0) and every candidate negative
-//            (r = 1..nb) of all NG interactions are scored in one 16/32-step pass
-//            of ds_read_b128 -- the summation order, hence every margin test and
-//            every sample count, is the reference's.
-//   sample   within one interaction the weights do not change between draws
-//            (PYX:857-899 updates once, after the loop), so the first violator of
-//            the speculatively scored batch IS the sequential loop's choice; the
-//            PRNG stream of the position is advanced by exactly `sampled` draws.
-//   lookup   in_positives (PYX:270-284) as an LPR-ary search run by the group.
-//   update   groups with a violator are handed, one after the other, to the WHOLE
-//            wave: lane c owns coordinate c (Adagrad/Adadelta are per-coordinate,
-//            PYX:416-449), reads its cell of the three rows from the LDS tile, the
-//            accumulators from memory, evaluates the reference's float64 cell
-//            arithmetic and publishes new-old with global_atomic_add_f32.
+// warp_tile.hip -- host side of the lane-group WARP tile kernel (warp_tile_kernel.hpp): the
+// record packing kernel, tile geometry and the dispatcher over the instantiated variants.
 #include "device.hpp"
 #include "kernels.hpp"
 
-#include <type_traits>
-
 namespace lfm {
-
-namespace {
-
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
-
-// x % n for x < 2^31, 2 <= n < 2^31, with magic = floor(2^32 / n) + 1:
-// floor(x*magic / 2^32) is floor(x/n) or one more (x*magic/2^32 lies in (x/n, x/n + 1/2)).
-__device__ __forceinline__ int fast_mod(uint32_t x, uint32_t n, uint32_t magic)
-{
-    uint32_t q = __umulhi(x, magic);
-    int r = (int)(x - q * n);
-    return r < 0 ? r + (int)n : r;
-}
-
-// Lane (k & 15) of every 16-lane DPP row, broadcast to the row (v_mov_b32 row_newbcast).
-__device__ __forceinline__ int row_bcast(int v, int k)
-{
-    switch (k & 15) {
-#define LFM_RB(K) case K: return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
-        LFM_RB(0) LFM_RB(1) LFM_RB(2) LFM_RB(3) LFM_RB(4) LFM_RB(5) LFM_RB(6) LFM_RB(7)
-        LFM_RB(8) LFM_RB(9) LFM_RB(10) LFM_RB(11) LFM_RB(12) LFM_RB(13) LFM_RB(14) LFM_RB(15)
-#undef LFM_RB
-    }
-    return v;
-}
-
-// Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
-__device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi)
-{
-    float acc = __fadd_rn(bu, bi);
-    int c = 0;
-    // 8 ds_read_b128 in flight per 16 coordinates: the LDS latency is paid once per block
-    for (; c + 16 <= d; c += 16) {
-        float4 a[4], x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = ld4(u + c + 4 * j);
-            x[j] = ld4(v + c + 4 * j);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc = __fadd_rn(acc, __fmul_rn(a[j].x, x[j].x));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].y, x[j].y));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].z, x[j].z));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].w, x[j].w));
-        }
-    }
-    for (; c < d; c += 4) {
-        float4 a = ld4(u + c);
-        float4 x = ld4(v + c);
-        acc = __fadd_rn(acc, __fmul_rn(a.x, x.x));
-        acc = __fadd_rn(acc, __fmul_rn(a.y, x.y));
-        acc = __fadd_rn(acc, __fmul_rn(a.z, x.z));
-        acc = __fadd_rn(acc, __fmul_rn(a.w, x.w));
-    }
-    return acc;
-}
-
-// in_positives (PYX:270-284) for NG lane groups at once: every participating group
-// searches its own sorted row [lo, hi) for its own item with an LPR-ary search.
-template <int LPR>
-__device__ __forceinline__ bool group_in_positives(const int32_t *indices, int item, int lo, int hi,
-                                                   bool part, int gbase, int p)
-{
-    constexpr uint32_t GM = LPR == 32 ? 0xffffffffu : ((1u << LPR) - 1u);
-    constexpr int SH = LPR == 32 ? 5 : 4;
-    bool dead = !part;  // group already knows the answer is "absent"
-    while (true) {
-        bool wide = !dead && (hi - lo > LPR);
-        if (__ballot(wide) == 0ull) break;
-        int step = (hi - lo + LPR - 1) >> SH;
-        int idx = lo + p * step;
-        bool ok = wide && idx < hi;
-        int v = ok ? indices[idx] : 0x7fffffff;
-        unsigned long long m = __ballot(ok && v <= item);
-        int cnt = __popc((uint32_t)(m >> gbase) & GM);
-        if (wide) {
-            if (cnt == 0) dead = true;  // item below the row's first entry
-            else {
-                lo = lo + (cnt - 1) * step;
-                hi = min(hi, lo + step);
-            }
-        }
-    }
-    int idx = lo + p;
-    bool hit = !dead && idx < hi && indices[idx] == item;
-    unsigned long long m = __ballot(hit);
-    return ((uint32_t)(m >> gbase) & GM) != 0u;
-}
-
-}  // namespace
-
-// TIMED (profiling builds of the same kernel, lfm_opts.warp_kernel = 2): every wave
-// accumulates s_memtime deltas per phase of a pass into a.counters[4..11].
-template <int LPR, bool TIMED, bool ADADELTA>
-__global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
-{
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int k) {
-        if constexpr (TIMED) {
-            if (a.debug & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain: pure phases
-            unsigned long long t = __builtin_readcyclecounter();
-            ph[k] += t - tprev;
-            tprev = t;
-        }
-    };
-    if constexpr (TIMED) tprev = __builtin_readcyclecounter();
-    constexpr int NG = WAVE / LPR;        // interactions per wave pass
-    constexpr int NC = (LPR * 4) / WAVE;  // coordinates per lane in the update phase
-    constexpr uint32_t GM = LPR == 32 ? 0xffffffffu : ((1u << LPR) - 1u);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = lane_id(), wib = threadIdx.x >> 6;
-    const int g = lane / LPR, p = lane % LPR, gbase = g * LPR;
-    const int d = a.m.d, TS = a.tile_stride, RG = a.tile_rows;
-    // wave-private tile: NG*RG item rows (row 0 of a group = the positive) + NG user rows
-    float *tile = smem + (size_t)wib * (NG * RG + NG) * TS;
-    float *vrows = tile + (size_t)g * RG * TS;
-    float *urow = tile + (size_t)(NG * RG + g) * TS;
-    const bool pc = 4 * p < d;  // this lane carries a 16-byte piece of every gathered row
-    const float *Wi = a.m.W[0], *Wu = a.m.W[1];
-    const float *bi_tab = a.m.b[0], *bu_tab = a.m.b[1];
-    const int max_sampled = a.m.max_sampled;
-    const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
-    const uint32_t base_seed = a.seeds[0];
-    const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
-    const int um = a.update_mode;
-
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
-    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
-    const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
-    float *WiW = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
-    float *WuW = a.m.W[1], *Gu = a.m.G[1], *Mu = a.m.M[1];
-
-    // Software pipeline over the interaction records, three passes deep: while pass t is
-    // processed, the bounds of pass t+1's positives row, the (user, item, y, weight) record
-    // of pass t+2 and the shuffle entry of pass t+3 are in flight.
-    int64_t ib = a.begin + gw * NG;
-    int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
-    int c_lo = 0, c_hi = 0, row2 = 0;
-    if (ib + g < a.end) {
-        cur = a.recs[a.shuffle[ib + g]];
-        c_lo = indptr[cur.x];
-        c_hi = indptr[cur.x + 1];
-    }
-    if (ib + stride + g < a.end) nxt = a.recs[a.shuffle[ib + stride + g]];
-    if (ib + 2 * stride + g < a.end) row2 = a.shuffle[ib + 2 * stride + g];
-
-    for (; ib < a.end; ib += stride) {
-        const int64_t i = ib + g;
-        const bool in = i < a.end;
-        int n_lo = 0, n_hi = 0, row3 = 0;
-        int4 rec2 = make_int4(0, 0, 0, 0);
-        if (i + stride < a.end) {
-            n_lo = indptr[nxt.x];
-            n_hi = indptr[nxt.x + 1];
-        }
-        if (i + 2 * stride < a.end) rec2 = a.recs[row2];
-        if (i + 3 * stride < a.end) row3 = a.shuffle[i + 3 * stride];
-        const int c_user = cur.x, c_pos = cur.y;
-        const float c_y = __int_as_float(cur.z), c_w = __int_as_float(cur.w);
-        const bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
-        int sampled = 0, chosen = -1, chosen_r = 0;
-        stamp(0);
-
-        if (__ballot(act) != 0ull) {
-            // ---- gather: user row, positive row, user bias
-            const bool gl = act && pc;
-            // lanes without a piece read the table's first 16 bytes instead of branching
-            const float4 u4 = ld4(gl ? Wu + (size_t)c_user * d + 4 * p : Wu);
-            const float4 p4 = ld4(gl ? Wi + (size_t)c_pos * d + 4 * p : Wi);
-            float bu = 0.0f;
-            if (act) bu = bu_tab[c_user];
-            uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
-            if (gl) {
-                st4(urow + 4 * p, u4);
-                st4(vrows + 4 * p, p4);
-            }
-            // accumulator rows / bias cells of the groups that will (probably) update
-            float gP[NG][NC], gN[NG][NC], gU[NG][NC], mP[NG][NC], mN[NG][NC], mU[NG][NC];
-            float obW[NG], obG[NG], obM[NG];
-            unsigned long long specm = 0ull;  // groups whose accumulators were requested early
-            int spec_cand = -1;               // ... for this candidate negative
-            auto load_rows = [&](int gg, int user, int pos, int neg, bool only_neg) {
-                const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
-#pragma unroll
-                for (int q = 0; q < NC; ++q) {
-                    // plain loads, lanes past d re-read coordinate 0: no exec-masked branches,
-                    // so all rows of all groups are in flight together
-                    const int c = lane + WAVE * q;
-                    const int cc = c < d ? c : 0;
-                    gN[gg][q] = Gi[bn + cc];
-                    if (ADADELTA) mN[gg][q] = Mi[bn + cc];
-                    if (!only_neg) {
-                        gP[gg][q] = Gi[bp + cc];
-                        gU[gg][q] = Gu[bu_ + cc];
-                        if (ADADELTA) {
-                            mP[gg][q] = Mi[bp + cc];
-                            mU[gg][q] = Mu[bu_ + cc];
-                        }
-                    }
-                }
-                // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
-                const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-                const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
-                const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
-                const float *bMp = lane >= 2 ? a.m.bM[1] : a.m.bM[0];
-                if (!only_neg || lane == 1) {
-                    obW[gg] = bWp[brow];
-                    obG[gg] = bGp[brow];
-                    if (ADADELTA) obM[gg] = bMp[brow];
-                }
-            };
-            double pp = 0.0;
-            int done = 0;  // draws consumed by every group that is still looking (wave-uniform)
-            while (done < max_sampled) {
-                const bool need = act && chosen < 0;
-                if (__ballot(need) == 0ull) break;
-                const int nb = min(max_sampled - done, done == 0 ? a.first_batch : RG - 1);
-                // lane p holds the stream after min(p, nb) further steps: draw #(done + p)
-                uint32_t s = state;
-                for (int j = 0; j < nb; ++j)
-                    if (j < p) s = lcg(s);
-                const int myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);  // PYX:860-861
-                const bool rowlane = need && p <= nb && (p > 0 || done == 0);
-                float bi = 0.0f;
-                if (rowlane) bi = bi_tab[myitem];
-                // up to 10 candidate rows per round, ALL requested before the first is staged
-                const bool gln = need && pc;
-                if constexpr (LPR == 16) {
-                    // a lane group is a DPP row: row_newbcast:k hands lane k's item to its 16
-                    // lanes in one VALU instruction (no LDS round trip per candidate)
-                    auto round = [&](auto K0) {
-                        constexpr int k0 = decltype(K0)::value;
-                        float4 v[10];
-#pragma unroll
-                        for (int c5 = 0; c5 < 10; c5 += 5) {
-                            if (k0 + c5 <= nb) {  // wave-uniform
-#pragma unroll
-                                for (int j = 0; j < 5; ++j) {
-                                    // lanes past nb hold draw nb again: row nb is simply restaged
-                                    const int neg = row_bcast(myitem, k0 + c5 + j);
-                                    v[c5 + j] = ld4(gln ? Wi + (size_t)neg * d + 4 * p : Wi);
-                                }
-                            }
-                        }
-                        // only groups still looking restage: a finished group's chosen row must survive
-#pragma unroll
-                        for (int c5 = 0; c5 < 10; c5 += 5) {
-                            if (k0 + c5 <= nb && gln) {
-#pragma unroll
-                                for (int j = 0; j < 5; ++j)
-                                    st4(vrows + (size_t)min(k0 + c5 + j, nb) * TS + 4 * p, v[c5 + j]);
-                            }
-                        }
-                    };
-                    round(std::integral_constant<int, 1>());
-                    if (nb > 10) round(std::integral_constant<int, 11>());
-                } else {
-                    for (int k0 = 1; k0 <= nb; k0 += 10) {
-                        float4 v[10];
-                        int kk[10];
-#pragma unroll
-                        for (int c5 = 0; c5 < 10; c5 += 5) {
-                            if (k0 + c5 <= nb) {  // wave-uniform
-                                int negs[5];
-#pragma unroll
-                                for (int j = 0; j < 5; ++j) {
-                                    kk[c5 + j] = min(k0 + c5 + j, nb);
-                                    negs[j] = __shfl(myitem, gbase + kk[c5 + j], WAVE);
-                                }
-#pragma unroll
-                                for (int j = 0; j < 5; ++j)
-                                    v[c5 + j] = ld4(gln ? Wi + (size_t)negs[j] * d + 4 * p : Wi);
-                            }
-                        }
-#pragma unroll
-                        for (int c5 = 0; c5 < 10; c5 += 5) {
-                            if (k0 + c5 <= nb && gln) {
-#pragma unroll
-                                for (int j = 0; j < 5; ++j)
-                                    st4(vrows + (size_t)kk[c5 + j] * TS + 4 * p, v[c5 + j]);
-                            }
-                        }
-                    }
-                }
-                wave_sync();
-                stamp(1);  // gathers landed and staged
-                float score = 0.0f;
-                if (rowlane) score = row_dot(urow, vrows + (size_t)p * TS, d, bu, bi);
-                if (done == 0) pp = (double)__shfl(score, gbase, WAVE);
-                // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
-                const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
-                uint32_t vm = (uint32_t)(__ballot(viol) >> gbase) & GM;
-                int used = nb;
-                stamp(2);  // scoring pass
-                if (done == 0) {
-                    // The first violator is almost always the choice (a uniformly drawn item is
-                    // rarely one of the user's positives): request the accumulator rows of its
-                    // update now, so they travel while in_positives confirms it.
-                    const int r1 = vm != 0u ? (__ffs((int)vm) - 1) : 0;
-                    spec_cand = __shfl(myitem, gbase + r1, WAVE);
-                    specm = __ballot(need && vm != 0u && p == 0);
-#pragma unroll
-                    for (int gg = 0; gg < NG; ++gg) {
-                        if ((specm >> (gg * LPR)) & 1ull)
-                            load_rows(gg, __builtin_amdgcn_readlane(c_user, gg * LPR),
-                                      __builtin_amdgcn_readlane(c_pos, gg * LPR),
-                                      __builtin_amdgcn_readlane(spec_cand, gg * LPR), false);
-                    }
-                }
-                while (true) {
-                    const bool part = need && chosen < 0 && vm != 0u;
-                    if (__ballot(part) == 0ull) break;
-                    const int r = part ? (__ffs((int)vm) - 1) : 0;
-                    if (part) vm &= vm - 1u;
-                    const int cand = __shfl(myitem, gbase + r, WAVE);
-                    const bool found = group_in_positives<LPR>(indices, cand, c_lo, c_hi, part, gbase, p);
-                    if (part) {
-                        c3++;  // PYX:878-879: the draw still counts
-                        if (!found) {
-                            chosen = cand;
-                            chosen_r = r;
-                            used = r;
-                        }
-                    }
-                }
-                const uint32_t ns = (uint32_t)__shfl((int)s, gbase + used, WAVE);
-                if (need) {
-                    sampled += used;
-                    state = ns;
-                }
-                wave_sync();
-                done += nb;
-                stamp(3);  // in_positives searches
-            }
-            if (act) {
-                c0++;
-                c1 += (unsigned long long)sampled;
-                if (chosen >= 0) c2++;
-            }
-
-            // ---- updates: one group at a time, the whole wave on its three rows ----
-            // The prefetched records are forced into registers on EVERY path before any atomic
-            // is issued: the next pass then never waits for them behind the atomics'
-            // acknowledgements.
-            asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y), "+v"(rec2.z),
-                         "+v"(rec2.w));
-            double lossd = 0.0;
-            if (act && chosen >= 0) {
-                lossd = (double)c_w * a.logtab[sampled];  // PYX:881-885, log from host libm
-                if (lossd > MAX_LOSS) lossd = MAX_LOSS;
-            }
-            const unsigned long long upd = __ballot(act && chosen >= 0 && p == 0);
-            if (upd != 0ull) {
-                // accumulators not requested early (violator found in a later batch), or requested
-                // for a candidate that turned out to be a positive
-#pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    if ((upd >> (gg * LPR)) & 1ull) {
-                        const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
-                        const bool early = (specm >> (gg * LPR)) & 1ull;
-                        if (!early || neg != __builtin_amdgcn_readlane(spec_cand, gg * LPR))
-                            load_rows(gg, __builtin_amdgcn_readlane(c_user, gg * LPR),
-                                      __builtin_amdgcn_readlane(c_pos, gg * LPR), neg, early);
-                    }
-                }
-                // Every accumulator must be in registers before the first atomic is issued: a wait for
-                // one of them placed later would also wait for that atomic's acknowledgement
-                // (vmcnt is an in-order counter).
-#pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    if ((upd >> (gg * LPR)) & 1ull) {
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            asm volatile("" : "+v"(gP[gg][q]), "+v"(gN[gg][q]), "+v"(gU[gg][q]));
-                            if (ADADELTA) asm volatile("" : "+v"(mP[gg][q]), "+v"(mN[gg][q]), "+v"(mU[gg][q]));
-                        }
-                        asm volatile("" : "+v"(obW[gg]), "+v"(obG[gg]));
-                        if (ADADELTA) asm volatile("" : "+v"(obM[gg]));
-                    }
-                }
-                stamp(4);  // accumulator rows landed
-                // cell arithmetic (PYX:416-449 in float64) and atomic publication
-#pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    if ((upd >> (gg * LPR)) & 1ull) {
-                        const int user = __builtin_amdgcn_readlane(c_user, gg * LPR);
-                        const int pos = __builtin_amdgcn_readlane(c_pos, gg * LPR);
-                        const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
-                        const int cr = __builtin_amdgcn_readlane(chosen_r, gg * LPR);
-                        const double loss = read_laned(lossd, gg * LPR);
-                        const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
-                        const float *tu = tile + (size_t)(NG * RG + gg) * TS;
-                        const float *tp = tile + (size_t)(gg * RG) * TS;
-                        const float *tn = tile + (size_t)(gg * RG + cr) * TS;
-                        // All cell arithmetic of the group first, as ONE straight-line block (the
-                        // 3*NC row cells and the bias cell are independent float64 dependency
-                        // chains the scheduler interleaves), then every publication.
-                        float oWr[NC][3], nWr[NC][3], nGr[NC][3], nMr[NC][3];
-                        double lr;
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            const int c = lane + WAVE * q;
-                            const int cc = c < d ? c : 0;
-                            const float Uc = tu[cc], Pc = tp[cc], Nc = tn[cc];
-                            const double u = (double)Uc;
-                            const double df = (double)__fsub_rn(Nc, Pc);  // float32 subtraction, PYX:634-635
-                            oWr[q][0] = Pc;
-                            oWr[q][1] = Nc;
-                            oWr[q][2] = Uc;
-                            cell_math(Pc, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, 0.0,
-                                      nWr[q][0], nGr[q][0], nMr[q][0], lr);
-                            cell_math(Nc, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, 0.0,
-                                      nWr[q][1], nGr[q][1], nMr[q][1], lr);
-                            cell_math(Uc, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, 0.0,
-                                      nWr[q][2], nGr[q][2], nMr[q][2], lr);
-                        }
-                        float bnW, bnG, bnM;
-                        const float ooM = ADADELTA ? obM[gg] : 0.0f;
-                        cell_math(obW[gg], obG[gg], ooM, 1.0, lane == 0 ? -loss : loss, h, 0.0, bnW, bnG, bnM, lr);
-                        // keep the arithmetic above one block: nothing of it may sink below a publication
-#pragma unroll
-                        for (int q = 0; q < NC; ++q)
-                            asm volatile("" : "+v"(nWr[q][0]), "+v"(nWr[q][1]), "+v"(nWr[q][2]), "+v"(nGr[q][0]),
-                                         "+v"(nGr[q][1]), "+v"(nGr[q][2]));
-                        asm volatile("" : "+v"(bnW), "+v"(bnG));
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            const int c = lane + WAVE * q;
-                            if (c < d) {
-                                publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
-                                publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
-                                publish(WiW + bn + c, nWr[q][1], oWr[q][1], um);
-                                publish(Gi + bn + c, nGr[q][1], gN[gg][q], um);
-                                publish(WuW + bu_ + c, nWr[q][2], oWr[q][2], um);
-                                publish(Gu + bu_ + c, nGr[q][2], gU[gg][q], um);
-                                if (ADADELTA) {
-                                    publish(Mi + bp + c, nMr[q][0], mP[gg][q], um);
-                                    publish(Mi + bn + c, nMr[q][1], mN[gg][q], um);
-                                    publish(Mu + bu_ + c, nMr[q][2], mU[gg][q], um);
-                                }
-                            }
-                        }
-                        if (lane < 3) {
-                            const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-                            float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
-                            float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
-                            float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
-                            publish(bWp + brow, bnW, obW[gg], um);
-                            publish(bGp + brow, bnG, obG[gg], um);
-                            if (ADADELTA) publish(bMp + brow, bnM, ooM, um);
-                        }
-                    }
-                }
-                wave_sync();  // the tile is rewritten by the next pass
-                stamp(5);  // cell arithmetic, atomics issued (acknowledged, in the timed build)
-            }
-        }
-        else {
-            asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y), "+v"(rec2.z),
-                         "+v"(rec2.w));
-        }
-        stamp(6);
-        if (in && p == 0) {
-            if (a.neg_log) a.neg_log[i] = chosen;
-            if (a.sampled_log) a.sampled_log[i] = sampled;
-        }
-        cur = nxt;
-        c_lo = n_lo;
-        c_hi = n_hi;
-        nxt = rec2;
-        row2 = row3;
-    }
-
-    // counters: sum over the group leaders, one atomic per wave and counter
-    if (p != 0) c0 = c1 = c2 = c3 = 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        c0 += __shfl_xor(c0, off, WAVE);
-        c1 += __shfl_xor(c1, off, WAVE);
-        c2 += __shfl_xor(c2, off, WAVE);
-        c3 += __shfl_xor(c3, off, WAVE);
-    }
-    if constexpr (TIMED) {
-        if (lane == 0)
-            for (int k = 0; k < 8; ++k) atomicAdd(a.counters + 4 + k, ph[k]);
-    }
-    if (lane == 0) {
-        if (c0) atomicAdd(a.counters + 0, c0);
-        if (c1) atomicAdd(a.counters + 1, c1);
-        if (c2) atomicAdd(a.counters + 2, c2);
-        if (c3) atomicAdd(a.counters + 3, c3);
-    }
-}
 
 // One 16-byte record per example instead of four 4-byte arrays: the epoch kernel then makes
 // one random access per interaction into the (shuffled) COO instead of four.
@@ -551,40 +24,40 @@ hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids,
     return hipGetLastError();
 }
 
-// LDS bytes per 256-thread workgroup of the tile kernel, or 0 if (d, max_sampled) is
-// outside what it supports.  rows/stride are the tile geometry it must be launched with.
-size_t warp_tile_geometry(int d, int max_sampled, int *rows, int *stride)
+// Tile geometry for `ng` interactions per wavefront pass (1, 2 or 4): lanes per row = 64 / ng,
+// a lane carries vec = 1, 2 or 4 consecutive floats of a row.  Returns the LDS bytes per
+// 256-thread workgroup, or 0 if (d, max_sampled, ng) is outside what the kernel supports.
+size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec)
 {
-    if (d < 4 || d > 128 || (d & 3) != 0 || max_sampled < 1) return 0;
-    const int lpr = d <= 64 ? 16 : 32, ng = WAVE / lpr;
-    const int ts = d + 4;  // 16-byte aligned rows, rows 4 dwords apart in bank phase
+    if (d < 4 || (d & 3) != 0 || max_sampled < 1 || (ng != 1 && ng != 2 && ng != 4)) return 0;
+    const int lpr = WAVE / ng;
+    int v = 0;
+    for (int c : {1, 2, 4})
+        if (!v && lpr * c >= d && lpr * c >= WAVE) v = c;
+    if (!v) return 0;  // d too wide for this many interactions per pass
+    const int ts = d + 4;  // 16-byte aligned rows, consecutive rows 4 dwords apart in bank phase
     int rg = std::min(max_sampled, lpr - 1) + 1;
-    // keep three workgroups per CU resident (160 KiB LDS): <= 52 KiB per workgroup
-    while (rg > 2 && (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float) > 52 * 1024) --rg;
+    // at least two workgroups per CU (160 KiB LDS)
+    while (rg > 2 && (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float) > 78 * 1024) --rg;
     *rows = rg;
     *stride = ts;
+    *vec = v;
     return (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float);
 }
 
-hipError_t launch_fit_warp_tile(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus,
-                                bool timed)
+hipError_t launch_tile_lpr16(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
+hipError_t launch_tile_lpr32(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
+hipError_t launch_tile_lpr64(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
+
+hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
+                                int cus, bool timed)
 {
-    const bool small = a.m.d <= 64;
-    void (*kernel)(FitArgs);
-    if (a.m.adadelta)
-        kernel = small ? fit_warp_tile_kernel<16, false, true> : fit_warp_tile_kernel<32, false, true>;
-    else if (timed)
-        kernel = small ? fit_warp_tile_kernel<16, true, false> : fit_warp_tile_kernel<32, true, false>;
-    else
-        kernel = small ? fit_warp_tile_kernel<16, false, false> : fit_warp_tile_kernel<32, false, false>;
-    if (cus > 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) == hipSuccess &&
-            per_cu > 0)
-            grid = std::min(grid, per_cu * cus);
+    switch (ng) {
+    case 4: return launch_tile_lpr16(a, vec, grid, smem, st, cus, timed);
+    case 2: return launch_tile_lpr32(a, vec, grid, smem, st, cus, timed);
+    case 1: return launch_tile_lpr64(a, vec, grid, smem, st, cus, timed);
+    default: return hipErrorInvalidValue;
     }
-    kernel<<<grid, 256, smem, st>>>(a);
-    return hipGetLastError();
 }
 
 }  // namespace lfm

@@ -1,0 +1,17 @@
+// warp_tile_lpr32.hip -- instantiations of the lane-group tile kernel with 32 lanes per row
+// (2 interactions per wavefront pass); see warp_tile_kernel.hpp.
+#include "warp_tile_kernel.hpp"
+
+namespace lfm {
+
+hipError_t launch_tile_lpr32(const FitArgs &a, int vec, int grid, size_t smem, hipStream_t st, int cus,
+                             bool timed)
+{
+    switch (vec) {
+    case 2: return launch_tile_variant<32, 2>(a, grid, smem, st, cus, timed);
+    case 4: return launch_tile_variant<32, 4>(a, grid, smem, st, cus, timed);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lfm

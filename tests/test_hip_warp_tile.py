@@ -33,7 +33,11 @@ def fast():
 
 
 _DEFAULTS = dict(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0,
-                 log_samples=False, warp_kernel=0, update_mode=0)
+                 log_samples=False, warp_kernel=0, update_mode=0, debug=0)
+
+# options.debug bits 0-2 force the tile kernel's interactions per wavefront pass (NG = 4, 2, 1:
+# 16, 32, 64 lanes per row); 0 = the session's automatic choice
+NGS = [0, 4, 2, 1]
 
 
 @pytest.fixture(autouse=True)
@@ -84,14 +88,18 @@ FROZEN = [
     ("d128-ms35-multibatch", 100, 300, 3000, 128, 35, 0, False),
     ("longrows", 12, 6000, 30000, 64, 10, 0, False),
     ("two-items", 50, 2, 60, 64, 10, 0, False),
+    ("d256-ms10", 60, 90, 1500, 256, 10, 0, False),
 ]
 
 
 @pytest.mark.parametrize("case", FROZEN, ids=[c[0] for c in FROZEN])
-@pytest.mark.parametrize("kernel", [0, 1], ids=["tile", "generic"])
+@pytest.mark.parametrize("kernel", ["generic", "tile-auto", "tile-ng4", "tile-ng2", "tile-ng1"])
 def test_frozen_weights_samples_exact(fast, case, kernel):
     from lightfm_amd.options import options
     _, nu, ni, nnz, d, ms, fb, ratings = case
+    ng = {"generic": 0, "tile-auto": 0, "tile-ng4": 4, "tile-ng2": 2, "tile-ng1": 1}[kernel]
+    if (ng == 4 and d > 64) or (ng == 2 and d > 128):
+        pytest.skip("row wider than the lane group covers: the session falls back to fewer per wave")
     coo = H.make_interactions(nu, ni, nnz, seed=17, ratings=ratings, zipf=0.6)
     rng = np.random.RandomState(9)
     st = oracle.State(ni, nu, d, rng, max_sampled=ms)
@@ -101,7 +109,8 @@ def test_frozen_weights_samples_exact(fast, case, kernel):
     a, b = st.copy(), st.copy()
     zeros = np.zeros_like(coo.data)
     shuffle, seeds = H.epoch_inputs(coo, rng)
-    options.set(log_samples=True, launches_per_epoch=3, first_batch=fb, warp_kernel=kernel)
+    options.set(log_samples=True, launches_per_epoch=3, first_batch=fb,
+                warp_kernel=1 if kernel == "generic" else 0, debug=ng)
     _hip_warp(fast, coo, a, shuffle, seeds, zeros)
     o = _orc_warp(coo, b, shuffle, seeds, zeros)
     neg, sampled = options.last_logs
@@ -113,12 +122,14 @@ def test_frozen_weights_samples_exact(fast, case, kernel):
 
 
 SEQ = [("d64-adagrad", 64, "adagrad", 10), ("d32-adadelta", 32, "adadelta", 6),
-       ("d128-adagrad", 128, "adagrad", 10), ("d20-adagrad", 20, "adagrad", 20)]
+       ("d128-adagrad", 128, "adagrad", 10), ("d20-adagrad", 20, "adagrad", 20),
+       ("d200-adagrad", 200, "adagrad", 10)]
 
 
 @pytest.mark.parametrize("case", SEQ, ids=[c[0] for c in SEQ])
 @pytest.mark.parametrize("update_mode", [1, 3], ids=["store", "atomic"])
-def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode):
+@pytest.mark.parametrize("ng", [4, 2, 1])
+def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode, ng):
     """launches_per_epoch = n makes the Hogwild kernel sequential: the sample logs must then
     equal the oracle's (same per-position streams) exactly and, two epochs later, every
     array bit for bit with the default plain-store Hogwild update (update_mode 1).  Mode 3
@@ -127,12 +138,14 @@ def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode):
     one float32 ulp of the largest weight."""
     from lightfm_amd.options import options
     _, d, sched, ms = case
+    if (ng == 4 and d > 64) or (ng == 2 and d > 128):
+        pytest.skip("row wider than the lane group covers")
     coo = H.make_interactions(40, 30, 260, seed=3, ratings=True)
     rng = np.random.RandomState(4)
     st = oracle.State(30, 40, d, rng, schedule=sched, max_sampled=ms)
     _spread(st)
     a, b = st.copy(), st.copy()
-    options.set(log_samples=True, launches_per_epoch=len(coo.data), update_mode=update_mode)
+    options.set(log_samples=True, launches_per_epoch=len(coo.data), update_mode=update_mode, debug=ng)
     for _ in range(2):
         shuffle, seeds = H.epoch_inputs(coo, rng)
         _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
@@ -187,7 +200,7 @@ def test_concurrent_disjoint_groups_bit_exact(fast, d, group):
     st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
     _spread(st)
     a, b = st.copy(), st.copy()
-    options.set(log_samples=True, launches_per_epoch=n // group, update_mode=1)
+    options.set(log_samples=True, launches_per_epoch=n // group, update_mode=1, debug=group)
     _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
     o = _orc_warp(coo, b, shuffle, seeds, coo.data)
     neg, sampled = options.last_logs
