@@ -199,18 +199,40 @@ __device__ __forceinline__ void load_rep(const DCsr &f, const float *W, const fl
 #pragma unroll
     for (int q = 0; q < NC; ++q) r.v[q] = 0.0f;
     r.bias = 0.0f;
-    int s = uni(f.indptr[row]), e = uni(f.indptr[row + 1]);
-    for (int k = s; k < e; ++k) {
-        int feat = uni(f.indices[k]);
-        float w = (float)((double)unif(f.data[k]) * scale);
-        const float *wr = W + (size_t)feat * d;
+    const int s = uni(f.indptr[row]), e = uni(f.indptr[row + 1]);
+    // The row's (feature, weight) entries are fetched 64 at a time, one per lane (one round
+    // trip), then the embedding rows 8 at a time (one round trip per 8 features); the float32
+    // accumulation still runs in CSR order.
+    for (int k0 = s; k0 < e; k0 += WAVE) {
+        const int cnt = min(WAVE, e - k0);
+        const int myfeat = lane < cnt ? f.indices[k0 + lane] : 0;
+        const float myw = lane < cnt ? f.data[k0 + lane] : 0.0f;
+        for (int j0 = 0; j0 < cnt; j0 += 8) {
+            float x[8][NC], bx[8];
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            int c = lane + WAVE * q;
-            float x = (c < d) ? ldw(wr + c) : 0.0f;
-            r.v[q] = __fadd_rn(r.v[q], __fmul_rn(w, x));
+            for (int j = 0; j < 8; ++j) {
+                const int feat = read_lane(myfeat, min(j0 + j, cnt - 1));
+                const float *wr = W + (size_t)feat * d;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int c = lane + WAVE * q;
+                    x[j][q] = ldw(wr + (c < d ? c : 0));
+                }
+                bx[j] = ldw(b + feat);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j0 + j < cnt) {
+                    const float w = (float)((double)read_lanef(myw, j0 + j) * scale);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        r.v[q] = __fadd_rn(r.v[q], __fmul_rn(w, c < d ? x[j][q] : 0.0f));
+                    }
+                    r.bias = __fadd_rn(r.bias, __fmul_rn(w, bx[j]));
+                }
+            }
         }
-        r.bias = __fadd_rn(r.bias, __fmul_rn(w, ldw(b + feat)));
     }
 }
 
@@ -380,6 +402,79 @@ __device__ __forceinline__ void update_row(const DCsr &f, int row, int side, con
     }
 }
 
+// update_row for parallel (Hogwild) mode: the same cells and the same arithmetic, but the row's
+// entries are fetched in one round trip (one per lane), every bias cell is updated by its own
+// lane at once, and the coordinate cells of 4 features are in flight together.  A feature that
+// occurs twice in the row gets both updates computed from the same old value (Hogwild within the
+// wavefront); serial mode keeps the strictly sequential update_row above.
+template <int NC>
+__device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int side, const DModel &m,
+                                                   const float (&x)[NC], double gcoef, double gbias,
+                                                   double alpha, bool atomic, int lane,
+                                                   double &lr_bias, double (&lr_comp)[NC])
+{
+    const Hyper h{m.adadelta, m.lr, m.rho, m.eps};
+    const int d = m.d;
+    int s, e;
+    if (f.identity) { s = row; e = row + 1; }
+    else { s = uni(f.indptr[row]); e = uni(f.indptr[row + 1]); }
+    lr_bias = 0.0;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) lr_comp[q] = 0.0;
+    for (int k0 = s; k0 < e; k0 += WAVE) {
+        const int cnt = min(WAVE, e - k0);
+        int myfeat = k0 + lane;
+        float myw = 1.0f;
+        if (!f.identity) {
+            myfeat = lane < cnt ? f.indices[k0 + lane] : 0;
+            myw = lane < cnt ? f.data[k0 + lane] : 0.0f;
+        }
+        // biases (PYX:571-599): lane j owns entry j
+        double lrb = 0.0;
+        if (lane < cnt)
+            lrb = cell_update(m.b[side] + myfeat, m.bG[side] + myfeat, m.bM[side] + myfeat, (double)myw,
+                              gbias, h, alpha, atomic);
+        if (alpha != 0.0) lr_bias += wave_sum(lrb);
+        // coordinates (PYX:602-638): lane owns its coordinates, 4 entries in flight
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            float oW[4][NC], oG[4][NC], oM[4][NC];
+            size_t base[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                base[j] = (size_t)read_lane(myfeat, min(j0 + j, cnt - 1)) * d;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int c = lane + WAVE * q;
+                    const int cc = c < d ? c : 0;
+                    oW[j][q] = ldw(m.W[side] + base[j] + cc);
+                    oG[j][q] = ldw(m.G[side] + base[j] + cc);
+                    oM[j][q] = h.adadelta ? ldw(m.M[side] + base[j] + cc) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j0 + j < cnt) {
+                    const double w = (double)read_lanef(myw, j0 + j);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        if (c < d) {
+                            float nW, nG, nM;
+                            double lr;
+                            cell_math(oW[j][q], oG[j][q], oM[j][q], w, gcoef * (double)x[q], h, alpha, nW,
+                                      nG, nM, lr);
+                            lr_comp[q] += lr;
+                            publish(m.W[side] + base[j] + c, nW, oW[j][q], atomic ? 0 : 1);
+                            publish(m.G[side] + base[j] + c, nG, oG[j][q], atomic ? 0 : 1);
+                            if (h.adadelta) publish(m.M[side] + base[j] + c, nM, oM[j][q], atomic ? 0 : 1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Ordered (reference order) or tree sum of the learning-rate partials -> the
 // avg_learning_rate of PYX:640-649 before the division.
 template <int NC, int NROWS>
@@ -449,9 +544,15 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
     for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(N.v[q], P.v[q]);
     // Every address sees its read-modify-writes in the reference's order: a lane keeps
     // pos -> neg -> user for its coordinates, lane 0 does the same for the bias cells.
-    update_row<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
-    update_row<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
-    update_row<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
+    if (a.serial) {
+        update_row<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+        update_row<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
+        update_row<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
+    } else {
+        update_row_batched<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+        update_row_batched<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
+        update_row_batched<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
+    }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
         double avg = sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
@@ -467,8 +568,13 @@ __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int u
 {
     const bool atomic = !a.serial && a.update_mode == 0;
     double lrb[3] = {0.0, 0.0, 0.0}, lrc[3][NC];
-    update_row<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
-    update_row<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
+    if (a.serial) {
+        update_row<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+        update_row<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
+    } else {
+        update_row_batched<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
+        update_row_batched<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
+    }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
         double avg = sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
