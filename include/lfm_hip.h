@@ -70,7 +70,7 @@ typedef struct lfm_opts {
     int32_t first_batch;        /* negatives scored speculatively in the first batch; 0 = auto */
     int32_t max_waves;          /* parallel mode: cap on interactions in flight (between reading
                                    the weights and publishing the update); 0 = auto =
-                                   min(n_users, n_items) / 6, the bound under which
+                                   min(n_users, n_items) / 8, the bound under which
                                    precision@10 stays within 0.002 of the reference
                                    (DESIGN.md "Hogwild at GPU width")                   */
     int32_t *neg_log;           /* host [n] or NULL: chosen negative per shuffled position, -1 = none */
@@ -180,6 +180,13 @@ int lfm_session_set_interactions(lfm_session *s, const lfm_csr *positives,
                                  const float *Y, const float *sample_weight, int64_t n);
 /* Shuffle slots: device copies of shuffle index arrays (slot 0 is the default). */
 int lfm_session_upload_shuffle(lfm_session *s, int32_t slot, const int32_t *shuffle, int64_t n);
+/* Fills `slot` ON DEVICE with a keyed pseudo-random permutation of [0, n) (6-round Feistel
+ * network with cycle walking): replaces the host-side random_state.shuffle(arange(n)) of
+ * LFM:689-690 + the upload when the caller only needs *a* uniform shuffle, not numpy's. */
+int lfm_session_device_shuffle(lfm_session *s, int32_t slot, uint32_t key0, uint32_t key1);
+/* The same permutation computed on the host (no device needed); and a slot's content. */
+int lfm_shuffle_permutation(int32_t *out, int64_t n, uint32_t key0, uint32_t key1);
+int lfm_session_download_shuffle(lfm_session *s, int32_t slot, int32_t *out, int64_t n);
 /* One epoch with the shuffle held in `slot`. */
 int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, double item_alpha,
                       double user_alpha, int32_t k, int32_t n_positives, const uint32_t *seeds,

@@ -56,6 +56,14 @@ class _Session(object):
         N.check(N.lib().lfm_session_upload_shuffle(self.handle, slot, N.i32p(shuffle),
                                                    C.c_int64(len(shuffle))))
 
+    def device_shuffle(self, key0, key1, slot=0):
+        N.check(N.lib().lfm_session_device_shuffle(self.handle, slot, C.c_uint32(key0), C.c_uint32(key1)))
+
+    def download_shuffle(self, n, slot=0):
+        out = np.empty(n, np.int32)
+        N.check(N.lib().lfm_session_download_shuffle(self.handle, slot, N.i32p(out), C.c_int64(n)))
+        return out
+
     def epoch(self, loss, item_alpha, user_alpha, k, n, seeds, opts, slot=0):
         N.check(N.lib().lfm_session_epoch(
             self.handle, N.LOSS_IDS[loss], slot, C.c_double(item_alpha), C.c_double(user_alpha),
@@ -322,13 +330,20 @@ class LightFM(object):
                 session.set_interactions(positives, rows, cols, data, sample_weight)
             self._last_epoch_stats = []
             for _ in self._progress(epochs, verbose=verbose):
-                shuffle_indices = np.arange(n, dtype=np.int32)
-                self.random_state.shuffle(shuffle_indices)
+                if options.device_shuffle and options.mode == "parallel":
+                    # two draws key a permutation built on the device (the caller's RandomState
+                    # still advances every epoch, tests/test_movielens.py:669-682 of the reference)
+                    # (624 draws = one full Mersenne-Twister block, so get_state()[1] changes too)
+                    keys = self.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+                    session.device_shuffle(int(keys[0]), int(keys[1]))
+                else:
+                    shuffle_indices = np.arange(n, dtype=np.int32)
+                    self.random_state.shuffle(shuffle_indices)
+                    session.upload_shuffle(shuffle_indices)
                 seeds = None
                 if loss != "logistic":  # _lightfm_fast.pyx.template:812-814
                     seeds = np.ascontiguousarray(self.random_state.randint(
                         0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
-                session.upload_shuffle(shuffle_indices)
                 opts, _ = make_opts()
                 session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts)
                 self._last_epoch_stats.append({"kernel_ms": float(opts.kernel_ms),

@@ -6,14 +6,17 @@ mode               "parallel" (default): Hogwild over thousands of wavefronts, o
 launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
 first_batch        negatives scored speculatively in the first batch (0 = auto).
 max_waves          cap on interactions in flight, parallel mode (0 = auto = min(n_users,
-                   n_items) / 6).
+                   n_items) / 8).
 update_mode        0 auto (= 3), 1 plain load/store Hogwild, 2 no writes (profiling),
                    3 atomic deltas (global_atomic_add_f32, the default).
 occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
 warp_kernel        0 auto (lane-group tile kernel where it applies), 1 force the generic
                    one-interaction-per-wavefront WARP kernel.
 log_samples        record (negative, sampled) per shuffled position into last_logs.
-device_shuffle     LightFM.fit_partial only: see lightfm.py.
+device_shuffle     LightFM.fit_partial, parallel mode: True (default) builds each epoch's shuffle
+                   on the device from two RandomState draws (lfm_session_device_shuffle); False
+                   draws numpy's random_state.shuffle(arange(n)) on the host like the reference
+                   (LFM:689-690) and uploads it.  Serial mode always uses the host shuffle.
 
 Environment: LIGHTFM_AMD_MODE, LIGHTFM_AMD_LAUNCHES, LIGHTFM_AMD_FIRST_BATCH.
 """
@@ -30,6 +33,7 @@ class _Options(object):
         self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
         self.warp_kernel = int(os.environ.get("LIGHTFM_AMD_WARP_KERNEL", "0"))
         self.debug = int(os.environ.get("LIGHTFM_AMD_DEBUG", "0"))
+        self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None
