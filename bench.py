@@ -220,7 +220,9 @@ def main():
                             D, 1, 1, mean_probe)
     per_epoch = options.launches_per_epoch or max(1, min(64, (train.nnz + (1 << 20) - 1) >> 20))
     launches = per_epoch * args.steps
-    kernel_name = "fit_warp_kernel<1, true, 1>" if options.warp_kernel == 1 else "fit_warp_tile_kernel<16>"
+    ng = int(stats[-1].tile_ng)
+    kernel_name = ("fit_warp_kernel<1, true, 1>" if ng == 0 else
+                   "fit_warp_tile_kernel<%d, %d, false, false>" % (64 // ng, {4: 4, 2: 2, 1: 1}[ng]))
     achieved = alg / kernel_s / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -233,12 +235,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches // args.steps,
+                "interactions_per_wavefront_pass": ng, "interactions_in_flight": int(stats[-1].in_flight),
                 "draws_per_interaction": sum(s.counters[1] for s in stats) / max(1.0, sum(s.counters[0] for s in stats)),
                 "updates_per_interaction": sum(s.counters[2] for s in stats) / max(1.0, sum(s.counters[0] for s in stats))}
 
     if options.warp_kernel == 2:  # profiling build: per-phase shader cycles per wavefront pass
         ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
-        passes = sum(s.counters[0] for s in stats) / 4.0
+        passes = sum(s.counters[0] for s in stats) / float(max(1, int(stats[-1].tile_ng)))
         roofline["phase_cycles_per_pass"] = dict(zip(
             ("head", "gather", "score", "lookup", "acc_loads", "update", "tail", "unused"),
             [round(float(x) / passes, 1) for x in ph]))

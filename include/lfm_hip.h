@@ -99,6 +99,9 @@ typedef struct lfm_opts {
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator
                                    loads, 5 cell arithmetic + atomics, 6 tail */
+    int32_t tile_ng;            /* out: interactions per wavefront pass the tile kernel ran with
+                                   (4, 2, 1), 0 = a generic kernel ran                       */
+    int32_t in_flight;          /* out: interactions in flight the launches were sized for  */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

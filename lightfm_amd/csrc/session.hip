@@ -58,7 +58,10 @@ extern "C" int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hb
 {
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, device));
-    if (name) { strncpy(name, p.name, 255); name[255] = 0; }
+    if (name) {
+        strncpy(name, p.name[0] ? p.name : p.gcnArchName, 255);  // some boxes report an empty name
+        name[255] = 0;
+    }
     if (cus) *cus = p.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
     return LFM_OK;
@@ -727,6 +730,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (s->comm) LFM_TRY(snapshot_side(s, 0));
 
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
+    int in_flight = 1;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
         int T = needs_rng ? n_seeds : 1;
@@ -743,6 +747,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         const int64_t max_waves = in_flight_cap;
         max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / (WAVES_PER_BLOCK * tile_ng)));
         if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
+        in_flight = max_grid * WAVES_PER_BLOCK * tile_ng;
         for (int l = 0; l < L; ++l) {
             a.begin = s->n * l / L;
             a.end = s->n * (l + 1) / L;
@@ -768,6 +773,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     LFM_TRY(s->counters.download(c));
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
+    opts->tile_ng = use_tile ? tile_ng : 0;
+    opts->in_flight = in_flight;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     return LFM_OK;

@@ -1,0 +1,44 @@
+"""RCCL plumbing on one GPU: a communicator of ONE rank exercises librccl loading,
+ncclCommInitRank, the grouped all-reduce of the delta merge and the barrier (the N > 1
+arithmetic itself is covered on CPU by tests/test_multi_gpu_semantics.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_communicator_roundtrip():
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
+    from lightfm_amd.lightfm import _Session
+    from tests import helpers as H
+    assert N.device_count() > 0
+    coo = H.make_interactions(300, 200, 6000, seed=8)
+    m = LightFM(no_components=32, loss="warp", random_state=3)
+    m._initialize(32, 200, 300)
+    struct = m._get_lightfm_data()
+    s = _Session(struct, CSRMatrix(H.identity_features(200)), CSRMatrix(H.identity_features(300)))
+    try:
+        s.set_interactions(CSRMatrix(H.positives_csr(coo)), np.ascontiguousarray(coo.row),
+                           np.ascontiguousarray(coo.col), coo.data, coo.data)
+        uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
+        N.check(N.lib().lfm_comm_unique_id(uid))
+        s.comm_init(uid, 0, 1)
+        before = m.user_embeddings.copy()
+        for e in range(2):
+            s.device_shuffle(5 + e, 7)
+            opts, _ = make_opts()
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([11 + e], np.uint32), opts)
+            assert opts.counters[0] == coo.nnz
+        s.comm_barrier()
+        s.sync_to_host(struct)
+        trained = m.user_embeddings.copy()
+        s.comm_merge_users()     # X := X_start + allreduce(X - X_start) over one rank
+        s.sync_to_host(struct)
+    finally:
+        s.close()
+    assert not np.array_equal(before, trained)
+    np.testing.assert_allclose(m.user_embeddings, trained, rtol=1e-6, atol=1e-7)
+    assert np.isfinite(m.item_embeddings).all()
