@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
     using PieceT = typename Piece<VEC>::T;
     static_assert(LPR * VEC >= WAVE && (LPR * VEC) % WAVE == 0, "a row must cover whole wavefronts of coordinates");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = lane_id(), wib = threadIdx.x >> 6;
-    const int g = lane / LPR, p = lane % LPR, gbase = g * LPR;
+    const int lane = lane_id(), wib = uni((int)(threadIdx.x >> 6));
+    // one interaction per wavefront (LPR == 64): group index and every per-group value are
+    // wave-uniform -- say so, and the compiler keeps them in SGPRs / branches instead of masks
+    const int g = LPR == 64 ? 0 : lane / LPR, p = LPR == 64 ? lane : lane % LPR, gbase = g * LPR;
     const int d = a.m.d, TS = a.tile_stride, RG = a.tile_rows;
     // wave-private tile: NG*RG item rows (row 0 of a group = the positive) + NG user rows
     float *tile = smem + (size_t)wib * (NG * RG + NG) * TS;
@@ -214,9 +216,12 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
         }
         if (i + 2 * stride < a.end) rec2 = a.recs[row2];
         if (i + 3 * stride < a.end) row3 = a.shuffle[i + 3 * stride];
-        const int c_user = cur.x, c_pos = cur.y;
+        // with one interaction per wavefront the ids are wave-uniform: keep them in SGPRs so row
+        // addresses are scalar arithmetic (global_load with an SGPR base)
+        const int c_user = LPR == 64 ? uni(cur.x) : cur.x, c_pos = LPR == 64 ? uni(cur.y) : cur.y;
         const float c_y = __int_as_float(cur.z), c_w = __int_as_float(cur.w);
-        const bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
+        bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
+        if constexpr (LPR == 64) act = __ballot(act) != 0ull;
         int sampled = 0, chosen = -1, chosen_r = 0;
         stamp(0);
 
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
             double pp = 0.0;
             int done = 0;  // draws consumed by every group that is still looking (wave-uniform)
             while (done < max_sampled) {
-                const bool need = act && chosen < 0;
+                bool need = act && chosen < 0;
+                if constexpr (LPR == 64) need = __ballot(need) != 0ull;
                 if (__ballot(need) == 0ull) break;
                 const int nb = min(max_sampled - done, done == 0 ? a.first_batch : RG - 1);
                 // lane p holds the stream after min(p, nb) further steps: draw #(done + p)
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
 #pragma unroll
                                 for (int j = 0; j < 5; ++j) {
                                     kk[c5 + j] = min(k0 + c5 + j, nb);
-                                    negs[j] = __shfl(myitem, gbase + kk[c5 + j], WAVE);
+                                    negs[j] = LPR == 64 ? read_lane(myitem, kk[c5 + j])
+                                                        : __shfl(myitem, gbase + kk[c5 + j], WAVE);
                                 }
 #pragma unroll
                                 for (int j = 0; j < 5; ++j)
