@@ -58,6 +58,14 @@ __device__ __forceinline__ void stp(float *p, const typename Piece<VEC>::T &v)
     *reinterpret_cast<typename Piece<VEC>::T *>(p) = v;
 }
 
+// LDS-DMA: every active lane fetches 4 bytes from its own global address straight into
+// lds_row[lane] (global_load_lds_dword: no VGPR, no ds_write).  `lds_row` must be wave-uniform.
+typedef __attribute__((address_space(3))) float lds_float_t;
+__device__ __forceinline__ void dma_lane_dword(const float *g, float *lds_row)
+{
+    __builtin_amdgcn_global_load_lds(g, (lds_float_t *)lds_row, 4, 0, 0);
+}
+
 // x % n for x < 2^31, 2 <= n < 2^31, with magic = floor(2^32 / n) + 1:
 // floor(x*magic / 2^32) is floor(x/n) or one more (x*magic/2^32 lies in (x/n, x/n + 1/2)).
 __device__ __forceinline__ int fast_mod(uint32_t x, uint32_t n, uint32_t magic)
@@ -184,6 +192,16 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
     const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
 
+    // rand_r's LCG is affine, so k steps collapse into one multiply-add.  For the first batch of
+    // every pass lane p needs the stream after min(p, nb_first) more draws: it keeps
+    // (A^k, C*(A^(k-1) + ... + 1)) mod 2^32 for that k.
+    const int nb_first = min(max_sampled, a.first_batch);
+    uint32_t lcgA = 1u, lcgC = 0u;
+    for (int j = 0; j < min(p, nb_first); ++j) {
+        lcgA *= 1103515245u;
+        lcgC = lcgC * 1103515245u + 12345u;
+    }
+
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
@@ -228,15 +246,28 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
         if (__ballot(act) != 0ull) {
             // ---- gather: user row, positive row, user bias
             const bool gl = act && pc;
-            // lanes without a piece read the table's first 16 bytes instead of branching
-            const PieceT u4 = ldp<VEC>(gl ? Wu + (size_t)c_user * d + VEC * p : Wu);
-            const PieceT p4 = ldp<VEC>(gl ? Wi + (size_t)c_pos * d + VEC * p : Wi);
+            // One interaction per wavefront with one float per lane: a row is exactly what one
+            // global_load_lds_dword deposits (lane p -> row[p]), so rows go memory -> LDS directly.
+            constexpr bool DMA = (LPR == 64 && VEC == 1);
+            PieceT u4, p4;
+            if constexpr (DMA) {
+                if (gl) {
+                    dma_lane_dword(Wu + (size_t)c_user * d + p, urow);
+                    dma_lane_dword(Wi + (size_t)c_pos * d + p, vrows);
+                }
+            } else {
+                // lanes without a piece read the table's first 16 bytes instead of branching
+                u4 = ldp<VEC>(gl ? Wu + (size_t)c_user * d + VEC * p : Wu);
+                p4 = ldp<VEC>(gl ? Wi + (size_t)c_pos * d + VEC * p : Wi);
+            }
             float bu = 0.0f;
             if (act) bu = bu_tab[c_user];
             uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
-            if (gl) {
-                stp<VEC>(urow + VEC * p, u4);
-                stp<VEC>(vrows + VEC * p, p4);
+            if constexpr (!DMA) {
+                if (gl) {
+                    stp<VEC>(urow + VEC * p, u4);
+                    stp<VEC>(vrows + VEC * p, p4);
+                }
             }
             // accumulator rows / bias cells of the groups that will (probably) update
             float gP[NG][NC], gN[NG][NC], gU[NG][NC], mP[NG][NC], mN[NG][NC], mU[NG][NC];
@@ -281,16 +312,27 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                 if (__ballot(need) == 0ull) break;
                 const int nb = min(max_sampled - done, done == 0 ? a.first_batch : RG - 1);
                 // lane p holds the stream after min(p, nb) further steps: draw #(done + p)
-                uint32_t s = state;
-                for (int j = 0; j < nb; ++j)
-                    if (j < p) s = lcg(s);
+                uint32_t s = lcgA * state + lcgC;
+                if (done != 0) {  // later batches (max_sampled above the tile's rows): step by step
+                    s = state;
+                    for (int j = 0; j < nb; ++j)
+                        if (j < p) s = lcg(s);
+                }
                 const int myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);  // PYX:860-861
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
                 // up to 10 candidate rows per round, ALL requested before the first is staged
                 const bool gln = need && pc;
-                if constexpr (LPR == 16) {
+                if constexpr (DMA) {
+                    if (need) {  // wave-uniform
+                        for (int k = 1; k <= nb; ++k) {
+                            const int neg = read_lane(myitem, k);
+                            if (pc) dma_lane_dword(Wi + (size_t)neg * d + p, vrows + (size_t)k * TS);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
+                } else if constexpr (LPR == 16) {
                     // a lane group is a DPP row: row_newbcast:k hands lane k's item to its 16
                     // lanes in one VALU instruction (no LDS round trip per candidate)
                     auto round = [&](auto K0) {
