@@ -87,6 +87,8 @@ __device__ __forceinline__ int row_bcast(int v, int k)
     return v;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
 __device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi)
 {
@@ -102,10 +104,14 @@ __device__ __forceinline__ float row_dot(const float *u, const float *v, int d, 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc = __fadd_rn(acc, __fmul_rn(a[j].x, x[j].x));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].y, x[j].y));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].z, x[j].z));
-            acc = __fadd_rn(acc, __fmul_rn(a[j].w, x[j].w));
+            // the products are independent: two per v_pk_mul_f32 (each still one IEEE f32
+            // multiply); the additions stay one sequential chain
+            const v2f lo = v2f{a[j].x, a[j].y} * v2f{x[j].x, x[j].y};
+            const v2f hi = v2f{a[j].z, a[j].w} * v2f{x[j].z, x[j].w};
+            acc = __fadd_rn(acc, lo.x);
+            acc = __fadd_rn(acc, lo.y);
+            acc = __fadd_rn(acc, hi.x);
+            acc = __fadd_rn(acc, hi.y);
         }
     }
     for (; c < d; c += 4) {
