@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                 stamp(1);  // gathers landed and staged
                 float score = 0.0f;
                 if (rowlane) score = row_dot(urow, vrows + (size_t)p * TS, d, bu, bi);
-                if (done == 0) pp = (double)__shfl(score, gbase, WAVE);
+                // (one interaction per wavefront: lane reads instead of shuffles keep the whole
+                // sampling control flow below in SGPRs and scalar branches)
+                if (done == 0) pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
                 // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
                 const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
                 unsigned long long vm = (__ballot(viol) >> gbase) & GM;
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                     // rarely one of the user's positives): request the accumulator rows of its
                     // update now, so they travel while in_positives confirms it.
                     const int r1 = vm != 0ull ? (__ffsll((long long)vm) - 1) : 0;
-                    spec_cand = __shfl(myitem, gbase + r1, WAVE);
+                    spec_cand = LPR == 64 ? read_lane(myitem, r1) : __shfl(myitem, gbase + r1, WAVE);
                     specm = __ballot(need && vm != 0ull && p == 0);
 #pragma unroll
                     for (int gg = 0; gg < NG; ++gg) {
@@ -426,8 +428,9 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                     if (__ballot(part) == 0ull) break;
                     const int r = part ? (__ffsll((long long)vm) - 1) : 0;
                     if (part) vm &= vm - 1ull;
-                    const int cand = __shfl(myitem, gbase + r, WAVE);
-                    const bool found = group_in_positives<LPR>(indices, cand, c_lo, c_hi, part, gbase, p);
+                    const int cand = LPR == 64 ? read_lane(myitem, r) : __shfl(myitem, gbase + r, WAVE);
+                    const bool found = group_in_positives<LPR>(indices, cand, LPR == 64 ? uni(c_lo) : c_lo,
+                                                               LPR == 64 ? uni(c_hi) : c_hi, part, gbase, p);
                     if (part) {
                         c3++;  // PYX:878-879: the draw still counts
                         if (!found) {
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                         }
                     }
                 }
-                const uint32_t ns = (uint32_t)__shfl((int)s, gbase + used, WAVE);
+                const uint32_t ns = (uint32_t)(LPR == 64 ? read_lane((int)s, used) : __shfl((int)s, gbase + used, WAVE));
                 if (need) {
                     sampled += used;
                     state = ns;
