@@ -1,0 +1,98 @@
+"""lightfm_amd.evaluation on the GPU against slow numpy restatements built on model.predict --
+the approach of the reference's tests/test_evaluation.py (T_EVAL:34-269)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fitted():
+    from lightfm_amd import LightFM, _native
+    assert _native.device_count() > 0
+    nu, ni = 50, 40
+    full = sp.rand(nu, ni, density=0.3, format="csr", random_state=3)
+    full.data[:] = 1.0
+    mask = sp.rand(nu, ni, density=0.5, format="csr", random_state=4).astype(bool)
+    test = full.multiply(mask).tocsr()
+    train = (full - test).tocsr()
+    train.eliminate_zeros()
+    test.eliminate_zeros()
+    model = LightFM(loss="warp", no_components=8, random_state=1).fit(train, epochs=5)
+    return model, train.astype(np.float32), test.astype(np.float32)
+
+
+def _scores(model, nu, ni):
+    uids = np.repeat(np.arange(nu, dtype=np.int32), ni)
+    iids = np.tile(np.arange(ni, dtype=np.int32), nu)
+    return model.predict(uids, iids).reshape(nu, ni)
+
+
+def _slow_ranks(scores, test, train=None):
+    """Pessimistic rank of every test item among all items that are not train positives."""
+    out = {}
+    for u in range(test.shape[0]):
+        s = scores[u].copy()
+        excluded = np.zeros(len(s), bool)
+        if train is not None:
+            excluded[train[u].indices] = True
+        for i in test[u].indices:
+            others = ~excluded
+            others[i] = False
+            out[(u, i)] = int(np.sum(s[others] >= s[i]))
+    return out
+
+
+@pytest.mark.parametrize("with_train", [False, True])
+def test_precision_recall_reciprocal_rank(fitted, with_train):
+    from lightfm_amd.evaluation import precision_at_k, recall_at_k, reciprocal_rank
+    model, train, test = fitted
+    nu, ni = test.shape
+    tr = train if with_train else None
+    ranks = _slow_ranks(_scores(model, nu, ni), test, tr)
+    k = 5
+    prec, rec, mrr = [], [], []
+    for u in range(nu):
+        items = test[u].indices
+        if len(items) == 0:
+            continue
+        r = np.array([ranks[(u, i)] for i in items])
+        prec.append(np.sum(r < k) / k)
+        rec.append(np.sum(r < k) / len(items))
+        mrr.append(1.0 / (r.min() + 1))
+    kw = dict(train_interactions=tr) if with_train else {}
+    np.testing.assert_allclose(precision_at_k(model, test, k=k, **kw), prec, rtol=1e-6)
+    np.testing.assert_allclose(recall_at_k(model, test, k=k, **kw), rec, rtol=1e-6)
+    np.testing.assert_allclose(reciprocal_rank(model, test, **kw), mrr, rtol=1e-6)
+
+
+def test_auc_matches_pairwise_definition(fitted):
+    from lightfm_amd.evaluation import auc_score
+    model, train, test = fitted
+    nu, ni = test.shape
+    scores = _scores(model, nu, ni)
+    want = []
+    for u in range(nu):
+        pos = test[u].indices
+        if len(pos) == 0:
+            continue
+        excluded = np.zeros(ni, bool)
+        excluded[train[u].indices] = True
+        excluded[pos] = True
+        neg = np.where(~excluded)[0]
+        if len(neg) == 0:
+            want.append(0.5)
+            continue
+        wins = sum(np.sum(scores[u, p] > scores[u, neg]) for p in pos)
+        want.append(wins / (len(pos) * len(neg)))
+    got = auc_score(model, test, train_interactions=train)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_intersecting_train_and_test_is_rejected(fitted):
+    from lightfm_amd.evaluation import precision_at_k
+    model, train, test = fitted
+    with pytest.raises(ValueError):
+        precision_at_k(model, train, train_interactions=train)
+    precision_at_k(model, train, train_interactions=train, check_intersections=False)
