@@ -475,6 +475,206 @@ __device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int s
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parallel (Hogwild) update of the 2 or 3 feature rows an interaction touches, as ONE pipeline:
+//   A  the (feature, weight) entries of every row, one per lane: one round trip for all rows;
+//   B  every bias cell by its own lane: all loads, then all arithmetic, then all publications;
+//   C  the coordinate cells, entries of all rows flattened and taken CH at a time; the loads of
+//      chunk k+1 are issued BEFORE chunk k is published, so no load ever waits behind an
+//      atomic's acknowledgement (vmcnt is an in-order counter).
+// Same cells and same float64 cell arithmetic as update_row (PYX:337-451); what is relaxed is the
+// order between cells, which Hogwild mode does not keep anyway.  Rows longer than a wavefront
+// (and NC > 2) take the per-row path above.  Returns the sum of the cells' learning rates.
+template <int NC>
+struct RowJob {
+    DCsr f;  // by value: a pointer into the kernel argument block would force it into scratch
+    int row, side;
+    float x[NC];          // per-lane gradient factors of the row
+    double gcoef, gbias;  // g = gcoef * x[q] for coordinates, gbias for the bias cells
+    double alpha;
+};
+
+// Three named values picked by a wave-uniform row index.  (Deliberately not an array: LLVM turns
+// a select chain over array elements into a dynamically indexed load, i.e. scratch memory.)
+template <typename T>
+struct Tri {
+    T a, b, c;
+    __device__ __forceinline__ T pick(int r) const { return r == 0 ? a : (r == 1 ? b : c); }
+    __device__ __forceinline__ T &at(int r) { return r == 0 ? a : (r == 1 ? b : c); }
+};
+
+template <int NC, int NR>
+__device__ __forceinline__ double rows_update_parallel(const DModel &m, const RowJob<NC> (&job)[NR],
+                                                       bool atomic, int lane)
+{
+    static_assert(NR == 2 || NR == 3, "two (logistic) or three (WARP / BPR / k-OS) rows");
+    constexpr int CH = 4;
+    constexpr int L = NR - 1;  // index of the last real row; unused slots of a Tri mirror it
+    const Hyper h{m.adadelta, m.lr, m.rho, m.eps};
+    const int d = m.d;
+    const Tri<int> side{job[0].side, job[1].side, job[L].side};
+    const Tri<double> gcoef{job[0].gcoef, job[1].gcoef, job[L].gcoef};
+    const Tri<double> gbias{job[0].gbias, job[1].gbias, job[L].gbias};
+    const Tri<double> alpha{job[0].alpha, job[1].alpha, job[L].alpha};
+    Tri<float> x[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) x[q] = Tri<float>{job[0].x[q], job[1].x[q], job[L].x[q]};
+    Tri<int> n{0, 0, 0}, feat{0, 0, 0};
+    Tri<float> w{0.0f, 0.0f, 0.0f};
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {  // A
+        const DCsr &f = job[r].f;
+        if (f.identity) {
+            n.at(r) = 1;
+            feat.at(r) = job[r].row;
+            w.at(r) = 1.0f;
+        } else {
+            const int s = uni(f.indptr[job[r].row]), e = uni(f.indptr[job[r].row + 1]);
+            n.at(r) = e - s;
+            big = big || (e - s) > WAVE;
+            feat.at(r) = lane < e - s ? f.indices[s + min(lane, e - s - 1)] : 0;
+            w.at(r) = lane < e - s ? f.data[s + min(lane, e - s - 1)] : 0.0f;
+        }
+    }
+    double lr_acc = 0.0;
+    if (big) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double lb, lc[NC];
+            float xv[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) xv[q] = job[r].x[q];
+            update_row_batched<NC>(job[r].f, job[r].row, job[r].side, m, xv, job[r].gcoef, job[r].gbias,
+                                   job[r].alpha, atomic, lane, lb, lc);
+            lr_acc += lane == 0 ? lb : 0.0;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) lr_acc += lc[q];
+        }
+        return wave_sum(lr_acc);
+    }
+    auto put = [&](float *p, float nv, float ov) {
+        if (atomic) {
+            const float dlt = __fsub_rn(nv, ov);
+            if (dlt != 0.0f) atomicAdd(p, dlt);
+        } else {
+            *p = nv;
+        }
+    };
+    {  // B
+        float oW[NR], oG[NR], oM[NR], nW[NR], nG[NR], nM[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool on = lane < n.pick(r);
+            const int s = side.pick(r), ft = feat.pick(r);
+            oW[r] = on ? ldw(m.b[s] + ft) : 0.0f;
+            oG[r] = on ? ldw(m.bG[s] + ft) : 1.0f;
+            oM[r] = (on && h.adadelta) ? ldw(m.bM[s] + ft) : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double lr;
+            cell_math(oW[r], oG[r], oM[r], (double)w.pick(r), gbias.pick(r), h, alpha.pick(r), nW[r], nG[r],
+                      nM[r], lr);
+            if (lane < n.pick(r)) lr_acc += lr;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (lane < n.pick(r)) {
+                const int s = side.pick(r), ft = feat.pick(r);
+                put(m.b[s] + ft, nW[r], oW[r]);
+                put(m.bG[s] + ft, nG[r], oG[r]);
+                if (h.adadelta) put(m.bM[s] + ft, nM[r], oM[r]);
+            }
+        }
+    }
+    // C
+    const int total = n.a + n.b + (NR == 3 ? n.c : 0);
+    auto locate = [&](int e, int &r, int &j) {  // wave-uniform
+        r = 0;
+        j = e;
+        if (j >= n.a) {
+            j -= n.a;
+            r = 1;
+            if (NR == 3 && j >= n.b) {
+                j -= n.b;
+                r = 2;
+            }
+        }
+    };
+    float oW[CH][NC], oG[CH][NC], oM[CH][NC], cw[CH];
+    int cfeat[CH], crow[CH];
+    auto load_chunk = [&](int e0) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            int r, j;
+            locate(min(e0 + k, total - 1), r, j);
+            const int sd = side.pick(r);
+            crow[k] = r;
+            cw[k] = read_lanef(w.pick(r), j);
+            cfeat[k] = read_lane(feat.pick(r), j);
+            const size_t base = (size_t)cfeat[k] * d;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int cc = (lane + WAVE * q) < d ? (lane + WAVE * q) : 0;
+                oW[k][q] = ldw(m.W[sd] + base + cc);
+                oG[k][q] = ldw(m.G[sd] + base + cc);
+                oM[k][q] = h.adadelta ? ldw(m.M[sd] + base + cc) : 0.0f;
+            }
+        }
+    };
+    load_chunk(0);
+    for (int e0 = 0; e0 < total; e0 += CH) {
+        // arithmetic of the chunk; v* = what is published (deltas when atomic)
+        float vW[CH][NC], vG[CH][NC], vM[CH][NC];
+        int vfeat[CH], vrow[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            vfeat[k] = cfeat[k];
+            vrow[k] = crow[k];
+            const int r = crow[k];
+            const double gc = gcoef.pick(r), al = alpha.pick(r);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                float nW, nG, nM;
+                double lr;
+                cell_math(oW[k][q], oG[k][q], oM[k][q], (double)cw[k], gc * (double)x[q].pick(r), h, al, nW, nG,
+                          nM, lr);
+                if (e0 + k < total && lane + WAVE * q < d) lr_acc += lr;
+                vW[k][q] = atomic ? __fsub_rn(nW, oW[k][q]) : nW;
+                vG[k][q] = atomic ? __fsub_rn(nG, oG[k][q]) : nG;
+                vM[k][q] = atomic ? __fsub_rn(nM, oM[k][q]) : nM;
+            }
+        }
+        // the next chunk's loads go out BEFORE this chunk is published
+        if (e0 + CH < total) load_chunk(e0 + CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (e0 + k < total) {
+                const int sd = side.pick(vrow[k]);
+                const size_t base = (size_t)vfeat[k] * d;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int cidx = lane + WAVE * q;
+                    if (cidx < d) {
+                        if (atomic) {
+                            if (vW[k][q] != 0.0f) atomicAdd(m.W[sd] + base + cidx, vW[k][q]);
+                            if (vG[k][q] != 0.0f) atomicAdd(m.G[sd] + base + cidx, vG[k][q]);
+                            if (h.adadelta && vM[k][q] != 0.0f) atomicAdd(m.M[sd] + base + cidx, vM[k][q]);
+                        } else {
+                            m.W[sd][base + cidx] = vW[k][q];
+                            m.G[sd][base + cidx] = vG[k][q];
+                            if (h.adadelta) m.M[sd][base + cidx] = vM[k][q];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // only the lazy-regularisation scale step (alpha != 0) consumes the learning-rate sum
+    return (alpha.a != 0.0 || alpha.b != 0.0 || alpha.c != 0.0) ? wave_sum(lr_acc) : 0.0;
+}
+
 // Ordered (reference order) or tree sum of the learning-rate partials -> the
 // avg_learning_rate of PYX:640-649 before the division.
 template <int NC, int NROWS>
@@ -539,6 +739,7 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
 {
     const bool atomic = !a.serial && a.update_mode == 0;
     double lrb[3], lrc[3][NC];
+    bool pre_summed = false;
     float diff[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(N.v[q], P.v[q]);
@@ -548,13 +749,26 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
         update_row<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
         update_row<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
         update_row<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
+    } else if constexpr (NC <= 2) {
+        RowJob<NC> jobs[3] = {{a.itf, pos, 0, {}, -loss, -loss, a.item_alpha},
+                              {a.itf, neg, 0, {}, loss, loss, a.item_alpha},
+                              {a.usf, user, 1, {}, loss, loss, a.user_alpha}};
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            jobs[0].x[q] = U.v[q];
+            jobs[1].x[q] = U.v[q];
+            jobs[2].x[q] = diff[q];
+        }
+        const double lr_total = rows_update_parallel<NC, 3>(a.m, jobs, atomic, lane);
+        lrb[0] = lr_total;  // already the wave-wide sum: see the tail below
+        pre_summed = true;
     } else {
         update_row_batched<NC>(a.itf, pos, 0, a.m, U.v, -loss, -loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
         update_row_batched<NC>(a.itf, neg, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[1], lrc[1]);
         update_row_batched<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
     }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
-        double avg = sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
+        double avg = pre_summed ? lrb[0] : sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
         avg /= (double)cells;
         apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
@@ -568,15 +782,27 @@ __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int u
 {
     const bool atomic = !a.serial && a.update_mode == 0;
     double lrb[3] = {0.0, 0.0, 0.0}, lrc[3][NC];
+    bool pre_summed = false;
     if (a.serial) {
         update_row<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
         update_row<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
+    } else if constexpr (NC <= 2) {
+        RowJob<NC> jobs[2] = {{a.itf, item, 0, {}, loss, loss, a.item_alpha},
+                              {a.usf, user, 1, {}, loss, loss, a.user_alpha}};
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            jobs[0].x[q] = U.v[q];
+            jobs[1].x[q] = I.v[q];
+        }
+        const double lr_total = rows_update_parallel<NC, 2>(a.m, jobs, atomic, lane);
+        lrb[0] = lr_total;  // already the wave-wide sum: see the tail below
+        pre_summed = true;
     } else {
         update_row_batched<NC>(a.itf, item, 0, a.m, U.v, loss, loss, a.item_alpha, atomic, lane, lrb[0], lrc[0]);
         update_row_batched<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
     }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
-        double avg = sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
+        double avg = pre_summed ? lrb[0] : sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
         avg /= (double)cells;
         apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
