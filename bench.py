@@ -183,6 +183,7 @@ def main():
 
     def step(e):
         opts, _ = make_opts()
+        opts.history = e * train.nnz  # epoch e of one training run: epoch 0 ramps the concurrency up
         session.epoch("warp", 0.0, 0.0, 5, 10, seeds[e], opts, slot=e)
         if not session.check_finite():
             raise SystemExit("model diverged")
@@ -218,8 +219,7 @@ def main():
     alg = algorithmic_bytes(sum(s.counters[0] for s in stats), sum(s.counters[1] for s in stats),
                             sum(s.counters[2] for s in stats), sum(s.counters[3] for s in stats),
                             D, 1, 1, mean_probe)
-    per_epoch = options.launches_per_epoch or max(1, min(64, (train.nnz + (1 << 20) - 1) >> 20))
-    launches = per_epoch * args.steps
+    launches = sum(int(s.launches) for s in stats)
     ng = int(stats[-1].tile_ng)
     kernel_name = ("fit_warp_kernel<1, true, 1>" if ng == 0 else
                    "fit_warp_tile_kernel<%d, %d, false, false>" % (64 // ng, {4: 4, 2: 2, 1: 1}[ng]))
@@ -234,7 +234,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
-                "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches // args.steps,
+                "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches / args.steps,
                 "interactions_per_wavefront_pass": ng, "interactions_in_flight": int(stats[-1].in_flight),
                 "draws_per_interaction": sum(s.counters[1] for s in stats) / max(1.0, sum(s.counters[0] for s in stats)),
                 "updates_per_interaction": sum(s.counters[2] for s in stats) / max(1.0, sum(s.counters[0] for s in stats))}

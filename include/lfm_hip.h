@@ -68,11 +68,10 @@ typedef struct lfm_opts {
     int32_t launches_per_epoch; /* parallel mode: kernel launches per epoch (a launch
                                    boundary is a device-wide release/acquire); 0 = auto */
     int32_t first_batch;        /* negatives scored speculatively in the first batch; 0 = auto */
-    int32_t max_waves;          /* parallel mode: cap on interactions in flight (between reading
-                                   the weights and publishing the update); 0 = auto =
-                                   min(n_users, n_items) / 8, the bound under which
-                                   precision@10 stays within 0.002 of the reference
-                                   (DESIGN.md "Hogwild at GPU width")                   */
+    int32_t max_waves;          /* parallel mode: FIXED cap on interactions in flight (between
+                                   reading the weights and publishing the update); 0 = auto =
+                                   ramp with the training history up to the whole chip
+                                   (`history`, `ramp_k` below; DESIGN.md "Hogwild at GPU width") */
     int32_t *neg_log;           /* host [n] or NULL: chosen negative per shuffled position, -1 = none */
     int32_t *sampled_log;       /* host [n] or NULL: draws consumed per shuffled position */
     int64_t counters[4];        /* out: positives visited, draws, updates, in_positives probes */
@@ -101,7 +100,13 @@ typedef struct lfm_opts {
                                    loads, 5 cell arithmetic + atomics, 6 tail */
     int32_t tile_ng;            /* out: interactions per wavefront pass the tile kernel ran with
                                    (4, 2, 1), 0 = a generic kernel ran                       */
-    int32_t in_flight;          /* out: interactions in flight the launches were sized for  */
+    int32_t in_flight;          /* out: interactions in flight of the epoch's last launch   */
+    int64_t history;            /* in: interactions this model has already been trained on (all
+                                   earlier epochs); concurrency is ramped with it, see max_waves.
+                                   0 = a fresh (or unknown) model: the epoch starts the ramp   */
+    int32_t ramp_k;             /* in: at most (history + done) / ramp_k interactions in flight;
+                                   0 = auto (32), < 0 = no ramp                               */
+    int32_t launches;           /* out: kernel launches of the epoch                        */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

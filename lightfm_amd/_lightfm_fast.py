@@ -87,6 +87,8 @@ def make_opts(n=0, want_log=False):
     o.occupancy = int(options.occupancy)
     o.warp_kernel = int(options.warp_kernel)
     o.debug = int(options.debug)
+    o.ramp_k = int(options.ramp_k)
+    o.history = int(options.history)
     logs = None
     if want_log:
         logs = (np.full(n, -1, np.int32), np.zeros(n, np.int32))

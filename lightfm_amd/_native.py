@@ -46,7 +46,8 @@ class LfmOpts(C.Structure):
                 ("neg_log", I32P), ("sampled_log", I32P),
                 ("counters", C.c_int64 * 4), ("kernel_ms", C.c_float),
                 ("update_mode", C.c_int32), ("occupancy", C.c_int32), ("warp_kernel", C.c_int32), ("debug", C.c_int32),
-                ("phase_cycles", C.c_int64 * 8), ("tile_ng", C.c_int32), ("in_flight", C.c_int32)]
+                ("phase_cycles", C.c_int64 * 8), ("tile_ng", C.c_int32), ("in_flight", C.c_int32),
+                ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32)]
 
 
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)

@@ -678,40 +678,56 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                    (size_t)WAVES_PER_BLOCK * 2 * a.pair_cap);
     if (smem > 160 * 1024) return fail(LFM_EUNSUPPORTED, "k-OS n too large for the LDS pair buffer");
 
-    // Interactions allowed in flight (between reading the weights and publishing the update):
-    // every one of them is computed against weights the others are changing, and all their
-    // updates land.  Auto: min(n_users, n_items) / 8 -- measured: precision@10 within 0.002 of
-    // the reference at the ML-100k and ML-20M shapes (DESIGN.md "Hogwild at GPU width").
-    const int64_t rows_min = std::min<int64_t>(s->usf.rows, s->itf.rows);
-    const int64_t in_flight_cap = opts->max_waves > 0 ? opts->max_waves : std::max<int64_t>(16, rows_min / 8);
+    // Interactions allowed in flight (between reading the weights and publishing the update).
+    // Every one of them is computed against weights the others are changing, and all their
+    // updates land.  That is harmless once the model has left its initial state, and ruinous
+    // before: with all scores ~0 every interaction violates the margin with the maximum loss, and
+    // hundreds of concurrent maximum steps on a popular row (or a shared feature row) overshoot
+    // it for good -- its accumulators then freeze the damage.  So concurrency is RAMPED with the
+    // training history: at most (interactions already trained on) / ramp_k in flight, up to the
+    // whole chip (DESIGN.md "Hogwild at GPU width": measured precision@10 parity).  An explicit
+    // lfm_opts.max_waves is a fixed cap instead (experiments, tests).
+    const int64_t ramp_k = opts->ramp_k > 0 ? opts->ramp_k : 32;
+    const int64_t history0 = opts->history > 0 ? opts->history : 0;
+    const bool fixed_cap = opts->max_waves > 0;
+    // Shared feature rows (hybrid models) stay sensitive after the ramp: every interaction in
+    // flight touches avg-nnz of a side's feature rows.  Steady-state bound for such a side:
+    // (feature rows) / (avg nnz per row) interactions in flight (measured at the ML-100k shape
+    // with 40 tags x 4 per item; identity sides are not bounded).
+    int64_t shared_cap = INT64_MAX / 4;
+    for (const DevCsr *f : {&s->itf, &s->usf}) {
+        if (f->identity || f->rows <= 0 || f->nnz <= 0) continue;
+        const double avg = (double)f->nnz / (double)f->rows;
+        shared_cap = std::min<int64_t>(shared_cap, std::max<int64_t>(64, (int64_t)((double)f->cols / std::max(1.0, avg))));
+    }
+    auto allowed_in_flight = [&](int64_t done_this_epoch) -> int64_t {
+        if (fixed_cap) return opts->max_waves;
+        if (opts->ramp_k < 0) return INT64_MAX / 4;  // ramp disabled
+        return std::min<int64_t>(shared_cap, std::max<int64_t>(8, (history0 + done_this_epoch) / ramp_k));
+    };
 
     // Parallel WARP over identity features without regularisation (BASELINE configs C2/C4):
     // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
-    // NG = 4 is the most instruction-efficient mapping; when the in-flight cap leaves the chip
-    // short of wavefronts, fewer interactions per wavefront buy more of them (latency hiding).
+    // NG = 4 is the most instruction-efficient mapping; when a launch may keep only few
+    // interactions in flight, fewer per wavefront buy more wavefronts (latency hiding).
+    struct TilePlan { bool ok = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
+    TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
-    int tile_ng = 1, tile_vec = 0;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
         s->usf.identity && item_alpha == 0.0 && user_alpha == 0.0 && s->itf.rows >= 2) {
         const int forced = opts->debug & 7;  // experiment override: 1, 2 or 4
         for (int ng : {4, 2, 1}) {
-            int trows = 0, tstride = 0, tvec = 0;
-            size_t tsmem = warp_tile_geometry(s->d, s->max_sampled, ng, &trows, &tstride, &tvec);
-            if (tsmem == 0) continue;
-            const bool enough_waves = in_flight_cap / ng >= (int64_t)s->cus * 8;
-            if (forced ? (ng != forced) : (!enough_waves && ng != 1)) continue;
+            if (forced && ng != forced) continue;
+            TilePlan &t = tile[ng];
+            t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec);
+            if (t.smem == 0) continue;
+            t.ok = true;
+            t.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
+            t.first_batch = std::max(1, std::min(t.first_batch, t.rows - 1));
             use_tile = true;
-            smem = tsmem;
-            tile_ng = ng;
-            tile_vec = tvec;
-            a.tile_rows = trows;
-            a.tile_stride = tstride;
-            a.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
-            a.first_batch = std::max(1, std::min(a.first_batch, trows - 1));
-            a.n_items_magic = (uint32_t)((1ull << 32) / (uint64_t)s->itf.rows) + 1u;
-            break;
         }
         if (use_tile) {
+            a.n_items_magic = (uint32_t)((1ull << 32) / (uint64_t)s->itf.rows) + 1u;
             if (!s->recs_valid) {
                 LFM_TRY(s->recs.alloc((size_t)s->n));
                 HIP_TRY(launch_pack_records(a.user_ids, a.item_ids, a.Y, a.weight, s->n, s->recs.p, s->stream));
@@ -730,7 +746,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (s->comm) LFM_TRY(snapshot_side(s, 0));
 
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
-    int in_flight = 1;
+    int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
         int T = needs_rng ? n_seeds : 1;
@@ -740,27 +756,62 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (a.end > a.begin) HIP_TRY(launch_fit(loss, a, 1, WAVE, smem, s->stream));
         }
     } else {
+        // Launch plan: the epoch is cut into launches (a kernel boundary is a device-wide
+        // release/acquire) of at most `slice` positions; while the ramp is still below the chip's
+        // residency a launch covers 64 passes of its wavefronts, so the ramp costs milliseconds.
         int L = opts->launches_per_epoch;
         if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
-        int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(smem, 1)));
-        int max_grid = s->cus * blocks_per_cu;
-        const int64_t max_waves = in_flight_cap;
-        max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, max_waves / (WAVES_PER_BLOCK * tile_ng)));
-        if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
-        in_flight = max_grid * WAVES_PER_BLOCK * tile_ng;
-        for (int l = 0; l < L; ++l) {
-            a.begin = s->n * l / L;
-            a.end = s->n * (l + 1) / L;
-            if (a.end <= a.begin) continue;
-            int64_t waves = (a.end - a.begin + tile_ng - 1) / tile_ng;
-            int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            if (use_tile) HIP_TRY(launch_fit_warp_tile(a, tile_ng, tile_vec, grid, smem, s->stream, s->cus, opts->warp_kernel == 2));
-            else HIP_TRY(launch_fit(loss, a, grid, 256, smem, s->stream, occupancy, s->cus));
+        const int64_t slice = std::max<int64_t>(1, (s->n + L - 1) / L);
+        const size_t generic_smem = smem;
+        FitArgs base = a;
+        int64_t begin = 0;
+        int ng_used = 0;
+        while (begin < s->n) {
+            const int64_t allowed = allowed_in_flight(begin);
+            // pick the kernel variant for this launch
+            int ng = 0;
+            if (use_tile) {
+                for (int c : {4, 2, 1})
+                    if (!ng && tile[c].ok && (allowed / c >= (int64_t)s->cus * 8 || c == 1)) ng = c;
+                if (!ng)
+                    for (int c : {1, 2, 4})
+                        if (!ng && tile[c].ok) ng = c;
+            }
+            a = base;
+            size_t lsmem = generic_smem;
+            int per_wave = 1;
+            if (ng) {
+                const TilePlan &t = tile[ng];
+                lsmem = t.smem;
+                per_wave = ng;
+                a.tile_rows = t.rows;
+                a.tile_stride = t.stride;
+                a.first_batch = t.first_batch;
+            }
+            const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lsmem, 1)));
+            int max_grid = s->cus * blocks_per_cu;
+            const bool below_residency = allowed / (WAVES_PER_BLOCK * per_wave) < max_grid;
+            max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, allowed / (WAVES_PER_BLOCK * per_wave)));
+            if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
+            const int64_t flight = (int64_t)max_grid * WAVES_PER_BLOCK * per_wave;
+            int64_t len = std::min<int64_t>(slice, s->n - begin);
+            if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
+            a.begin = begin;
+            a.end = begin + len;
+            const int64_t waves = (len + per_wave - 1) / per_wave;
+            const int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            if (ng) HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2));
+            else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
                 HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904
             }
+            begin += len;
+            in_flight = (int)std::min<int64_t>(flight, INT32_MAX);  // of the last (largest) launch
+            ng_used = ng;
+            ++n_launches;
         }
+        tile_ng_used = ng_used;
     }
     if (reg) HIP_TRY(launch_regularize(a.m, 1, s->stream));  // PYX:910-912 (no-op when scales are 1)
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -773,8 +824,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     LFM_TRY(s->counters.download(c));
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
-    opts->tile_ng = use_tile ? tile_ng : 0;
+    opts->tile_ng = tile_ng_used;
     opts->in_flight = in_flight;
+    opts->launches = n_launches;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     return LFM_OK;

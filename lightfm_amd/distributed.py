@@ -101,13 +101,15 @@ class DistributedFit(object):
         m = self.model
         n = self.shard.nnz
         stats = []
-        for _ in range(epochs):
+        for epoch in range(epochs):
             shuffle = np.arange(n, dtype=np.int32)
             m.random_state.shuffle(shuffle)
             seeds = np.ascontiguousarray(m.random_state.randint(
                 0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
             self.session.upload_shuffle(shuffle)
             opts, _ = make_opts()
+            opts.history = int(getattr(m, "_trained_interactions", 0))
+            m._trained_interactions = opts.history + n
             self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts)
             stats.append(opts)
             if not self.session.check_finite():

@@ -145,6 +145,7 @@ class LightFM(object):
     # ------------------------------------------------------------------ state
 
     def _reset_state(self):
+        self._trained_interactions = 0  # drives the concurrency ramp (lfm_opts.history)
         for name in _WEIGHTS:
             setattr(self, name, None)
 
@@ -345,7 +346,9 @@ class LightFM(object):
                     seeds = np.ascontiguousarray(self.random_state.randint(
                         0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
                 opts, _ = make_opts()
+                opts.history = int(getattr(self, "_trained_interactions", 0))
                 session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts)
+                self._trained_interactions = getattr(self, "_trained_interactions", 0) + n
                 self._last_epoch_stats.append({"kernel_ms": float(opts.kernel_ms),
                                                "counters": list(opts.counters)})
                 if not session.check_finite():  # LFM:664

@@ -5,8 +5,12 @@ mode               "parallel" (default): Hogwild over thousands of wavefronts, o
                    reference's order with its rand_r streams -- bit-exact, for parity tests.
 launches_per_epoch kernel launches per epoch in parallel mode (0 = auto).
 first_batch        negatives scored speculatively in the first batch (0 = auto).
-max_waves          cap on interactions in flight, parallel mode (0 = auto = min(n_users,
-                   n_items) / 8).
+max_waves          FIXED cap on interactions in flight, parallel mode; 0 = auto = ramp with the
+                   training history: at most (interactions trained on so far) / ramp_k in flight,
+                   up to the whole chip.
+ramp_k             see max_waves; 0 = auto (32), < 0 = no ramp.
+history            interactions the model was already trained on, for the low-level epoch
+                   functions (LightFM.fit_partial keeps count itself).
 update_mode        0 auto (= 3), 1 plain load/store Hogwild, 2 no writes (profiling),
                    3 atomic deltas (global_atomic_add_f32, the default).
 occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
@@ -33,6 +37,8 @@ class _Options(object):
         self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
         self.warp_kernel = int(os.environ.get("LIGHTFM_AMD_WARP_KERNEL", "0"))
         self.debug = int(os.environ.get("LIGHTFM_AMD_DEBUG", "0"))
+        self.ramp_k = int(os.environ.get("LIGHTFM_AMD_RAMP_K", "0"))
+        self.history = 0
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.log_samples = False
         self.last_counters = None

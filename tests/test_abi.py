@@ -33,7 +33,7 @@ def test_struct_layouts_match_header(native):
     import ctypes as C
     assert C.sizeof(native.LfmCSR) == 40
     assert C.sizeof(native.LfmModel) == 12 * 8 + 4 * 4 + 3 * 4 + 4 + 2 * 8
-    assert C.sizeof(native.LfmOpts) == 16 + 16 + 32 + 4 + 4 + 4 + 8 + 4 + 64 + 8
+    assert C.sizeof(native.LfmOpts) == 16 + 16 + 32 + 4 + 4 + 4 + 8 + 4 + 64 + 8 + 16
 
 
 def test_no_cpu_fallback_without_gpu(native):

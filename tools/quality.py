@@ -26,12 +26,16 @@ else:
     nu, ni, nnz = [int(x) for x in name.split("x")]
     data = synthetic.make_interactions(nu, ni, nnz)
 train, test = synthetic.train_test_split(data, 0.1, seed=1)
+item_features = None
+if os.environ.get("QUALITY_TAGS"):  # hybrid model: [identity | tags] item features
+    n_tags, per_item = [int(x) for x in os.environ["QUALITY_TAGS"].split(",")]
+    item_features = synthetic.tag_item_features(data.shape[1], n_tags=n_tags, per_item=per_item)
 print("data", name, data.shape, "train", train.nnz, "test", test.nnz, flush=True)
 
 
 def evaluate(m):
-    ptr = precision_at_k(m, train, k=10).mean()
-    pte = precision_at_k(m, test, train_interactions=train, k=10).mean()
+    ptr = precision_at_k(m, train, k=10, item_features=item_features).mean()
+    pte = precision_at_k(m, test, train_interactions=train, k=10, item_features=item_features).mean()
     return ptr, pte
 
 
@@ -40,7 +44,7 @@ for threads in (1, min(16, os.cpu_count())):
     for seed in (1, 2, 3):
         m = RefLightFM(no_components=d, loss=loss, random_state=seed)
         t = time.time()
-        m.fit(train, epochs=epochs, num_threads=threads)
+        m.fit(train, item_features=item_features, epochs=epochs, num_threads=threads)
         dt = time.time() - t
         res.append(evaluate(m) + (dt,))
     r = np.array(res)
@@ -54,7 +58,7 @@ for cap, um in [(c, u) for c in caps for u in modes]:
     for seed in (1, 2, 3):
         options.set(mode="parallel", max_waves=cap, update_mode=um)
         m = LightFM(no_components=d, loss=loss, random_state=seed)
-        m.fit(train, epochs=epochs, num_threads=1)
+        m.fit(train, item_features=item_features, epochs=epochs, num_threads=1)
         ms = sum(s["kernel_ms"] for s in m._last_epoch_stats)
         draws = sum(s["counters"][1] for s in m._last_epoch_stats)
         upd = sum(s["counters"][2] for s in m._last_epoch_stats)
