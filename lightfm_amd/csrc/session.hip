@@ -69,17 +69,31 @@ extern "C" int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hb
 
 // ------------------------------------------------------------ device memory ---
 
-// Allocation flavour of the weight tables (experiment knob, see DESIGN.md "coherence"):
-// 0 = hipMalloc (coarse-grained: an XCD's L2 may serve lines another XCD has rewritten until
-// the launch ends), 1 = hipDeviceMallocFinegrained, 3 = hipDeviceMallocUncached.
+// Allocation flavour of the weight tables: 0 = hipMalloc (coarse-grained: an XCD's L2 may serve
+// lines another XCD has rewritten until the launch ends), 1 = hipDeviceMallocFinegrained,
+// 3 = hipDeviceMallocUncached (default).  The embedding rows are gathered at random with a 37 % L2
+// hit rate and rewritten by atomics that drop them from the L2 again: going straight to the
+// fabric (Infinity Cache) is 14 % faster than through the L2 (0.82 vs 0.72 G interactions/s on
+// the bench workload), and reads are never stale.  Measured precision@10 is the same.
 static int table_alloc_flags()
 {
     static int f = -1;
     if (f < 0) {
         const char *e = getenv("LIGHTFM_AMD_TABLE_ALLOC");
-        f = e ? atoi(e) : 0;
+        f = e ? atoi(e) : 3;
     }
     return f;
+}
+
+// which of the six table kinds (W, G, M, b, bG, bM = bits 0..5) get that flavour (experiment knob)
+static int table_alloc_mask()
+{
+    static int m = -1;
+    if (m < 0) {
+        const char *e = getenv("LIGHTFM_AMD_TABLE_ALLOC_MASK");
+        m = e ? atoi(e) : 63;
+    }
+    return m;
 }
 
 template <typename T>
@@ -340,9 +354,16 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     s->lr = model->lr;
     s->rho = model->rho;
     s->eps = model->eps;
+    // Tables that fit the L2s stay cached (small models, the parity tests' serial mode); beyond
+    // the 32 MiB of aggregate L2 they are allocated uncached (see table_alloc_flags).
+    size_t table_bytes = 0;
+    for (int side = 0; side < 2; ++side)
+        for (int k = 0; k < 6; ++k)
+            if (kind_used(s, k)) table_bytes += tab_count(s, side, k) * sizeof(float);
+    const bool big_tables = table_bytes > (32u << 20) || getenv("LIGHTFM_AMD_TABLE_ALLOC") != nullptr;
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
-            s->tab[side][k].flags = table_alloc_flags();
+            s->tab[side][k].flags = (big_tables && ((table_alloc_mask() >> k) & 1)) ? table_alloc_flags() : 0;
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
             if (kind_used(s, k)) guard(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
