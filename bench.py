@@ -6,7 +6,9 @@
 Workload (BASELINE.json configs[1]): MovieLens-20M SHAPE (138,493 users x 26,744
 items x 20,000,263 interactions; synthetic, no dataset is reachable offline),
 loss='warp', no_components=64, identity features, adagrad, lr 0.05,
-max_sampled=10, parallel (Hogwild) mode of the HIP backend.
+max_sampled=10, parallel (Hogwild) mode of the HIP backend with its defaults (atomic
+publication, concurrency ramped with the training history: step e is epoch e of ONE training
+run, so the ramp happens in the first warm-up epoch and the timed epochs run with the chip full).
 
 A "step" is ONE EPOCH = one pass of the hot path over all interactions of the
 rank's shard (every positive visited once, negatives sampled, Adagrad updates
@@ -101,7 +103,7 @@ def main():
     ap.add_argument("--debug-zipf", type=float, default=None, help="experiment: item popularity exponent")
     ap.add_argument("--debug-no-shuffle", action="store_true", help="experiment: identity shuffle")
     ap.add_argument("--debug-empty-positives", action="store_true", help="experiment: no in_positives probes")
-    for knob in ("update_mode", "occupancy", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "debug"):
+    for knob in ("update_mode", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "debug"):
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
 
@@ -128,7 +130,7 @@ def main():
     import scipy.sparse as sp
 
     from lightfm_amd.options import options
-    tuned = {k: getattr(args, k) for k in ("update_mode", "occupancy", "first_batch",
+    tuned = {k: getattr(args, k) for k in ("update_mode", "first_batch",
                                            "launches_per_epoch", "max_waves", "warp_kernel", "debug")
              if getattr(args, k) is not None}
     options.set(**tuned)

@@ -85,8 +85,7 @@ typedef struct lfm_opts {
                                    2 = compute but do not write (profiling ablation);
                                    3 = publish new - old with global_atomic_add_f32: no update
                                        is lost (DESIGN.md "Hogwild at GPU width")              */
-    int32_t occupancy;          /* wavefronts per SIMD the identity-feature WARP kernel is
-                                   compiled for: 0 = auto, 4, 6 or 8                           */
+    int32_t occupancy;          /* reserved (ignored)                                          */
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
                                    regularisation: 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),

@@ -503,10 +503,6 @@ static hipError_t launch_nc(int loss, const FitArgs &a, int grid, int block, siz
     case 0: fit_logistic_kernel<NC><<<grid, block, smem, st>>>(a); break;
     case 1:
         if (!a.serial && a.itf.identity && a.usf.identity && a.item_alpha == 0.0 && a.user_alpha == 0.0) {
-            if constexpr (NC <= 2) {
-                if (occupancy == 8) return launch_resident(fit_warp_kernel<NC, true, 8>, a, grid, block, smem, st, cus);
-                if (occupancy == 6) return launch_resident(fit_warp_kernel<NC, true, 6>, a, grid, block, smem, st, cus);
-            }
             return launch_resident(fit_warp_kernel<NC, true, 1>, a, grid, block, smem, st, cus);
         }
         return launch_resident(fit_warp_kernel<NC, false, 1>, a, grid, block, smem, st, cus);

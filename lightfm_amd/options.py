@@ -13,16 +13,18 @@ history            interactions the model was already trained on, for the low-le
                    functions (LightFM.fit_partial keeps count itself).
 update_mode        0 auto (= 3), 1 plain load/store Hogwild, 2 no writes (profiling),
                    3 atomic deltas (global_atomic_add_f32, the default).
-occupancy          waves/SIMD variant of the identity WARP kernel (0 auto, 4, 6, 8).
 warp_kernel        0 auto (lane-group tile kernel where it applies), 1 force the generic
-                   one-interaction-per-wavefront WARP kernel.
+                   one-interaction-per-wavefront WARP kernel, 2 tile kernel with phase timers.
+debug              bits 0-2 force the tile kernel's interactions per wavefront pass (1, 2, 4).
 log_samples        record (negative, sampled) per shuffled position into last_logs.
 device_shuffle     LightFM.fit_partial, parallel mode: True (default) builds each epoch's shuffle
                    on the device from two RandomState draws (lfm_session_device_shuffle); False
                    draws numpy's random_state.shuffle(arange(n)) on the host like the reference
                    (LFM:689-690) and uploads it.  Serial mode always uses the host shuffle.
 
-Environment: LIGHTFM_AMD_MODE, LIGHTFM_AMD_LAUNCHES, LIGHTFM_AMD_FIRST_BATCH.
+Environment: LIGHTFM_AMD_MODE, _LAUNCHES, _FIRST_BATCH, _MAX_WAVES, _RAMP_K, _UPDATE_MODE,
+_WARP_KERNEL, _DEBUG, _DEVICE_SHUFFLE; LIGHTFM_AMD_TABLE_ALLOC / _TABLE_ALLOC_MASK select the
+allocation flavour of the weight tables (csrc/session.hip).
 """
 import os
 
