@@ -23,7 +23,10 @@ def run(warm_cap, warm_epochs, cap, epochs=10):
         m.fit_partial(train, item_features=itf, epochs=epochs - warm_epochs)
         res.append(precision_at_k(m, test, train_interactions=train, k=10, item_features=itf).mean())
     print("warm %d epochs at %4d then cap %5d: p@10 test %.4f (std %.4f)" % (warm_epochs, warm_cap, cap, np.mean(res), np.std(res)), flush=True)
-for cap in (0,):
+for cap in (16, 117, 1024, 8192) if os.environ.get('WARMUP_SWEEP') else (0,):
     run(0, 0, cap)
+    if os.environ.get('WARMUP_SWEEP'):
+        run(8, 1, cap)
+        run(8, 2, cap)
 
 
