@@ -16,7 +16,7 @@ struct PredictArgs {
 
 struct RanksArgs {
     const float *user_rep;  // [n_test_users_rows, rs] dense representations (bias at [d])
-    const float *item_rep;  // [n_items, rs]
+    const float *item_rep;  // [rs, n_items] component-major (coalesced across items)
     int32_t rs, d;
     DCsr test, train;
     float *ranks;           // aligned with test.data
@@ -37,8 +37,9 @@ hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st
 
 hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st);
 // dense representation table of every row of f (PYX:287-317), out[row*rs + 0..d]
+// transposed = 1: component-major, out[c*f.rows + row]
 hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs,
-                           float *out, hipStream_t st);
+                           float *out, hipStream_t st, int transposed = 0);
 hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);

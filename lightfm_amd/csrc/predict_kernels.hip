@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs a)
     }
 }
 
+// Dense representations of every row of f.  Row-major (out[row*rs + c]) or, with `transposed`,
+// component-major (out[c*rows + row]): the layout predict_ranks reads coalesced across items.
 template <int NC>
 __global__ __launch_bounds__(256) void rep_rows_kernel(DCsr f, const float *W, const float *b, int d,
-                                                       int rs, float *out)
+                                                       int rs, float *out, int transposed)
 {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -47,20 +49,32 @@ __global__ __launch_bounds__(256) void rep_rows_kernel(DCsr f, const float *W, c
     for (int64_t row = gw; row < f.rows; row += nw) {
         Rep<NC> r;
         load_rep<NC>(f, W, b, d, (int)row, 1.0, lane, r);
-        float *o = out + (size_t)row * rs;
+        float *o = transposed ? out + row : out + (size_t)row * rs;
+        const size_t cs = transposed ? (size_t)f.rows : 1;
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             int c = lane + WAVE * q;
-            if (c < d) o[c] = r.v[q];
+            if (c < d) o[c * cs] = r.v[q];
         }
-        if (lane == 0) o[d] = r.bias;
+        if (lane == 0) o[d * cs] = r.bias;
     }
 }
 
-__device__ __forceinline__ float dense_dot(const float *u, const float *v, int d)
+// Sequential float32 dot (PYX:320-334) of the user's representation (LDS) with item `j` of the
+// component-major item table: lanes of a wavefront read consecutive items, so every load is
+// coalesced.
+__device__ __forceinline__ float dense_dot(const float *u, const float *vT, size_t n_items, int j, int d)
 {
-    float acc = __fadd_rn(u[d], v[d]);
-    for (int c = 0; c < d; ++c) acc = __fadd_rn(acc, __fmul_rn(u[c], v[c]));
+    float acc = __fadd_rn(u[d], vT[(size_t)d * n_items + j]);
+    int c = 0;
+    for (; c + 8 <= d; c += 8) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = vT[(size_t)(c + k) * n_items + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __fadd_rn(acc, __fmul_rn(u[c + k], x[k]));
+    }
+    for (; c < d; ++c) acc = __fadd_rn(acc, __fmul_rn(u[c], vT[(size_t)c * n_items + j]));
     return acc;
 }
 
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(256) void ranks_kernel(RanksArgs a)
             if ((int)threadIdx.x < m) {
                 int it = a.test.indices[c0 + threadIdx.x];
                 tid_[threadIdx.x] = it;
-                tscore[threadIdx.x] = dense_dot(urep, a.item_rep + (size_t)it * a.rs, a.d);
+                tscore[threadIdx.x] = dense_dot(urep, a.item_rep, (size_t)a.test.cols, it, a.d);
                 tcount[threadIdx.x] = 0;
             }
             __syncthreads();
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256) void ranks_kernel(RanksArgs a)
                 int j = r * blockDim.x + threadIdx.x;
                 bool live = j < n_items && !bsearch_row(a.train, user, j);  // PYX:1303-1304
                 float sj = 0.0f;
-                if (live) sj = dense_dot(urep, a.item_rep + (size_t)j * a.rs, a.d);
+                if (live) sj = dense_dot(urep, a.item_rep, (size_t)a.test.cols, j, a.d);
                 for (int t = 0; t < m; ++t) {
                     bool hit = live && (j != tid_[t]) && (sj >= tscore[t]);  // PYX:1317-1319
                     unsigned long long mk = __ballot(hit);
@@ -178,14 +192,14 @@ hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream
 }
 
 hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs, float *out,
-                           hipStream_t st)
+                           hipStream_t st, int transposed)
 {
     if (f.rows <= 0) return hipSuccess;
     int grid = (int)std::min<int64_t>(4096, ((int64_t)f.rows + 3) / 4);
-    if (d <= 64) rep_rows_kernel<1><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
-    else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
-    else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
-    else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out);
+    if (d <= 64) rep_rows_kernel<1><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
+    else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
+    else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
+    else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -942,7 +942,7 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     LFM_TRY(irep.alloc((size_t)itf.rows * rs));
     LFM_TRY(dranks.upload(ranks, (size_t)test->nnz));
     HIP_TRY(launch_rep_rows(usf, s->tab[1][0].p, s->tab[1][3].p, s->d, rs, urep.p, s->stream));
-    HIP_TRY(launch_rep_rows(itf, s->tab[0][0].p, s->tab[0][3].p, s->d, rs, irep.p, s->stream));
+    HIP_TRY(launch_rep_rows(itf, s->tab[0][0].p, s->tab[0][3].p, s->d, rs, irep.p, s->stream, 1));
     RanksArgs a;
     a.user_rep = urep.p;
     a.item_rep = irep.p;
