@@ -71,10 +71,10 @@ extern "C" int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hb
 
 // Allocation flavour of the weight tables: 0 = hipMalloc (coarse-grained: an XCD's L2 may serve
 // lines another XCD has rewritten until the launch ends), 1 = hipDeviceMallocFinegrained,
-// 3 = hipDeviceMallocUncached (default).  The embedding rows are gathered at random with a 37 % L2
-// hit rate and rewritten by atomics that drop them from the L2 again: going straight to the
-// fabric (Infinity Cache) is 14 % faster than through the L2 (0.82 vs 0.72 G interactions/s on
-// the bench workload), and reads are never stale.  Measured precision@10 is the same.
+// 3 = hipDeviceMallocUncached (default for models beyond the L2s' capacity): 14 % faster on the
+// bench workload (0.84 vs 0.72 G interactions/s), same measured precision@10, and reads are never
+// stale.  The gain comes from the small, hot bias tables (mask ablation): their lines
+// are what the atomics of other wavefronts keep dropping from every XCD's L2.
 static int table_alloc_flags()
 {
     static int f = -1;
