@@ -50,6 +50,8 @@ struct FitArgs {
     const float *Y, *weight;
     const int32_t *shuffle;
     const int4 *recs;    // warp_tile.hip: (user, item, Y bits, weight bits) per example, AoS
+    const float *b_read[2];  // warp_tile_kernel.hpp: where the SCORING reads biases (item, user):
+                             // the live tables, or per-launch cached snapshots of them
     int64_t n;           // all examples (BPR modulo, PYX:1124)
     int64_t begin, end;  // shuffled positions of this launch
     double item_alpha, user_alpha;

@@ -248,6 +248,7 @@ struct lfm_session {
     DBuf<int32_t> user_ids, item_ids;
     DBuf<float> Y, weight;
     bool weight_aliases_Y = false;
+    DBuf<float> bias_snap[2];  // per-launch cached copies of the bias tables (tile kernel scoring)
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
     bool recs_valid = false;
     int64_t n = 0;
@@ -507,6 +508,11 @@ static void static_chunk(int64_t n, int32_t T, int32_t t, int64_t *lo, int64_t *
 
 // ------------------------------------------------------------- multi-GPU ---
 
+__global__ void copy_kernel(float *dst, const float *src, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) dst[j] = src[j];
+}
 __global__ void sub_inplace_kernel(float *x, const float *y, int64_t n)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
@@ -784,6 +790,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
         const int64_t slice = std::max<int64_t>(1, (s->n + L - 1) / L);
         const size_t generic_smem = smem;
+        const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);
+        if (snap_biases)
+            for (int side = 0; side < 2; ++side) LFM_TRY(s->bias_snap[side].alloc(tab_count(s, side, 3)));
         FitArgs base = a;
         int64_t begin = 0;
         int ng_used = 0;
@@ -821,7 +830,25 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
             const int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            if (ng) HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2));
+            if (ng) {
+                // Scoring reads twelve 4-byte biases per interaction.  With uncached tables each
+                // is a fabric request; a cached snapshot taken at the launch boundary (the tables
+                // are tiny) serves them from L1/L2 instead, and no atomic ever drops its lines.
+                // Updates still read and publish the live tables.  (LFM debug bit 5 disables it.)
+                a.b_read[0] = a.m.b[0];
+                a.b_read[1] = a.m.b[1];
+                if (snap_biases) {
+                    for (int side = 0; side < 2; ++side) {
+                        const int64_t cnt = (int64_t)tab_count(s, side, 3);
+                        if (cnt) {
+                            const int cgrid = (int)std::min<int64_t>(1024, (cnt + 255) / 256);
+                            copy_kernel<<<cgrid, 256, 0, s->stream>>>(s->bias_snap[side].p, s->tab[side][3].p, cnt);
+                        }
+                        a.b_read[side] = s->bias_snap[side].p;
+                    }
+                }
+                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2));
+            }
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, occupancy, s->cus));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
     float *urow = tile + (size_t)(NG * RG + g) * TS;
     const bool pc = VEC * p < d;  // this lane carries a piece (VEC floats) of every gathered row
     const float *Wi = a.m.W[0], *Wu = a.m.W[1];
-    const float *bi_tab = a.m.b[0], *bu_tab = a.m.b[1];
+    const float *bi_tab = a.b_read[0], *bu_tab = a.b_read[1];
     const int max_sampled = a.m.max_sampled;
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
