@@ -3,16 +3,20 @@
 // features, no L2 regularisation, parallel (Hogwild) mode.
 // PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
 //
-// Work mapping (wave64).  A wavefront is split into NG = 64/LPR lane groups of LPR
-// lanes (LPR = 16 for d <= 64, 32 for d <= 128); each group owns ONE interaction
-// per pass, so a wave retires NG interactions per pass.
+// Work mapping (wave64).  A wavefront is split into NG = 64/LPR lane groups of LPR lanes;
+// each group owns ONE interaction per pass and a lane carries VEC floats of a row.
+// Instantiated (warp_tile_lpr*.hip) for (LPR, VEC) = (16,4) NG = 4; (32,2|4) NG = 2;
+// (64,1|2|4) NG = 1.  NG = 4 needs the fewest instructions per interaction (the scoring pass
+// and the PRNG are shared); session.hip launches fewer interactions per wavefront when few
+// may be in flight (the concurrency ramp), to have more wavefronts hiding latency.
 //
-//   gather   an embedding row is d*4 bytes = LPR lanes x 16 bytes: ONE
-//            global_load_dwordx4 per wave fetches one row for each of the NG
-//            interactions (1 KiB per instruction, fully coalesced per row).  User
-//            row, positive row and the rows of ALL candidate negatives of the
-//            batch (max_sampled of them) are requested back to back before the
-//            first is consumed, then staged in a wave-private LDS tile.
+//   gather   an embedding row is LPR lanes x 4*VEC bytes: ONE global_load_dwordx4 per wave
+//            (NG = 4) fetches one row for each of the NG interactions (1 KiB per
+//            instruction).  User row, positive row and the rows of ALL candidate negatives
+//            of the batch (max_sampled of them) are requested back to back before the first
+//            is consumed, then staged in a wave-private LDS tile; with NG = 1, VEC = 1 they
+//            go memory -> LDS directly (global_load_lds_dword).  Biases are read from
+//            a.b_read: the live tables or per-launch cached snapshots (session.hip).
 //   score    lane r of a group computes the reference's SEQUENTIAL float32 dot
 //            (PYX:320-334: (b_u + b_i) + u0*v0 + u1*v1 ...) of tile row r with the
 //            group's user row: the positive (r = 0) and every candidate negative
