@@ -50,3 +50,53 @@ def test_csrmatrix_rejects_wrong_dtypes(native):
     mat = sp.csr_matrix(np.array([[0, 1], [1, 0]], dtype=np.float64))
     with pytest.raises(ValueError):
         fast.CSRMatrix(mat)
+
+
+def test_argument_validation_happens_before_the_device_is_touched(native):
+    """lfm_session_create rejects malformed models / matrices with LFM_EINVAL (-> ValueError, what
+    the reference raises for bad input) even without a GPU; well-formed input then fails with
+    the no-device error instead of falling back to the CPU."""
+    import ctypes as C
+    import lightfm_amd._lightfm_fast as fast
+    lib = native.lib()
+    d, nu, ni = 8, 5, 7
+    arrs = [np.zeros((ni, d), np.float32)] * 3 + [np.zeros(ni, np.float32)] * 3 + \
+           [np.zeros((nu, d), np.float32)] * 3 + [np.zeros(nu, np.float32)] * 3
+    model = fast.FastLightFM(*arrs, d, 0, 0.05, 0.95, 1e-6, 10)
+    itf = fast.CSRMatrix(sp.identity(ni, dtype=np.float32, format="csr"))
+    usf = fast.CSRMatrix(sp.identity(nu, dtype=np.float32, format="csr"))
+    handle = C.c_void_p()
+
+    def create(m, a, b):
+        return lib.lfm_session_create(C.byref(handle), 0, m, a, b)
+
+    assert create(None, itf.byref(), usf.byref()) == -1                      # null model
+    assert b"null" in lib.lfm_last_error()
+    wide = fast.CSRMatrix(sp.identity(ni + 3, dtype=np.float32, format="csr"))
+    assert create(model.byref(), wide.byref(), usf.byref()) == -1            # more columns than embeddings
+    bad = fast.CSRMatrix(sp.identity(ni, dtype=np.float32, format="csr"))
+    bad.indptr[-1] += 1                                                       # indptr does not span nnz
+    assert create(model.byref(), bad.byref(), usf.byref()) == -1
+    big = fast.FastLightFM(*[np.zeros((ni, 600), np.float32)] * 3, *[np.zeros(ni, np.float32)] * 3,
+                           *[np.zeros((nu, 600), np.float32)] * 3, *[np.zeros(nu, np.float32)] * 3,
+                           600, 0, 0.05, 0.95, 1e-6, 10)
+    assert create(big.byref(), itf.byref(), usf.byref()) == -5               # LFM_EUNSUPPORTED: d > 512
+    with pytest.raises(NotImplementedError):
+        native.check(-5)
+    with pytest.raises(ValueError):
+        native.check(-1)
+    if native.device_count() == 0:
+        assert create(model.byref(), itf.byref(), usf.byref()) == -2         # LFM_ENODEV, no fallback
+        assert b"no CPU fallback" in lib.lfm_last_error()
+        with pytest.raises(native.HipBackendError):
+            native.check(-2)
+    else:
+        assert create(model.byref(), itf.byref(), usf.byref()) == 0
+        assert lib.lfm_session_destroy(handle) == 0
+
+
+def test_host_permutation_rejects_bad_sizes(native):
+    import ctypes as C
+    out = np.empty(4, np.int32)
+    assert native.lib().lfm_shuffle_permutation(native.i32p(out), C.c_int64(-1), 1, 2) == -1
+    assert native.lib().lfm_shuffle_permutation(None, C.c_int64(4), 1, 2) == -1
