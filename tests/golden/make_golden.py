@@ -36,9 +36,19 @@ def main():
             pred = np.empty(len(uids), np.float32)
             C = ref.CSRMatrix
             ref.predict_lightfm(C(item_f), C(user_f), uids, iids, pred, st.ref_struct(ref), 1)
+            # ranks / AUC of a fixed held-out set from the reference's predict_ranks and
+            # calculate_auc_from_rank (evaluation.py:247-249)
+            train, test = H.rank_problem(coo)
+            ranks = np.zeros_like(test.data)
+            ref.predict_ranks(C(item_f), C(user_f), C(test), C(train), ranks, st.ref_struct(ref), 1)
+            import scipy.sparse as sp
+            rmat = sp.csr_matrix((ranks.copy(), test.indices, test.indptr), shape=test.shape)
+            ntp = np.squeeze(np.array(train.getnnz(axis=1)).astype(np.int32))
+            auc = np.zeros(nu, np.float32)
+            ref.calculate_auc_from_rank(C(rmat), ntp, rmat.data, auc, 1)
             np.savez_compressed(
                 os.path.join(OUT, "%s__%s.npz" % (case[0], loss)),
-                predictions=pred[:: max(1, len(pred) // 512)],
+                predictions=pred[:: max(1, len(pred) // 512)], ranks=ranks, auc=auc,
                 **{n: getattr(st, n) for n in oracle.ARRAYS})
 
 

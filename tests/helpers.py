@@ -50,6 +50,17 @@ def positives_csr(coo):
     return m
 
 
+def rank_problem(coo, seed=99, nnz=300):
+    """(train CSR, disjoint test CSR) for predict_ranks / AUC fixtures."""
+    nu, ni = coo.shape
+    train = positives_csr(coo).astype(np.float32)
+    test = make_interactions(nu, ni, nnz, seed=seed).tocsr().astype(np.float32)
+    test = (test - test.multiply(train.astype(bool))).tocsr().astype(np.float32)
+    test.eliminate_zeros()
+    test.sort_indices()
+    return train, test
+
+
 def epoch_inputs(coo, rng, num_threads=1):
     """Host RNG order of lightfm.py:689-690 + _lightfm_fast.pyx:812-814."""
     shuffle = np.arange(len(coo.data), dtype=np.int32)

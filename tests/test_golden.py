@@ -35,3 +35,14 @@ def test_oracle_reproduces_reference_fixture(path):
     iids = np.tile(np.arange(ni, dtype=np.int32), nu)
     pred = oracle.predict(item_f, user_f, uids, iids, st)
     assert np.array_equal(pred[:: max(1, len(pred) // 512)], gold["predictions"])
+    # ranks and AUC against the reference's predict_ranks / calculate_auc_from_rank
+    import scipy.sparse as sp
+    train, test = H.rank_problem(coo)
+    ranks = np.zeros_like(test.data)
+    oracle.predict_ranks(item_f, user_f, test, train, ranks, st)
+    assert np.array_equal(ranks, gold["ranks"])
+    rmat = sp.csr_matrix((ranks.copy(), test.indices, test.indptr), shape=test.shape)
+    ntp = np.squeeze(np.array(train.getnnz(axis=1)).astype(np.int32))
+    auc = np.zeros(nu, np.float32)
+    oracle.auc_from_rank(rmat, ntp, rmat.data, auc)
+    assert np.array_equal(auc, gold["auc"])

@@ -252,3 +252,53 @@ def test_in_positives_truth_table(fast):
     present = set(cols.tolist())
     for c in list(cols[::997]) + [0, 1, 199999, 12345, int(cols[0]), int(cols[-1])]:
         assert fn(0, int(c), fast.CSRMatrix(big)) == (int(c) in present)
+
+
+def _golden_files():
+    import glob
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(glob.glob(os.path.join(gold, "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_hip_reproduces_the_reference_fixtures(fast, path):
+    """The HIP path against the golden vectors the REFERENCE produced (tests/golden/, generated
+    by make_golden.py from the reference's own compiled extension): two serial-mode epochs give
+    the 12 weight arrays, then predictions, ranks and AUCs -- no oracle in between."""
+    import os
+    from lightfm_amd.options import options
+    case_id, loss = os.path.basename(path)[:-4].split("__")
+    case = {c[0]: c for c in LOSS_CASES}[case_id]
+    gold = np.load(path)
+    coo, item_f, user_f, st, rng, alpha = _problem(case)
+    options.set(mode="serial")
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _run_hip(fast, loss, coo, item_f, user_f, st, shuffle, seeds, alpha)
+    options.set(mode="parallel")
+    exact = loss in ("warp", "warp-kos")
+    for n in oracle.ARRAYS:
+        if exact:
+            assert np.array_equal(getattr(st, n), gold[n]), n
+        else:  # exp() of the device libm: last-bit differences, stated tolerance 1e-6
+            np.testing.assert_allclose(getattr(st, n), gold[n], rtol=1e-6, atol=1e-9, err_msg=n)
+    if not exact:
+        for n in oracle.ARRAYS:  # score the reference's own weights from here on
+            getattr(st, n)[...] = gold[n]
+    nu, ni = coo.shape
+    Cm = fast.CSRMatrix
+    uids = np.repeat(np.arange(nu, dtype=np.int32), ni)
+    iids = np.tile(np.arange(ni, dtype=np.int32), nu)
+    pred = np.empty(len(uids), np.float32)
+    fast.predict_lightfm(Cm(item_f), Cm(user_f), uids, iids, pred, _hip_struct(fast, st), 1)
+    assert np.array_equal(pred[:: max(1, len(pred) // 512)], gold["predictions"])
+    train, test = H.rank_problem(coo)
+    ranks = np.zeros_like(test.data)
+    fast.predict_ranks(Cm(item_f), Cm(user_f), Cm(test), Cm(train), ranks, _hip_struct(fast, st), 1)
+    assert np.array_equal(ranks, gold["ranks"])
+    rmat = sp.csr_matrix((ranks.copy(), test.indices, test.indptr), shape=test.shape)
+    ntp = np.squeeze(np.array(train.getnnz(axis=1)).astype(np.int32))
+    auc = np.zeros(nu, np.float32)
+    fast.calculate_auc_from_rank(Cm(rmat), ntp, rmat.data, auc, 1)
+    assert np.array_equal(auc, gold["auc"])
