@@ -1,0 +1,121 @@
+"""Host-side logic of lightfm_amd.LightFM that runs before (or without) the device: argument
+checks, input coercion, initialisation order, error types -- the reference's contract
+(lightfm/lightfm.py, "LFM"; tests/test_api.py, "T_API").  CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from lightfm_amd import LightFM, _native
+
+
+def test_constructor_checks():
+    """LFM:205-216 / T_API:171-183."""
+    for bad in (dict(no_components=0), dict(k=0), dict(n=0), dict(rho=1.0), dict(epsilon=-1.0),
+                dict(item_alpha=-0.1), dict(user_alpha=-0.1), dict(learning_schedule="sgd"),
+                dict(loss="hinge")):
+        with pytest.raises(AssertionError):
+            LightFM(**bad)
+    with pytest.raises(ValueError):
+        LightFM(max_sampled=0)
+    m = LightFM(random_state=7)
+    assert isinstance(m.random_state, np.random.RandomState)
+    rs = np.random.RandomState(3)
+    assert LightFM(random_state=rs).random_state is rs
+
+
+def test_initialisation_order_and_values():
+    """LFM:281-312: item table drawn first, then the user table; W = (rand - 0.5) / d as float32,
+    biases 0, accumulators 1 (adagrad) or 0 (adadelta), momentum 0."""
+    d, ni, nu = 6, 5, 4
+    for schedule, g0 in (("adagrad", 1.0), ("adadelta", 0.0)):
+        m = LightFM(no_components=d, learning_schedule=schedule, random_state=11)
+        m._initialize(d, ni, nu)
+        rs = np.random.RandomState(11)
+        want_item = ((rs.rand(ni, d) - 0.5) / d).astype(np.float32)
+        want_user = ((rs.rand(nu, d) - 0.5) / d).astype(np.float32)
+        assert np.array_equal(m.item_embeddings, want_item)
+        assert np.array_equal(m.user_embeddings, want_user)
+        assert np.all(m.item_embedding_gradients == g0) and np.all(m.user_bias_gradients == g0)
+        assert np.all(m.item_biases == 0) and np.all(m.user_embedding_momentum == 0)
+        assert all(getattr(m, n).dtype == np.float32 for n in
+                   ("item_embeddings", "item_biases", "user_embedding_gradients", "user_bias_momentum"))
+
+
+def test_feature_matrix_construction():
+    """LFM:314-363: identity by default, CSR float32, shape errors."""
+    m = LightFM()
+    uf, itf = m._construct_feature_matrices(3, 4, None, None)
+    assert uf.shape == (3, 3) and itf.shape == (4, 4) and uf.dtype == np.float32 and uf.format == "csr"
+    with pytest.raises(Exception):
+        m._construct_feature_matrices(3, 4, sp.csr_matrix((2, 5)), None)
+    with pytest.raises(Exception):
+        m._construct_feature_matrices(3, 4, None, sp.csr_matrix((3, 5)))
+    m._initialize(4, 4, 3)
+    with pytest.raises(ValueError):  # more feature columns than estimated embeddings
+        m._construct_feature_matrices(3, 4, sp.identity(9, format="csr"), None)
+
+
+def test_positives_lookup_is_sorted_csr():
+    """LFM:365-372."""
+    coo = sp.coo_matrix((np.ones(5, np.float32), ([0, 0, 1, 0, 1], [4, 1, 3, 2, 0])), shape=(2, 5))
+    mat = LightFM()._get_positives_lookup_matrix(coo)
+    assert mat.format == "csr" and mat.has_sorted_indices
+    assert list(mat.indices[mat.indptr[0]:mat.indptr[1]]) == [1, 2, 4]
+
+
+def test_sample_weight_processing():
+    """LFM:381-420 / T_API:186-214."""
+    train = sp.coo_matrix(np.array([[0, 1], [0, 1]], dtype=np.float32))
+    m = LightFM()
+    assert m._process_sample_weight(train, None) is train.data          # aliases Y when all ones
+    two = sp.coo_matrix(np.array([[0, 2], [0, 1]], dtype=np.float32))
+    w = m._process_sample_weight(two, None)
+    assert w is not two.data and np.all(w == 1.0)
+    with pytest.raises(ValueError):
+        m._process_sample_weight(train, np.zeros(2))
+    with pytest.raises(ValueError):
+        m._process_sample_weight(train, sp.coo_matrix(np.zeros((3, 3))))
+    with pytest.raises(ValueError):
+        m._process_sample_weight(train, sp.coo_matrix((train.data, (train.row[::-1], train.col[::-1]))))
+    with pytest.raises(NotImplementedError):
+        LightFM(loss="warp-kos")._process_sample_weight(train, sp.coo_matrix(train))
+    ok = sp.coo_matrix((np.array([0.5, 2.0]), (train.row, train.col)), shape=train.shape)
+    assert m._process_sample_weight(train, ok).dtype == np.float32
+
+
+def test_errors_raised_before_any_device_work():
+    """T_API:309-351, 121-133: not fitted, NaN input, bad thread count, bad shapes."""
+    m = LightFM()
+    with pytest.raises(ValueError):
+        m.predict(np.arange(3), np.arange(3))
+    with pytest.raises(ValueError):
+        m.get_item_representations()
+    train = sp.rand(20, 30, density=0.2, format="coo", random_state=1)
+    bad = train.copy()
+    bad.data = bad.data * np.nan
+    with pytest.raises(ValueError):
+        LightFM(loss="warp").fit(bad)
+    with pytest.raises(ValueError):
+        LightFM().fit(train, num_threads=0)
+    with pytest.raises(Exception):
+        LightFM().fit(train, item_features=sp.csr_matrix((29, 5)))
+
+
+def test_sklearn_params():
+    """LFM:1049-1107 / T_API:297-306."""
+    m = LightFM(no_components=17, loss="bpr", max_sampled=3)
+    p = m.get_params()
+    assert p["no_components"] == 17 and p["loss"] == "bpr" and p["max_sampled"] == 3
+    assert LightFM(**p).get_params() == p
+    assert m.set_params(no_components=5) is m and m.no_components == 5
+    with pytest.raises(ValueError):
+        m.set_params(bogus=1)
+
+
+def test_fit_without_a_gpu_fails_loudly():
+    """No CPU fallback: valid input on a box without a HIP device raises the backend error."""
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    train = sp.rand(20, 30, density=0.2, format="coo", random_state=1)
+    with pytest.raises(_native.HipBackendError):
+        LightFM(loss="warp").fit(train)
