@@ -85,7 +85,10 @@ typedef struct lfm_opts {
                                    2 = compute but do not write (profiling ablation);
                                    3 = publish new - old with global_atomic_add_f32: no update
                                        is lost (DESIGN.md "Hogwild at GPU width")              */
-    int32_t occupancy;          /* reserved (ignored)                                          */
+    int32_t feat_kernel;        /* parallel mode, models the lane-group tile kernel does not cover
+                                   (feature CSRs, BPR, k-OS, logistic): 0 = auto (the pipelined
+                                   row-stream kernels, csrc/feat_kernel.hpp, when d <= 128 and
+                                   alpha == 0), 1 = force the generic kernels                   */
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
                                    regularisation: 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
@@ -106,6 +109,16 @@ typedef struct lfm_opts {
     int32_t ramp_k;             /* in: at most (history + done) / ramp_k interactions in flight;
                                    0 = auto (32), < 0 = no ramp                               */
     int32_t launches;           /* out: kernel launches of the epoch                        */
+    int32_t kernel_used;        /* out: 0 generic one-interaction-per-wavefront kernels, 1 lane-group
+                                   WARP tile kernel, 2 pipelined row-stream kernels (feat_kernel.hpp) */
+    int32_t shared_cap;         /* in: steady-state bound on interactions in flight for models with shared
+                                   feature rows; 0 = auto (feature rows / avg nnz per row of the side),
+                                   < 0 = none */
+    int64_t pos_begin, pos_end; /* in, parallel mode: run only shuffled positions [pos_begin, pos_end)
+                                   of the slot (0, 0 = the whole epoch).  The multi-GPU driver runs
+                                   an epoch as segments with a merge of the replicated tables
+                                   between them (lfm_session_comm_merge); `history` must then count
+                                   the positions of earlier segments too                        */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0
@@ -207,21 +220,56 @@ int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, const lfm_csr
                               float *ranks);
 /* Copies the 12 arrays back into the caller's buffers. */
 int lfm_session_sync_to_host(lfm_session *s, lfm_model *model);
+/* The inverse: overwrites the resident tables with the caller's arrays (same shapes). */
+int lfm_session_load_model(lfm_session *s, const lfm_model *model);
+/* Builds the positives lookup (LFM:365-372: interactions.tocsr() with sorted indices, duplicates
+ * summed away) ON DEVICE from the uploaded COO instead of taking it from the host: sort by
+ * (user, item) key + unique + row pointers.  Call after lfm_session_set_interactions(positives =
+ * NULL, ...); n_users / n_items = shape of the interaction matrix. */
+int lfm_session_build_positives(lfm_session *s, int32_t n_users, int32_t n_items);
+/* The resident positives lookup back on the host (tests): *nnz always; indptr [rows + 1] and
+ * indices [*nnz] when not NULL. */
+int lfm_session_download_positives(lfm_session *s, int32_t *indptr, int32_t *indices, int64_t *nnz);
+/* get_item_representations / get_user_representations with a feature matrix (LFM:991-1047):
+ * biases[r] = sum_f features[r,f] * b[f], embeddings[r,:] = sum_f features[r,f] * W[f,:], float32
+ * accumulation in CSR order.  side 0 = item, 1 = user; embeddings is [features.rows, d] row-major. */
+int lfm_session_representations(lfm_session *s, int32_t side, const lfm_csr *features, float *biases,
+                                float *embeddings);
 int lfm_session_destroy(lfm_session *s);
 
 /* ------------------------------------------------------------------------
  * Multi-GPU (no reference counterpart): one process per GPU,
- * interactions sharded by user; after every epoch the replicated item-side
- * tables are merged with an RCCL all-reduce of their per-epoch deltas.
+ * interactions sharded by user; the replicated item-side tables are merged with an
+ * RCCL all-reduce of their deltas at a cadence the host driver chooses
+ * (lightfm_amd/distributed.py: merge_schedule).
  * ------------------------------------------------------------------------ */
 #define LFM_UNIQUE_ID_BYTES 128
 int lfm_comm_unique_id(char id[LFM_UNIQUE_ID_BYTES]);
 int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID_BYTES], int32_t rank,
                           int32_t nranks);
-/* Merge user-side tables too (rows are disjoint across ranks with identity user
- * features, so this is an exact union); call once before sync_to_host. */
-int lfm_session_comm_merge_users(lfm_session *s);
+/* Merge of the replicated tables (all ranks must call it the same number of times; the state
+ * after the call is the start of the next interval).  sides: bit 0 = item tables, bit 1 = user
+ * tables (only when user features are shared; with identity user features every rank holds just
+ * its own users' rows and they are never communicated).  mode:
+ *   LFM_MERGE_SUM       X := X0 + sum_r (X_r - X0) for every table (local SGD with summed steps)
+ *   LFM_MERGE_MEAN      embeddings/biases take the MEAN of the ranks' deltas, accumulators the sum
+ *   LFM_MERGE_ADAGRAD   accumulators are summed first; every rank's embedding delta is then rescaled
+ *                       by sqrt((G0 + dG_r/2) / (G0 + sum dG/2)) -- the step it would have taken had
+ *                       it seen the other ranks' squared gradients too -- and the rescaled deltas summed */
+#define LFM_MERGE_SUM 0
+#define LFM_MERGE_MEAN 1
+#define LFM_MERGE_ADAGRAD 2
+int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode);
+/* Marks the current tables of `sides` as the start of a merge interval (lfm_session_comm_init
+ * does it for the replicated sides; sessions merged with lfm_sessions_merge_local call it once
+ * before training). */
+int lfm_session_merge_begin(lfm_session *s, int32_t sides);
+/* max over ranks of a flag (e.g. "my tables are not finite"), so that all ranks raise together */
+int lfm_session_comm_any(lfm_session *s, int32_t flag);
 int lfm_session_comm_barrier(lfm_session *s);
+/* The same merge arithmetic for K sessions living in ONE process on ONE device (no RCCL): how the
+ * multi-GPU semantics are measured on a single GPU (tools/multi_gpu_emulation.py) and tested. */
+int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode);
 
 #ifdef __cplusplus
 }

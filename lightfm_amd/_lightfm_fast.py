@@ -84,10 +84,11 @@ def make_opts(n=0, want_log=False):
     o.first_batch = int(options.first_batch)
     o.max_waves = int(options.max_waves)
     o.update_mode = int(options.update_mode)
-    o.occupancy = int(options.occupancy)
+    o.feat_kernel = int(options.feat_kernel)
     o.warp_kernel = int(options.warp_kernel)
     o.debug = int(options.debug)
     o.ramp_k = int(options.ramp_k)
+    o.shared_cap = int(options.shared_cap)
     o.history = int(options.history)
     logs = None
     if want_log:

@@ -45,9 +45,12 @@ class LfmOpts(C.Structure):
                 ("first_batch", C.c_int32), ("max_waves", C.c_int32),
                 ("neg_log", I32P), ("sampled_log", I32P),
                 ("counters", C.c_int64 * 4), ("kernel_ms", C.c_float),
-                ("update_mode", C.c_int32), ("occupancy", C.c_int32), ("warp_kernel", C.c_int32), ("debug", C.c_int32),
+                ("update_mode", C.c_int32), ("feat_kernel", C.c_int32), ("warp_kernel", C.c_int32),
+                ("debug", C.c_int32),
                 ("phase_cycles", C.c_int64 * 8), ("tile_ng", C.c_int32), ("in_flight", C.c_int32),
-                ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32)]
+                ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32),
+                ("kernel_used", C.c_int32), ("shared_cap", C.c_int32),
+                ("pos_begin", C.c_int64), ("pos_end", C.c_int64)]
 
 
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)
@@ -58,10 +61,14 @@ EXPORTS = (
     "lfm_session_create", "lfm_session_set_interactions", "lfm_session_upload_shuffle",
     "lfm_session_device_shuffle", "lfm_shuffle_permutation", "lfm_session_download_shuffle",
     "lfm_session_epoch", "lfm_session_check_finite", "lfm_session_predict",
-    "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_destroy",
-    "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge_users",
-    "lfm_session_comm_barrier",
+    "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
+    "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
+    "lfm_session_destroy",
+    "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_merge_begin",
+    "lfm_session_comm_any", "lfm_session_comm_barrier", "lfm_sessions_merge_local",
 )
+MERGE_SUM, MERGE_MEAN, MERGE_ADAGRAD = 0, 1, 2
+MERGE_MODES = {"sum": MERGE_SUM, "mean": MERGE_MEAN, "adagrad": MERGE_ADAGRAD}
 
 _lib = None
 

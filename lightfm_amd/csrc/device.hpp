@@ -332,6 +332,52 @@ __device__ __forceinline__ void publish(float *p, float nv, float ov, int mode =
     }
 }
 
+// Adadelta in parallel (Hogwild) mode.  Its accumulators are exponential moving averages
+// (PYX:416-434): publishing new - old would apply the decay -(1-rho)*old once per CONCURRENT
+// writer -- K wavefronts that read the same G of a popular row leave G*(1 - K(1-rho)) + ...,
+// negative once K > 1/(1-rho) = 20, and the next sqrt is a NaN.  So G and M are written with
+// compare-and-swap against the value the arithmetic started from and recomputed from the value
+// actually in memory on conflict: every writer sees a distinct predecessor, exactly like some
+// sequential interleaving.  Without contention this is the plain cell (bit-identical).  W is
+// still an additive delta.
+__device__ __forceinline__ double publish_adadelta(float *Wp, float *Gp, float *Mp, float oW, float oG,
+                                                   float oM, double w, double g, const Hyper &h,
+                                                   double alpha)
+{
+    float nW, nG, nM, cg = oG, cm = oM;
+    double lr;
+    for (;;) {
+        cell_math(oW, cg, cm, w, g, h, alpha, nW, nG, nM, lr);
+        const int prev = atomicCAS(reinterpret_cast<int *>(Gp), __float_as_int(cg), __float_as_int(nG));
+        if (prev == __float_as_int(cg)) break;
+        cg = __int_as_float(prev);
+    }
+    for (;;) {
+        const int prev = atomicCAS(reinterpret_cast<int *>(Mp), __float_as_int(cm), __float_as_int(nM));
+        if (prev == __float_as_int(cm)) break;
+        cm = __int_as_float(prev);
+        cell_math(oW, cg, cm, w, g, h, alpha, nW, nG, nM, lr);
+    }
+    const float dlt = __fsub_rn(nW, oW);
+    if (dlt != 0.0f) atomicAdd(Wp, dlt);
+    return lr;
+}
+
+// Publication of one cell whose new values were computed by cell_math from (oW, oG, oM).
+// mode: 0 atomic (deltas; adadelta accumulators by compare-and-swap), 1 plain stores, 2 nothing.
+__device__ __forceinline__ void publish_cell(float *Wp, float *Gp, float *Mp, float oW, float oG,
+                                             float oM, float nW, float nG, float nM, double w, double g,
+                                             const Hyper &h, double alpha, int mode)
+{
+    if (mode == 0 && h.adadelta) {
+        publish_adadelta(Wp, Gp, Mp, oW, oG, oM, w, g, h, alpha);
+        return;
+    }
+    publish(Wp, nW, oW, mode);
+    publish(Gp, nG, oG, mode);
+    if (h.adadelta) publish(Mp, nM, oM, mode);
+}
+
 // Load-compute-store of one cell.  `atomic`: publish deltas; otherwise plain stores
 // (serial mode).
 __device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, double w, double g,
@@ -342,9 +388,7 @@ __device__ __forceinline__ double cell_update(float *Wp, float *Gp, float *Mp, d
     double lr;
     cell_math(oW, oG, oM, w, g, h, alpha, nW, nG, nM, lr);
     if (atomic) {
-        publish(Wp, nW, oW);
-        publish(Gp, nG, oG);
-        if (h.adadelta) publish(Mp, nM, oM);
+        publish_cell(Wp, Gp, Mp, oW, oG, oM, nW, nG, nM, w, g, h, alpha, 0);
     } else {
         *Wp = nW;
         *Gp = nG;
@@ -466,9 +510,9 @@ __device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int s
                             cell_math(oW[j][q], oG[j][q], oM[j][q], w, gcoef * (double)x[q], h, alpha, nW,
                                       nG, nM, lr);
                             lr_comp[q] += lr;
-                            publish(m.W[side] + base[j] + c, nW, oW[j][q], atomic ? 0 : 1);
-                            publish(m.G[side] + base[j] + c, nG, oG[j][q], atomic ? 0 : 1);
-                            if (h.adadelta) publish(m.M[side] + base[j] + c, nM, oM[j][q], atomic ? 0 : 1);
+                            publish_cell(m.W[side] + base[j] + c, m.G[side] + base[j] + c, m.M[side] + base[j] + c,
+                                         oW[j][q], oG[j][q], oM[j][q], nW, nG, nM, w, gcoef * (double)x[q], h, alpha,
+                                         atomic ? 0 : 1);
                         }
                     }
                 }
@@ -540,7 +584,9 @@ __device__ __forceinline__ double rows_update_parallel(const DModel &m, const Ro
         }
     }
     double lr_acc = 0.0;
-    if (big) {
+    // adadelta's accumulators are published by compare-and-swap (publish_adadelta), which needs
+    // the old values at publication time: the per-row path keeps them
+    if (big || (h.adadelta && atomic)) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             double lb, lc[NC];
@@ -855,25 +901,21 @@ __device__ __forceinline__ void warp_update_identity(double loss, const FitArgs 
         if (c < d) {
             double u = (double)U.v[q];
             cell_math(P.v[q], gP[q], mP[q], 1.0, -loss * u, h, 0.0, nW, nG, nM, lr);
-            publish(Wi + bp + c, nW, P.v[q], um);
-            publish(Gi + bp + c, nG, gP[q], um);
-            if (h.adadelta) publish(Mi + bp + c, nM, mP[q], um);
+            publish_cell(Wi + bp + c, Gi + bp + c, Mi + bp + c, P.v[q], gP[q], mP[q], nW, nG, nM, 1.0, -loss * u,
+                         h, 0.0, um);
             cell_math(N.v[q], gN[q], mN[q], 1.0, loss * u, h, 0.0, nW, nG, nM, lr);
-            publish(Wi + bn + c, nW, N.v[q], um);
-            publish(Gi + bn + c, nG, gN[q], um);
-            if (h.adadelta) publish(Mi + bn + c, nM, mN[q], um);
+            publish_cell(Wi + bn + c, Gi + bn + c, Mi + bn + c, N.v[q], gN[q], mN[q], nW, nG, nM, 1.0, loss * u,
+                         h, 0.0, um);
             double df = (double)__fsub_rn(N.v[q], P.v[q]);
             cell_math(U.v[q], gU[q], mU[q], 1.0, loss * df, h, 0.0, nW, nG, nM, lr);
-            publish(Wu + bu + c, nW, U.v[q], um);
-            publish(Gu + bu + c, nG, gU[q], um);
-            if (h.adadelta) publish(Mu + bu + c, nM, mU[q], um);
+            publish_cell(Wu + bu + c, Gu + bu + c, Mu + bu + c, U.v[q], gU[q], mU[q], nW, nG, nM, 1.0, loss * df,
+                         h, 0.0, um);
         }
     }
     if (lane < 3) {
-        cell_math(obW, obG, obM, 1.0, lane == 0 ? -loss : loss, h, 0.0, nW, nG, nM, lr);
-        publish(bW, nW, obW, um);
-        publish(bG, nG, obG, um);
-        if (h.adadelta) publish(bM, nM, obM, um);
+        const double gb = lane == 0 ? -loss : loss;
+        cell_math(obW, obG, obM, 1.0, gb, h, 0.0, nW, nG, nM, lr);
+        publish_cell(bW, bG, bM, obW, obG, obM, nW, nG, nM, 1.0, gb, h, 0.0, um);
     }
 }
 

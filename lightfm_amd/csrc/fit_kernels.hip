@@ -483,7 +483,7 @@ __global__ void nonfinite_kernel(const float *x, int64_t n, int *flag)
 // start of the launch instead of queueing behind a first wave of blocks.
 template <typename K>
 static hipError_t launch_resident(K kernel, const FitArgs &a, int grid, int block, size_t smem,
-                                  hipStream_t st, int cus)
+                                  hipStream_t st, int cus, int *grid_used)
 {
     if (cus > 0 && block == 256) {
         int per_cu = 0;
@@ -491,36 +491,37 @@ static hipError_t launch_resident(K kernel, const FitArgs &a, int grid, int bloc
             per_cu > 0)
             grid = std::min(grid, per_cu * cus);
     }
+    if (grid_used) *grid_used = grid;
     kernel<<<grid, block, smem, st>>>(a);
     return hipGetLastError();
 }
 
 template <int NC>
 static hipError_t launch_nc(int loss, const FitArgs &a, int grid, int block, size_t smem,
-                            hipStream_t st, int occupancy, int cus)
+                            hipStream_t st, int cus, int *grid_used)
 {
     switch (loss) {
-    case 0: fit_logistic_kernel<NC><<<grid, block, smem, st>>>(a); break;
+    case 0: return launch_resident(fit_logistic_kernel<NC>, a, grid, block, smem, st, cus, grid_used);
     case 1:
         if (!a.serial && a.itf.identity && a.usf.identity && a.item_alpha == 0.0 && a.user_alpha == 0.0) {
-            return launch_resident(fit_warp_kernel<NC, true, 1>, a, grid, block, smem, st, cus);
+            return launch_resident(fit_warp_kernel<NC, true, 1>, a, grid, block, smem, st, cus, grid_used);
         }
-        return launch_resident(fit_warp_kernel<NC, false, 1>, a, grid, block, smem, st, cus);
-    case 2: fit_bpr_kernel<NC><<<grid, block, smem, st>>>(a); break;
-    case 3: fit_warp_kos_kernel<NC><<<grid, block, smem, st>>>(a); break;
+        return launch_resident(fit_warp_kernel<NC, false, 1>, a, grid, block, smem, st, cus, grid_used);
+    case 2: return launch_resident(fit_bpr_kernel<NC>, a, grid, block, smem, st, cus, grid_used);
+    case 3: return launch_resident(fit_warp_kos_kernel<NC>, a, grid, block, smem, st, cus, grid_used);
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
-                      int occupancy, int cus)
+                      int cus, int *grid_used)
 {
     int d = a.m.d;
-    if (d <= 64) return launch_nc<1>(loss, a, grid, block, smem, st, occupancy, cus);
-    if (d <= 128) return launch_nc<2>(loss, a, grid, block, smem, st, occupancy, cus);
-    if (d <= 256) return launch_nc<4>(loss, a, grid, block, smem, st, occupancy, cus);
-    if (d <= 512) return launch_nc<8>(loss, a, grid, block, smem, st, occupancy, cus);
+    if (d <= 64) return launch_nc<1>(loss, a, grid, block, smem, st, cus, grid_used);
+    if (d <= 128) return launch_nc<2>(loss, a, grid, block, smem, st, cus, grid_used);
+    if (d <= 256) return launch_nc<4>(loss, a, grid, block, smem, st, cus, grid_used);
+    if (d <= 512) return launch_nc<8>(loss, a, grid, block, smem, st, cus, grid_used);
     return hipErrorInvalidValue;
 }
 

@@ -22,13 +22,14 @@ struct RanksArgs {
     float *ranks;           // aligned with test.data
 };
 
+// grid_used (optional): the grid actually launched (after the residency clamp)
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
-                      int occupancy = 0, int cus = 0);
+                      int cus = 0, int *grid_used = nullptr);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)
 // ng = interactions per wavefront pass (1, 2, 4); vec = floats of a row per lane
 size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec);
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
-                                int cus, bool timed = false);
+                                int cus, bool timed = false, int *grid_used = nullptr);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
@@ -38,8 +39,13 @@ hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st
 hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st);
 // dense representation table of every row of f (PYX:287-317), out[row*rs + 0..d]
 // transposed = 1: component-major, out[c*f.rows + row]
+// bias_out != nullptr: biases go to bias_out[row] instead of out[row*rs + d] (rs may then be d)
 hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs,
-                           float *out, hipStream_t st, int transposed = 0);
+                           float *out, hipStream_t st, int transposed = 0, float *bias_out = nullptr);
+// csr_build.hip: positives lookup CSR (sorted, duplicate-free) from the COO, on device
+hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids, int64_t n, int32_t n_users,
+                               int32_t n_items, int32_t *indices_out, int32_t *indptr_out, int64_t *nnz_out,
+                               hipStream_t st);
 hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs a)
 // component-major (out[c*rows + row]): the layout predict_ranks reads coalesced across items.
 template <int NC>
 __global__ __launch_bounds__(256) void rep_rows_kernel(DCsr f, const float *W, const float *b, int d,
-                                                       int rs, float *out, int transposed)
+                                                       int rs, float *out, int transposed, float *bias_out)
 {
     const int lane = lane_id();
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void rep_rows_kernel(DCsr f, const float *W, c
             int c = lane + WAVE * q;
             if (c < d) o[c * cs] = r.v[q];
         }
-        if (lane == 0) o[d * cs] = r.bias;
+        if (lane == 0) {
+            if (bias_out) bias_out[row] = r.bias;
+            else o[d * cs] = r.bias;
+        }
     }
 }
 
@@ -192,14 +195,14 @@ hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream
 }
 
 hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d, int rs, float *out,
-                           hipStream_t st, int transposed)
+                           hipStream_t st, int transposed, float *bias_out)
 {
     if (f.rows <= 0) return hipSuccess;
     int grid = (int)std::min<int64_t>(4096, ((int64_t)f.rows + 3) / 4);
-    if (d <= 64) rep_rows_kernel<1><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
-    else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
-    else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
-    else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed);
+    if (d <= 64) rep_rows_kernel<1><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
+    else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
+    else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
+    else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -163,6 +163,15 @@ struct DevCsr {
         if (need_data) LFM_TRY(data.upload(m->data, (size_t)m->nnz));
         return LFM_OK;
     }
+    void clear()
+    {
+        indices.release();
+        indptr.release();
+        data.release();
+        rows = cols = 0;
+        nnz = 0;
+        identity = false;
+    }
     DCsr view() const { return DCsr{indices.p, indptr.p, data.p, rows, cols, identity ? 1 : 0}; }
 };
 
@@ -258,8 +267,9 @@ struct lfm_session {
     // multi-GPU
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
-    DBuf<float> snap[2][6];
-    bool user_snap_valid = false;
+    DBuf<float> snap[2][6];     // the tables at the start of the current merge interval
+    int snap_sides = 0;         // bit 0 item, bit 1 user: which sides have a valid snapshot
+    DBuf<float> scratch[2];     // merge temporaries (ADAGRAD mode: this rank's dG; local reduce: sums)
 
     ~lfm_session()
     {
@@ -401,15 +411,19 @@ extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *posit
     HIP_TRY(hipSetDevice(s->device));
     s->n = n;
     s->recs_valid = false;
+    // an argument that is NULL leaves nothing of an earlier upload behind
     if (positives) {
         LFM_TRY(validate_csr(positives, "interactions"));
         LFM_TRY(s->pos.upload(positives, false, false));
+    } else {
+        s->pos.clear();
     }
     LFM_TRY(s->user_ids.upload(user_ids, (size_t)n));
-    if (item_ids) LFM_TRY(s->item_ids.upload(item_ids, (size_t)n));
-    if (Y) LFM_TRY(s->Y.upload(Y, (size_t)n));
-    s->weight_aliases_Y = (sample_weight == Y);
+    if (item_ids) LFM_TRY(s->item_ids.upload(item_ids, (size_t)n)); else s->item_ids.release();
+    if (Y) LFM_TRY(s->Y.upload(Y, (size_t)n)); else s->Y.release();
+    s->weight_aliases_Y = (Y != nullptr && sample_weight == Y);
     if (sample_weight && !s->weight_aliases_Y) LFM_TRY(s->weight.upload(sample_weight, (size_t)n));
+    else s->weight.release();
     return LFM_OK;
 }
 
@@ -518,11 +532,41 @@ __global__ void sub_inplace_kernel(float *x, const float *y, int64_t n)
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = t; j < n; j += st) x[j] -= y[j];
 }
-__global__ void add_inplace_kernel(float *x, const float *y, int64_t n)
+// x := (x * scale) + y ; snap := x   (end of a merge: deltas back to values, new interval start)
+__global__ void finish_merge_kernel(float *x, float *snap, float scale, int64_t n)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t; j < n; j += st) x[j] += y[j];
+    for (int64_t j = t; j < n; j += st) {
+        const float v = x[j] * scale + snap[j];
+        x[j] = v;
+        snap[j] = v;
+    }
 }
+// LFM_MERGE_ADAGRAD: dW (this rank's embedding delta, [rows, cols]) *= sqrt((G0 + dG_r/2) / (G0 + dG_all/2)),
+// element by element: the step this rank would have taken had its accumulators also seen the other
+// ranks' squared gradients of the interval (both at the interval's midpoint).
+__global__ void adagrad_rescale_kernel(float *dW, const float *g0, const float *dg_rank, const float *dg_all,
+                                       int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) {
+        const float num = g0[j] + 0.5f * dg_rank[j], den = g0[j] + 0.5f * dg_all[j];
+        if (den > 0.0f && num >= 0.0f && den > num) dW[j] *= sqrtf(num / den);
+    }
+}
+struct PtrPack { float *p[16]; };
+// every x_k := sum_k x_k  (the all-reduce of K sessions living on one device)
+__global__ void local_allreduce_kernel(PtrPack xs, int k, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) {
+        float acc = 0.0f;
+        for (int r = 0; r < k; ++r) acc += xs.p[r][j];
+        for (int r = 0; r < k; ++r) xs.p[r][j] = acc;
+    }
+}
+
+static int grid_for(int64_t cnt) { return (int)std::max<int64_t>(1, std::min<int64_t>(4096, (cnt + 255) / 256)); }
 
 static int snapshot_side(lfm_session *s, int side)
 {
@@ -534,37 +578,107 @@ static int snapshot_side(lfm_session *s, int side)
             HIP_TRY(hipMemcpyAsync(s->snap[side][k].p, s->tab[side][k].p, cnt * sizeof(float),
                                    hipMemcpyDeviceToDevice, s->stream));
     }
+    s->snap_sides |= 1 << side;
     return LFM_OK;
 }
 
-// X := X_start + sum over ranks (X_rank - X_start): the local-SGD merge of SURVEY 8(e).
-static int merge_side(lfm_session *s, int side)
+extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
 {
-    Rccl *r = rccl();
-    if (!r) return fail(LFM_ECOMM, "librccl.so not available");
-    for (int k = 0; k < 6; ++k) {
-        if (!kind_used(s, k)) continue;
-        int64_t cnt = (int64_t)tab_count(s, side, k);
-        if (!cnt) continue;
-        int grid = (int)std::min<int64_t>(4096, (cnt + 255) / 256);
-        sub_inplace_kernel<<<grid, 256, 0, s->stream>>>(s->tab[side][k].p, s->snap[side][k].p, cnt);
-    }
-    if (r->GroupStart) NCCL_TRY(r->GroupStart());
-    for (int k = 0; k < 6; ++k) {
-        if (!kind_used(s, k)) continue;
-        size_t cnt = tab_count(s, side, k);
-        if (!cnt) continue;
-        NCCL_TRY(r->AllReduce(s->tab[side][k].p, s->tab[side][k].p, cnt, ncclFloat, ncclSum, s->comm, s->stream));
-    }
-    if (r->GroupEnd) NCCL_TRY(r->GroupEnd());
-    for (int k = 0; k < 6; ++k) {
-        if (!kind_used(s, k)) continue;
-        int64_t cnt = (int64_t)tab_count(s, side, k);
-        if (!cnt) continue;
-        int grid = (int)std::min<int64_t>(4096, (cnt + 255) / 256);
-        add_inplace_kernel<<<grid, 256, 0, s->stream>>>(s->tab[side][k].p, s->snap[side][k].p, cnt);
+    if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge_begin arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    for (int side = 0; side < 2; ++side)
+        if ((sides >> side) & 1) LFM_TRY(snapshot_side(s, side));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LFM_OK;
+}
+
+// The merge of SURVEY 8(e) for a group of sessions: ONE session whose peers are other processes
+// (reduction = RCCL all-reduce over xGMI), or K sessions of this process on one device
+// (reduction = local_allreduce_kernel; same arithmetic, used to measure N-GPU semantics on one GPU).
+//   X := X0 + op_r (X_r - X0),  X0 = the snapshot taken at the start of the interval.
+static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int mode)
+{
+    lfm_session *s0 = ss[0];
+    const bool use_rccl = (k == 1 && s0->comm != nullptr);
+    Rccl *r = use_rccl ? rccl() : nullptr;
+    if (use_rccl && !r) return fail(LFM_ECOMM, "librccl.so not available");
+    if (k > 16) return fail(LFM_EINVAL, "at most 16 local sessions per merge group");
+    if (mode < 0 || mode > 2) return fail(LFM_EINVAL, "unknown merge mode");
+    if (s0->adadelta && mode == LFM_MERGE_ADAGRAD) mode = LFM_MERGE_MEAN;  // moving averages: no squared-gradient sums
+    // local groups run on sessions[0]'s stream; the others' streams are drained first
+    hipStream_t st = s0->stream;
+    for (int i = 1; i < k; ++i) HIP_TRY(hipStreamSynchronize(ss[i]->stream));
+    auto reduce_kinds = [&](int side, std::initializer_list<int> kinds) -> int {
+        if (use_rccl) {
+            if (r->GroupStart) NCCL_TRY(r->GroupStart());
+            for (int kind : kinds) {
+                if (!kind_used(s0, kind)) continue;
+                size_t cnt = tab_count(s0, side, kind);
+                if (!cnt) continue;
+                NCCL_TRY(r->AllReduce(s0->tab[side][kind].p, s0->tab[side][kind].p, cnt, ncclFloat, ncclSum, s0->comm, st));
+            }
+            if (r->GroupEnd) NCCL_TRY(r->GroupEnd());
+        } else if (k > 1) {
+            for (int kind : kinds) {
+                if (!kind_used(s0, kind)) continue;
+                int64_t cnt = (int64_t)tab_count(s0, side, kind);
+                if (!cnt) continue;
+                PtrPack pk;
+                for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->tab[side][kind].p;
+                local_allreduce_kernel<<<grid_for(cnt), 256, 0, st>>>(pk, k, cnt);
+            }
+        }
+        return LFM_OK;
+    };
+    for (int side = 0; side < 2; ++side) {
+        if (!((sides >> side) & 1)) continue;
+        for (int i = 0; i < k; ++i) {
+            if (!((ss[i]->snap_sides >> side) & 1)) return fail(LFM_EINVAL, "merge without lfm_session_merge_begin");
+            if (ss[i]->n_feat[side] != s0->n_feat[side] || ss[i]->d != s0->d) return fail(LFM_EINVAL, "sessions differ in shape");
+        }
+        // 1. tables -> deltas
+        for (int i = 0; i < k; ++i)
+            for (int kind = 0; kind < 6; ++kind) {
+                if (!kind_used(s0, kind)) continue;
+                int64_t cnt = (int64_t)tab_count(s0, side, kind);
+                if (cnt) sub_inplace_kernel<<<grid_for(cnt), 256, 0, st>>>(ss[i]->tab[side][kind].p, ss[i]->snap[side][kind].p, cnt);
+            }
+        float wscale = 1.0f;
+        if (mode == LFM_MERGE_ADAGRAD) {
+            // accumulators first (keeping this rank's own dG), then the rescaled embedding deltas
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                const size_t cw = tab_count(s, side, 1), cb = tab_count(s, side, 4);
+                LFM_TRY(s->scratch[0].alloc(cw));
+                LFM_TRY(s->scratch[1].alloc(cb));
+                if (cw) HIP_TRY(hipMemcpyAsync(s->scratch[0].p, s->tab[side][1].p, cw * sizeof(float), hipMemcpyDeviceToDevice, st));
+                if (cb) HIP_TRY(hipMemcpyAsync(s->scratch[1].p, s->tab[side][4].p, cb * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            LFM_TRY(reduce_kinds(side, {1, 4}));
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                const int64_t cw = (int64_t)tab_count(s, side, 1), cb = (int64_t)tab_count(s, side, 4);
+                if (cw) adagrad_rescale_kernel<<<grid_for(cw), 256, 0, st>>>(s->tab[side][0].p, s->snap[side][1].p, s->scratch[0].p, s->tab[side][1].p, cw);
+                if (cb) adagrad_rescale_kernel<<<grid_for(cb), 256, 0, st>>>(s->tab[side][3].p, s->snap[side][4].p, s->scratch[1].p, s->tab[side][4].p, cb);
+            }
+            LFM_TRY(reduce_kinds(side, {0, 3}));
+        } else {
+            LFM_TRY(reduce_kinds(side, {0, 1, 2, 3, 4, 5}));
+            if (mode == LFM_MERGE_MEAN) wscale = 1.0f / (float)nranks_total;
+        }
+        // 2. deltas -> values; the merged state starts the next interval
+        for (int i = 0; i < k; ++i)
+            for (int kind = 0; kind < 6; ++kind) {
+                if (!kind_used(s0, kind)) continue;
+                int64_t cnt = (int64_t)tab_count(s0, side, kind);
+                if (!cnt) continue;
+                const bool is_weight = kind == 0 || kind == 3;
+                const float sc = (is_weight || s0->adadelta) ? wscale : 1.0f;
+                finish_merge_kernel<<<grid_for(cnt), 256, 0, st>>>(ss[i]->tab[side][kind].p, ss[i]->snap[side][kind].p, sc, cnt);
+            }
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
     return LFM_OK;
 }
 
@@ -591,22 +705,40 @@ extern "C" int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID
     NCCL_TRY(r->CommInitRank(&s->comm, nranks, u, rank));
     s->rank = rank;
     s->nranks = nranks;
-    LFM_TRY(snapshot_side(s, 1));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    s->user_snap_valid = true;
-    return LFM_OK;
+    // replicated = the item side, and the user side when user features are shared between users
+    return lfm_session_merge_begin(s, s->usf.identity ? 1 : 3);
 }
 
-extern "C" int lfm_session_comm_merge_users(lfm_session *s)
+extern "C" int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode)
+{
+    if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    if (!s->comm || sides == 0) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    lfm_session *g[1] = {s};
+    return merge_group(g, 1, s->nranks, sides, mode);
+}
+
+extern "C" int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode)
+{
+    if (!sessions || k < 1 || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    for (int i = 0; i < k; ++i)
+        if (!sessions[i] || sessions[i]->device != sessions[0]->device || sessions[i]->comm)
+            return fail(LFM_EINVAL, "local merge needs sessions of one device without a communicator");
+    HIP_TRY(hipSetDevice(sessions[0]->device));
+    return merge_group(sessions, k, k, sides, mode);
+}
+
+extern "C" int lfm_session_comm_any(lfm_session *s, int32_t flag)
 {
     if (!s) return fail(LFM_EINVAL, "null session");
-    if (!s->comm) return LFM_OK;
+    if (!s->comm) return flag ? 1 : 0;
     HIP_TRY(hipSetDevice(s->device));
-    if (!s->user_snap_valid) return fail(LFM_EINVAL, "no user-side snapshot");
-    LFM_TRY(merge_side(s, 1));
-    LFM_TRY(snapshot_side(s, 1));
+    int v = flag ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(s->flag.p, &v, sizeof(int), hipMemcpyHostToDevice, s->stream));
+    NCCL_TRY(rccl()->AllReduce(s->flag.p, s->flag.p, 1, ncclInt32, ncclMax, s->comm, s->stream));
+    HIP_TRY(hipMemcpyAsync(&v, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return LFM_OK;
+    return v ? 1 : 0;
 }
 
 extern "C" int lfm_session_comm_barrier(lfm_session *s)
@@ -643,6 +775,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (needs_rng && (!seeds || n_seeds < 1)) return fail(LFM_EINVAL, "seeds required");
     if (loss != LFM_LOSS_WARP_KOS && s->n && (!s->item_ids.p || !s->Y.p))
         return fail(LFM_EINVAL, "item_ids / Y not uploaded");
+    if (loss != LFM_LOSS_WARP_KOS && s->n && !s->weight_aliases_Y && !s->weight.p)
+        return fail(LFM_EINVAL, "sample_weight not uploaded");
     if (needs_rng && !s->pos.indptr.p && s->pos.rows == 0 && s->n)
         return fail(LFM_EINVAL, "positives lookup not uploaded");
     if (loss == LFM_LOSS_WARP_KOS && (k < 1 || n_positives < 1)) return fail(LFM_EINVAL, "k and n must be positive");
@@ -671,7 +805,6 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // kernel-side encoding: 0 atomic deltas, 1 plain stores, 2 no writes
     a.update_mode = serial ? 1 : (opts->update_mode == 1 ? 1 : (opts->update_mode == 2 ? 2 : 0));
     a.debug = opts->debug;
-    const int occupancy = opts->occupancy;
     a.k = k;
     a.n_pos = n_positives;
     a.counters = s->counters.p;
@@ -722,8 +855,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // (feature rows) / (avg nnz per row) interactions in flight (measured at the ML-100k shape
     // with 40 tags x 4 per item; identity sides are not bounded).
     int64_t shared_cap = INT64_MAX / 4;
+    if (opts->shared_cap > 0) shared_cap = opts->shared_cap;
     for (const DevCsr *f : {&s->itf, &s->usf}) {
-        if (f->identity || f->rows <= 0 || f->nnz <= 0) continue;
+        if (opts->shared_cap != 0 || f->identity || f->rows <= 0 || f->nnz <= 0) continue;
         const double avg = (double)f->nnz / (double)f->rows;
         shared_cap = std::min<int64_t>(shared_cap, std::max<int64_t>(64, (int64_t)((double)f->cols / std::max(1.0, avg))));
     }
@@ -770,8 +904,6 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (a.sampled_log) HIP_TRY(hipMemsetAsync(a.sampled_log, 0, (size_t)s->n * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, 12 * sizeof(unsigned long long), s->stream));
 
-    if (s->comm) LFM_TRY(snapshot_side(s, 0));
-
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -794,10 +926,13 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         if (snap_biases)
             for (int side = 0; side < 2; ++side) LFM_TRY(s->bias_snap[side].alloc(tab_count(s, side, 3)));
         FitArgs base = a;
-        int64_t begin = 0;
+        // [pos_begin, pos_end): one segment of the epoch (multi-GPU driver), default the whole epoch
+        const int64_t seg_begin = std::max<int64_t>(0, std::min<int64_t>(opts->pos_begin, s->n));
+        const int64_t seg_end = opts->pos_end > 0 ? std::max(seg_begin, std::min<int64_t>(opts->pos_end, s->n)) : s->n;
+        int64_t begin = seg_begin;
         int ng_used = 0;
-        while (begin < s->n) {
-            const int64_t allowed = allowed_in_flight(begin);
+        while (begin < seg_end) {
+            const int64_t allowed = allowed_in_flight(begin - seg_begin);
             // pick the kernel variant for this launch
             int ng = 0;
             if (use_tile) {
@@ -824,12 +959,13 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, allowed / (WAVES_PER_BLOCK * per_wave)));
             if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
             const int64_t flight = (int64_t)max_grid * WAVES_PER_BLOCK * per_wave;
-            int64_t len = std::min<int64_t>(slice, s->n - begin);
+            int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
             const int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            int grid_used = grid;
             if (ng) {
                 // Scoring reads twelve 4-byte biases per interaction.  With uncached tables each
                 // is a fabric request; a cached snapshot taken at the launch boundary (the tables
@@ -847,15 +983,17 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         a.b_read[side] = s->bias_snap[side].p;
                     }
                 }
-                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2));
+                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2,
+                                             &grid_used));
             }
-            else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, occupancy, s->cus));
+            else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
                 HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904
             }
             begin += len;
-            in_flight = (int)std::min<int64_t>(flight, INT32_MAX);  // of the last (largest) launch
+            // of the last (largest) launch, after the launcher's residency clamp
+            in_flight = (int)std::min<int64_t>((int64_t)grid_used * WAVES_PER_BLOCK * per_wave, INT32_MAX);
             ng_used = ng;
             ++n_launches;
         }
@@ -863,7 +1001,6 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     }
     if (reg) HIP_TRY(launch_regularize(a.m, 1, s->stream));  // PYX:910-912 (no-op when scales are 1)
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    if (s->comm && s->nranks > 1) LFM_TRY(merge_side(s, 0));
     HIP_TRY(hipStreamSynchronize(s->stream));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -873,6 +1010,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
     opts->tile_ng = tile_ng_used;
+    opts->kernel_used = tile_ng_used ? 1 : 0;
     opts->in_flight = in_flight;
     opts->launches = n_launches;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
@@ -910,6 +1048,81 @@ extern "C" int lfm_session_sync_to_host(lfm_session *s, lfm_model *model)
     model->item_scale = sc[0];
     model->user_scale = sc[1];
     return LFM_OK;
+}
+
+extern "C" int lfm_session_load_model(lfm_session *s, const lfm_model *model)
+{
+    if (!s || !model) return fail(LFM_EINVAL, "null argument");
+    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
+        return fail(LFM_EINVAL, "model shape differs from the session's");
+    LFM_TRY(validate_model(model));
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int side = 0; side < 2; ++side)
+        for (int k = 0; k < 6; ++k)
+            if (kind_used(s, k)) LFM_TRY(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
+    double sc[2] = {model->item_scale, model->user_scale};
+    LFM_TRY(s->scales.upload(sc, 2));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_build_positives(lfm_session *s, int32_t n_users, int32_t n_items)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (n_users < 0 || n_items <= 0) return fail(LFM_EINVAL, "bad interaction matrix shape");
+    if (s->n && (!s->user_ids.p || !s->item_ids.p)) return fail(LFM_EINVAL, "user_ids / item_ids not uploaded");
+    if ((double)n_users * (double)n_items >= 1.8e19) return fail(LFM_EUNSUPPORTED, "shape beyond 64-bit keys");
+    HIP_TRY(hipSetDevice(s->device));
+    s->pos.clear();
+    LFM_TRY(s->pos.indptr.alloc((size_t)n_users + 1));
+    DBuf<int32_t> idx;
+    LFM_TRY(idx.alloc((size_t)std::max<int64_t>(s->n, 1)));
+    int64_t nnz = 0;
+    hipError_t e = build_positives_csr(s->user_ids.p, s->item_ids.p, s->n, n_users, n_items, idx.p,
+                                       s->pos.indptr.p, &nnz, s->stream);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? LFM_ENOMEM : LFM_ENODEV, std::string("build_positives_csr: ") + hipGetErrorString(e));
+    // keep the (slightly larger) buffer: duplicates are rare, a trimmed copy would cost more than it frees
+    std::swap(s->pos.indices.p, idx.p);
+    std::swap(s->pos.indices.n, idx.n);
+    s->pos.rows = n_users;
+    s->pos.cols = n_items;
+    s->pos.nnz = nnz;
+    s->pos.identity = false;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_download_positives(lfm_session *s, int32_t *indptr, int32_t *indices, int64_t *nnz)
+{
+    if (!s || !nnz) return fail(LFM_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    *nnz = s->pos.nnz;
+    if (indptr && s->pos.indptr.p)
+        HIP_TRY(hipMemcpy(indptr, s->pos.indptr.p, ((size_t)s->pos.rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (indices && s->pos.indices.p && s->pos.nnz)
+        HIP_TRY(hipMemcpy(indices, s->pos.indices.p, (size_t)s->pos.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_representations(lfm_session *s, int32_t side, const lfm_csr *features, float *biases,
+                                           float *embeddings)
+{
+    if (!s || !biases || !embeddings) return fail(LFM_EINVAL, "null argument");
+    if (side != 0 && side != 1) return fail(LFM_EINVAL, "side must be 0 (item) or 1 (user)");
+    LFM_TRY(validate_csr(features, "features"));
+    if (features->cols > s->n_feat[side]) return fail(LFM_EINVAL, "feature matrix has more columns than there are embeddings");
+    if (features->rows == 0) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DevCsr f;
+    LFM_TRY(f.upload(features, true, true));
+    DBuf<float> demb, dbias;
+    LFM_TRY(demb.alloc((size_t)features->rows * s->d));
+    LFM_TRY(dbias.alloc((size_t)features->rows));
+    HIP_TRY(launch_rep_rows(f.view(), s->tab[side][0].p, s->tab[side][3].p, s->d, s->d, demb.p, s->stream, 0, dbias.p));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    LFM_TRY(demb.download(embeddings));
+    return dbias.download(biases);
 }
 
 // ---------------------------------------------------------------- predict ---

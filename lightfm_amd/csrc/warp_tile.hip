@@ -45,17 +45,17 @@ size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride
     return (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float);
 }
 
-hipError_t launch_tile_lpr16(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
-hipError_t launch_tile_lpr32(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
-hipError_t launch_tile_lpr64(const FitArgs &, int, int, size_t, hipStream_t, int, bool);
+hipError_t launch_tile_lpr16(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
+hipError_t launch_tile_lpr32(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
+hipError_t launch_tile_lpr64(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
 
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
-                                int cus, bool timed)
+                                int cus, bool timed, int *grid_used)
 {
     switch (ng) {
-    case 4: return launch_tile_lpr16(a, vec, grid, smem, st, cus, timed);
-    case 2: return launch_tile_lpr32(a, vec, grid, smem, st, cus, timed);
-    case 1: return launch_tile_lpr64(a, vec, grid, smem, st, cus, timed);
+    case 4: return launch_tile_lpr16(a, vec, grid, smem, st, cus, timed, grid_used);
+    case 2: return launch_tile_lpr32(a, vec, grid, smem, st, cus, timed, grid_used);
+    case 1: return launch_tile_lpr64(a, vec, grid, smem, st, cus, timed, grid_used);
     default: return hipErrorInvalidValue;
     }
 }

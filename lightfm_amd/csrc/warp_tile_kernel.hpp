@@ -548,16 +548,23 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                         for (int q = 0; q < NC; ++q) {
                             const int c = lane + WAVE * q;
                             if (c < d) {
-                                publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
-                                publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
-                                publish(WiW + bn + c, nWr[q][1], oWr[q][1], um);
-                                publish(Gi + bn + c, nGr[q][1], gN[gg][q], um);
-                                publish(WuW + bu_ + c, nWr[q][2], oWr[q][2], um);
-                                publish(Gu + bu_ + c, nGr[q][2], gU[gg][q], um);
-                                if (ADADELTA) {
-                                    publish(Mi + bp + c, nMr[q][0], mP[gg][q], um);
-                                    publish(Mi + bn + c, nMr[q][1], mN[gg][q], um);
-                                    publish(Mu + bu_ + c, nMr[q][2], mU[gg][q], um);
+                                if constexpr (ADADELTA) {
+                                    // moving-average accumulators: compare-and-swap (device.hpp: publish_adadelta)
+                                    const double u = (double)oWr[q][2];
+                                    const double df = (double)__fsub_rn(oWr[q][1], oWr[q][0]);
+                                    publish_cell(WiW + bp + c, Gi + bp + c, Mi + bp + c, oWr[q][0], gP[gg][q], mP[gg][q],
+                                                 nWr[q][0], nGr[q][0], nMr[q][0], 1.0, -loss * u, h, 0.0, um);
+                                    publish_cell(WiW + bn + c, Gi + bn + c, Mi + bn + c, oWr[q][1], gN[gg][q], mN[gg][q],
+                                                 nWr[q][1], nGr[q][1], nMr[q][1], 1.0, loss * u, h, 0.0, um);
+                                    publish_cell(WuW + bu_ + c, Gu + bu_ + c, Mu + bu_ + c, oWr[q][2], gU[gg][q], mU[gg][q],
+                                                 nWr[q][2], nGr[q][2], nMr[q][2], 1.0, loss * df, h, 0.0, um);
+                                } else {
+                                    publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
+                                    publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
+                                    publish(WiW + bn + c, nWr[q][1], oWr[q][1], um);
+                                    publish(Gi + bn + c, nGr[q][1], gN[gg][q], um);
+                                    publish(WuW + bu_ + c, nWr[q][2], oWr[q][2], um);
+                                    publish(Gu + bu_ + c, nGr[q][2], gU[gg][q], um);
                                 }
                             }
                         }
@@ -566,9 +573,8 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                             float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
                             float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
                             float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
-                            publish(bWp + brow, bnW, obW[gg], um);
-                            publish(bGp + brow, bnG, obG[gg], um);
-                            if (ADADELTA) publish(bMp + brow, bnM, ooM, um);
+                            publish_cell(bWp + brow, bGp + brow, bMp + brow, obW[gg], obG[gg], ooM, bnW, bnG, bnM, 1.0,
+                                         lane == 0 ? -loss : loss, h, 0.0, um);
                         }
                     }
                 }
@@ -615,7 +621,8 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
 
 // Launch helper shared by the per-LPR translation units (warp_tile_lpr*.hip).
 template <int LPR, int VEC>
-hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus, bool timed)
+hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus, bool timed,
+                               int *grid_used)
 {
     void (*kernel)(FitArgs);
     if (a.m.adadelta) kernel = fit_warp_tile_kernel<LPR, VEC, false, true>;
@@ -627,6 +634,7 @@ hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStrea
             per_cu > 0)
             grid = std::min(grid, per_cu * cus);
     }
+    if (grid_used) *grid_used = grid;
     kernel<<<grid, 256, smem, st>>>(a);
     return hipGetLastError();
 }

@@ -5,10 +5,10 @@
 namespace lfm {
 
 hipError_t launch_tile_lpr16(const FitArgs &a, int vec, int grid, size_t smem, hipStream_t st, int cus,
-                             bool timed)
+                             bool timed, int *grid_used)
 {
     switch (vec) {
-    case 4: return launch_tile_variant<16, 4>(a, grid, smem, st, cus, timed);
+    case 4: return launch_tile_variant<16, 4>(a, grid, smem, st, cus, timed, grid_used);
     default: return hipErrorInvalidValue;
     }
 }

@@ -5,11 +5,11 @@
 namespace lfm {
 
 hipError_t launch_tile_lpr32(const FitArgs &a, int vec, int grid, size_t smem, hipStream_t st, int cus,
-                             bool timed)
+                             bool timed, int *grid_used)
 {
     switch (vec) {
-    case 2: return launch_tile_variant<32, 2>(a, grid, smem, st, cus, timed);
-    case 4: return launch_tile_variant<32, 4>(a, grid, smem, st, cus, timed);
+    case 2: return launch_tile_variant<32, 2>(a, grid, smem, st, cus, timed, grid_used);
+    case 4: return launch_tile_variant<32, 4>(a, grid, smem, st, cus, timed, grid_used);
     default: return hipErrorInvalidValue;
     }
 }

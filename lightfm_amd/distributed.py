@@ -1,14 +1,22 @@
 """Multi-GPU host logic (no counterpart in the reference).
 
 One process per GPU.  The interaction matrix is sharded by USER into contiguous row ranges
-balanced by interaction count; every rank trains its shard on its own GPU with the replicated
-item tables and its own slice of the user tables; after every epoch the item tables are merged
-on device by an RCCL all-reduce of their deltas (csrc/session.hip: merge_side), and once at the
-end the user tables are merged the same way (rows are disjoint across ranks with identity user
-features, so that merge is an exact union).
+balanced by interaction count.  With identity user features a rank holds ONLY its own users'
+rows of the user tables (ids rebased to the range; never communicated); the item tables are
+replicated.  An epoch runs as SEGMENTS of the rank's shuffled shard with a merge of the
+replicated tables after every segment (csrc/session.hip: merge_group, one grouped RCCL
+all-reduce of the tables' deltas over xGMI):
+
+* every rank derives the same segment list from global numbers only (`merge_schedule`), so all
+  ranks call the collective the same number of times;
+* the interval between merges GROWS with the training history -- like the number of
+  interactions in flight inside one GPU (DESIGN.md "Hogwild at GPU width"), replicas that
+  have not exchanged their updates are harmless once the model has left its initial state and
+  ruinous before -- from `merge_min` interactions up to `merge_max` (all ranks together).
 
 `torch.distributed` (any backend, gloo is enough) is used ONLY for the rendezvous: broadcasting
-the RCCL unique id and the initial item table.  The data path never goes through it.
+the RCCL unique id and the initial tables, and gathering the user rows at the end.  The data
+path never goes through it.
 """
 import ctypes as C
 
@@ -17,7 +25,8 @@ import scipy.sparse as sp
 
 from . import _native as N
 
-__all__ = ["plan_row_shards", "local_shard", "rank_seed", "merge_deltas", "DistributedFit"]
+__all__ = ["plan_row_shards", "local_shard", "rank_seed", "merge_deltas", "merge_schedule",
+           "MergePolicy", "DistributedFit"]
 
 
 def plan_row_shards(row_counts, world):
@@ -36,13 +45,18 @@ def plan_row_shards(row_counts, world):
     return np.asarray(bounds, dtype=np.int64)
 
 
-def local_shard(interactions, rank, world, bounds=None):
-    """The rank's interactions as a COO of the FULL shape (ids stay global)."""
+def local_shard(interactions, rank, world, bounds=None, rebase=False):
+    """The rank's interactions as a COO.  rebase=False: full shape, global user ids.
+    rebase=True: shape (users of the rank, n_items), user ids relative to bounds[rank]."""
     coo = interactions.tocoo()
     if bounds is None:
         bounds = plan_row_shards(np.bincount(coo.row, minlength=coo.shape[0]), world)
     keep = (coo.row >= bounds[rank]) & (coo.row < bounds[rank + 1])
-    return sp.coo_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=coo.shape,
+    rows, shape = coo.row[keep], coo.shape
+    if rebase:
+        rows = (rows - bounds[rank]).astype(coo.row.dtype)
+        shape = (int(bounds[rank + 1] - bounds[rank]), coo.shape[1])
+    return sp.coo_matrix((coo.data[keep], (rows, coo.col[keep])), shape=shape,
                          dtype=coo.dtype), bounds
 
 
@@ -53,39 +67,102 @@ def rank_seed(seed, rank):
 
 
 def merge_deltas(start, local, all_reduce_sum):
-    """X := X_start + sum over ranks (X_rank - X_start): the merge csrc/session.hip performs on
-    device with RCCL, restated in numpy (tests; `all_reduce_sum` sums an array over ranks)."""
+    """X := X_start + sum over ranks (X_rank - X_start): the LFM_MERGE_SUM arithmetic of
+    csrc/session.hip restated in numpy (tests; `all_reduce_sum` sums an array over ranks)."""
     delta = (local - start).astype(np.float32)
     return (start + all_reduce_sum(delta)).astype(np.float32)
 
 
-class DistributedFit(object):
-    """Drives `LightFM`-compatible epochs of one rank.  Usage (inside torch.distributed.run):
+class MergePolicy(object):
+    """When and how the replicated tables are merged.
 
-        fit = DistributedFit(model, interactions, rank, world, device=local_rank, dist=dist)
-        fit.run(epochs)          # model's weights are complete on every rank afterwards
+    merge_k    the interval between merges is (interactions all ranks have trained on so far)
+               / merge_k, clamped to [merge_min, merge_max]
+    merge_min  smallest interval (interactions of ALL ranks together)
+    merge_max  largest interval; 0 = world * 2**20 (one full-size launch per rank)
+    mode       "sum" | "mean" | "adagrad" (include/lfm_hip.h: LFM_MERGE_*)
     """
 
-    def __init__(self, model, interactions, rank, world, device=0, dist=None):
-        from ._lightfm_fast import CSRMatrix
-        from .lightfm import _Session
+    def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad"):
+        self.merge_k, self.merge_min, self.merge_max, self.mode = merge_k, merge_min, merge_max, mode
+
+    def mode_id(self):
+        return N.MERGE_MODES[self.mode]
+
+
+def merge_schedule(global_history, global_n, world, policy=None):
+    """Segment boundaries of one epoch as FRACTIONS of the epoch, 0 = f[0] < ... < f[-1] = 1,
+    computed from global numbers only (identical on every rank).  A rank runs its shuffled
+    positions [round(f[j] * n_local), round(f[j+1] * n_local)) and merges after each."""
+    policy = policy or MergePolicy()
+    if global_n <= 0:
+        return np.array([0.0, 1.0])
+    cap = policy.merge_max if policy.merge_max > 0 else world * (1 << 20)
+    lo = max(1, min(policy.merge_min, cap))
+    fr, g = [0.0], 0
+    while g < global_n:
+        seg = int(min(cap, max(lo, (global_history + g) // max(1, policy.merge_k))))
+        g = min(global_n, g + seg)
+        fr.append(g / float(global_n))
+    fr[-1] = 1.0
+    return np.asarray(fr)
+
+
+def segment_positions(fractions, n_local):
+    """The rank's positions for the schedule's fractions (monotone, ends at n_local)."""
+    pos = np.rint(np.asarray(fractions) * n_local).astype(np.int64)
+    pos[0], pos[-1] = 0, n_local
+    return np.maximum.accumulate(pos)
+
+
+class DistributedFit(object):
+    """Drives the epochs of one rank.  Usage (inside torch.distributed.run):
+
+        fit = DistributedFit(model, interactions, rank, world, device=local_rank, dist=dist)
+        fit.run(epochs)
+        fit.gather_users()       # optional: every rank's model then holds all user rows
+
+    `model` is a lightfm_amd.LightFM with identity user and item features (the BASELINE
+    multi-GPU configurations).  Its user arrays keep the FULL shape on the host; the rank's
+    session only sees (and allocates on the GPU) the slice of its own users.
+    """
+
+    def __init__(self, model, interactions, rank, world, device=0, dist=None, policy=None,
+                 host_shuffle=False):
+        from ._lightfm_fast import CSRMatrix, FastLightFM
+        from .lightfm import _Session, _WEIGHTS
         self.model, self.rank, self.world, self.dist = model, rank, world, dist
-        shard, self.bounds = local_shard(interactions, rank, world)
+        self.policy = policy or MergePolicy()
+        self.host_shuffle = host_shuffle
+        coo = interactions.tocoo()
+        coo = sp.coo_matrix((np.ascontiguousarray(coo.data, dtype=np.float32),
+                             (np.ascontiguousarray(coo.row, dtype=np.int32),
+                              np.ascontiguousarray(coo.col, dtype=np.int32))), shape=coo.shape)
+        shard, self.bounds = local_shard(coo, rank, world, rebase=True)
         self.shard = shard
-        n_users, n_items = shard.shape
+        self.global_n = int(coo.nnz)
+        n_users, n_items = coo.shape
         if model.item_embeddings is None:
             model._initialize(model.no_components, n_items, n_users)
         if world > 1:  # replicas start from rank 0's tables
             import torch
             for name in ("item_embeddings", "user_embeddings"):
                 dist.broadcast(torch.from_numpy(getattr(model, name)), src=0)
-        user_f = sp.identity(n_users, dtype=np.float32, format="csr")
+        b0, b1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        self.user_range = (b0, b1)
+        arrays = []
+        for name in _WEIGHTS:  # views: device results land in the model's own arrays
+            a = getattr(model, name)
+            arrays.append(a[b0:b1] if name.startswith("user") else a)
+        self.struct = FastLightFM(*arrays, model.no_components,
+                                  int(model.learning_schedule == "adadelta"), model.learning_rate,
+                                  model.rho, model.epsilon, model.max_sampled)
+        user_f = sp.identity(b1 - b0, dtype=np.float32, format="csr")
         item_f = sp.identity(n_items, dtype=np.float32, format="csr")
-        self.positives = model._get_positives_lookup_matrix(shard)
-        self.struct = model._get_lightfm_data()
         self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(user_f), device=device)
-        self.session.set_interactions(CSRMatrix(self.positives), np.ascontiguousarray(shard.row),
+        self.session.set_interactions(None, np.ascontiguousarray(shard.row),
                                       np.ascontiguousarray(shard.col), shard.data, shard.data)
+        self.session.build_positives(b1 - b0, n_items)
         if world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
@@ -96,27 +173,63 @@ class DistributedFit(object):
             self.session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()),
                                                           N.UNIQUE_ID_BYTES), rank, world)
 
-    def run(self, epochs, num_threads=1):
+    def run_epoch(self, seeds, slot=0):
+        """One epoch of this rank: segments + merges.  Returns the per-segment lfm_opts."""
         from ._lightfm_fast import make_opts
         m = self.model
         n = self.shard.nnz
+        history = int(getattr(m, "_trained_interactions", 0))  # interactions of ALL ranks so far
+        pos = segment_positions(merge_schedule(history, self.global_n, self.world, self.policy), n)
         stats = []
-        for epoch in range(epochs):
-            shuffle = np.arange(n, dtype=np.int32)
-            m.random_state.shuffle(shuffle)
+        for j in range(len(pos) - 1):
+            opts, _ = make_opts()
+            # in-flight ramp: this rank's share of what all ranks have trained on
+            opts.history = (history + int(round(self.global_n * pos[j] / max(1, n)))) // self.world
+            opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
+            if pos[j + 1] > pos[j]:
+                self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts, slot=slot)
+            self.session.comm_merge(1, self.policy.mode_id())
+            stats.append(opts)
+        m._trained_interactions = history + self.global_n
+        return stats
+
+    def run(self, epochs, num_threads=1):
+        m = self.model
+        n = self.shard.nnz
+        stats = []
+        for _ in range(epochs):
+            if self.host_shuffle:
+                shuffle = np.arange(n, dtype=np.int32)
+                m.random_state.shuffle(shuffle)
+                self.session.upload_shuffle(shuffle)
+            else:
+                keys = m.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+                self.session.device_shuffle(int(keys[0]), int(keys[1]))
             seeds = np.ascontiguousarray(m.random_state.randint(
                 0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
-            self.session.upload_shuffle(shuffle)
-            opts, _ = make_opts()
-            opts.history = int(getattr(m, "_trained_interactions", 0))
-            m._trained_interactions = opts.history + n
-            self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts)
-            stats.append(opts)
-            if not self.session.check_finite():
-                raise ValueError("Not all estimated parameters are finite")
-        self.session.comm_merge_users()
+            stats.extend(self.run_epoch(seeds))
+            # all ranks raise together (a rank that stopped alone would leave the others blocked in
+            # the next collective)
+            if self.session.comm_any(not self.session.check_finite()):
+                self.session.sync_to_host(self.struct)
+                raise ValueError("Not all estimated parameters are finite, your model may have diverged.")
         self.session.sync_to_host(self.struct)
         return stats
+
+    def gather_users(self):
+        """Every rank receives the other ranks' user rows (host plane, once, after training)."""
+        if self.world <= 1:
+            return
+        import torch
+        from .lightfm import _WEIGHTS
+        for name in _WEIGHTS:
+            if not name.startswith("user"):
+                continue
+            a = getattr(self.model, name)
+            for r in range(self.world):
+                b0, b1 = int(self.bounds[r]), int(self.bounds[r + 1])
+                if b1 > b0:
+                    self.dist.broadcast(torch.from_numpy(a[b0:b1]), src=r)
 
     def close(self):
         self.session.close()

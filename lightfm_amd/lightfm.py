@@ -4,16 +4,24 @@ below) whose epochs run on the MI355X.
 Everything a caller can observe is kept: constructor arguments and assertions
 (LFM:189-241), the 12 weight attributes and their initialisation order
 (LFM:245-312), input coercion and the exceptions raised for bad input
-(LFM:314-420, 617-652, 819-849), the consumption of `random_state` (one
-`shuffle` then one `randint(size=num_threads)` per epoch, LFM:689-690 +
-_lightfm_fast.pyx.template:812-814), pickling, `fit_partial` resuming, sklearn
+(LFM:314-420, 617-652, 819-849), pickling, `fit_partial` resuming, sklearn
 `get_params/set_params`.
+
+`random_state`: when the caller hands in a `numpy.random.RandomState` INSTANCE (a stream it
+may share with other code), every epoch consumes it exactly like the reference -- one
+`shuffle(arange(n))` then one `randint(size=num_threads)` (LFM:689-690 +
+_lightfm_fast.pyx.template:812-814) -- so the stream is in the same state after `fit`.  When
+the model owns its stream (seed or None) the epoch's visiting order is instead built on the
+device from one `randint(size=624)` block (`options.device_shuffle`, a keyed permutation:
+lfm_session_device_shuffle), because numpy's sequential Fisher-Yates over 20 M entries costs
+ten device epochs; `options.device_shuffle = False` restores the reference's draws there too.
 
 What changes is below the boundary: instead of handing host arrays to the Cython
 extension once per epoch, `fit_partial` opens ONE device-resident session
-(include/lfm_hip.h: lfm_session_*), uploads weights / feature CSRs / the COO once,
-runs every epoch on the GPU (only the shuffled index list and the seeds travel
-per epoch), checks finiteness on device and copies the weights back at the end.
+(include/lfm_hip.h: lfm_session_*), uploads weights / feature CSRs / the COO once, builds the
+positives lookup on the device (lfm_session_build_positives instead of LFM:365-372's host
+`tocsr()`), runs every epoch on the GPU (only the keys or the shuffled index list and the seeds
+travel per epoch), checks finiteness on device and copies the weights back at the end.
 """
 import ctypes as C
 
@@ -48,6 +56,14 @@ class _Session(object):
 
     def set_interactions(self, positives, rows, cols, data, weight):
         n = len(rows)
+        # raw pointers go to the library: hold the typed-memoryview contract here
+        rows = N.require(rows, np.int32, 1, "user_ids")
+        if cols is not None:
+            cols = N.require(cols, np.int32, 1, "item_ids")
+        if data is not None:
+            data = N.require(data, np.float32, 1, "Y")
+        if weight is not None:
+            weight = N.require(weight, np.float32, 1, "sample_weight")
         N.check(N.lib().lfm_session_set_interactions(
             self.handle, positives.byref() if positives is not None else None, N.i32p(rows),
             N.i32p(cols), N.f32p(data), N.f32p(weight), C.c_int64(n)))
@@ -79,11 +95,47 @@ class _Session(object):
     def comm_init(self, unique_id, rank, nranks):
         N.check(N.lib().lfm_session_comm_init(self.handle, unique_id, rank, nranks))
 
-    def comm_merge_users(self):
-        N.check(N.lib().lfm_session_comm_merge_users(self.handle))
+    def comm_merge(self, sides=1, mode=0):
+        N.check(N.lib().lfm_session_comm_merge(self.handle, sides, mode))
+
+    def merge_begin(self, sides=1):
+        N.check(N.lib().lfm_session_merge_begin(self.handle, sides))
+
+    @staticmethod
+    def merge_local(sessions, sides=1, mode=0):
+        """K sessions of this process on one device merged like K ranks (no RCCL)."""
+        arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
+        N.check(N.lib().lfm_sessions_merge_local(arr, len(sessions), sides, mode))
+
+    def comm_any(self, flag):
+        return bool(N.check(N.lib().lfm_session_comm_any(self.handle, int(bool(flag)))))
 
     def comm_barrier(self):
         N.check(N.lib().lfm_session_comm_barrier(self.handle))
+
+    def load_model(self, model_struct):
+        N.check(N.lib().lfm_session_load_model(self.handle, model_struct.byref()))
+
+    def build_positives(self, n_users, n_items):
+        N.check(N.lib().lfm_session_build_positives(self.handle, n_users, n_items))
+
+    def download_positives(self, n_users):
+        nnz = C.c_int64()
+        N.check(N.lib().lfm_session_download_positives(self.handle, None, None, C.byref(nnz)))
+        indptr = np.empty(n_users + 1, np.int32)
+        indices = np.empty(nnz.value, np.int32)
+        N.check(N.lib().lfm_session_download_positives(self.handle, N.i32p(indptr), N.i32p(indices),
+                                                       C.byref(nnz)))
+        return indptr, indices
+
+    def representations(self, side, features):
+        """(biases, embeddings) of every row of `features` (CSRMatrix), side 0 item / 1 user."""
+        d = self._keep[0].no_components
+        biases = np.empty(features.rows, np.float32)
+        emb = np.empty((features.rows, d), np.float32)
+        N.check(N.lib().lfm_session_representations(self.handle, side, features.byref(), N.f32p(biases),
+                                                    N.f32p(emb)))
+        return biases, emb
 
     def close(self):
         if self.handle:
@@ -133,6 +185,9 @@ class LightFM(object):
         self.item_alpha = item_alpha
         self.user_alpha = user_alpha
 
+        # a RandomState INSTANCE may be shared with the caller's other code: consume it exactly
+        # like the reference (see the module docstring)
+        self._shared_random_state = isinstance(random_state, np.random.RandomState)
         if random_state is None:
             self.random_state = np.random.RandomState()
         elif isinstance(random_state, np.random.RandomState):
@@ -313,25 +368,36 @@ class LightFM(object):
         if epochs <= 0:
             return
         loss = self.loss
+        needs_lookup = loss in ("warp", "bpr", "warp-kos")
         positives = None
-        if loss in ("warp", "bpr", "warp-kos"):
-            # built before the shuffle indices, as in LFM:682-690
+        if needs_lookup and options.host_positives:
+            # the reference's host-side lookup matrix (LFM:365-372), built before the shuffle
+            # indices as in LFM:682-690
             positives = CSRMatrix(self._get_positives_lookup_matrix(interactions))
         rows = np.ascontiguousarray(interactions.row, dtype=np.int32)
         cols = np.ascontiguousarray(interactions.col, dtype=np.int32)
-        data = interactions.data
+        data = np.ascontiguousarray(interactions.data, dtype=np.float32)
+        if sample_weight is not interactions.data:
+            sample_weight = np.ascontiguousarray(sample_weight, dtype=np.float32)
+        else:
+            sample_weight = data
         n = len(data)
+        device_shuffle = (options.device_shuffle and options.mode == "parallel"
+                          and not getattr(self, "_shared_random_state", False))
 
         model = self._get_lightfm_data()
         session = _Session(model, CSRMatrix(item_features), CSRMatrix(user_features))
         try:
-            if loss == "warp-kos":
+            if loss == "warp-kos" and positives is not None:
                 session.set_interactions(positives, rows, None, None, None)
             else:
                 session.set_interactions(positives, rows, cols, data, sample_weight)
+            if needs_lookup and positives is None:
+                # the same matrix (sorted rows, duplicates merged) built on the device from the COO
+                session.build_positives(interactions.shape[0], interactions.shape[1])
             self._last_epoch_stats = []
             for _ in self._progress(epochs, verbose=verbose):
-                if options.device_shuffle and options.mode == "parallel":
+                if device_shuffle:
                     # two draws key a permutation built on the device (the caller's RandomState
                     # still advances every epoch, tests/test_movielens.py:669-682 of the reference)
                     # (624 draws = one full Mersenne-Twister block, so get_state()[1] changes too)
@@ -438,21 +504,33 @@ class LightFM(object):
 
     # -------------------------------------------------------- representations
 
+    def _representations(self, side, features):
+        """features @ (biases, embeddings) on the device: one wavefront per feature row gathers the
+        embedding rows (csrc/predict_kernels.hip: rep_rows_kernel; float32, CSR order)."""
+        features = sp.csr_matrix(features, dtype=CYTHON_DTYPE)
+        table = self.item_embeddings if side == 0 else self.user_embeddings
+        if features.shape[1] != table.shape[0]:  # what scipy's `features * embeddings` raises
+            raise ValueError("dimension mismatch")
+        empty = sp.csr_matrix((0, 0), dtype=CYTHON_DTYPE)
+        session = _Session(self._get_lightfm_data(), CSRMatrix(empty), CSRMatrix(empty))
+        try:
+            return session.representations(side, CSRMatrix(features))
+        finally:
+            session.close()
+
     def get_item_representations(self, features=None):
         """(biases, embeddings) of items, optionally through a feature matrix (LFM:991-1018)."""
         self._check_initialized()
         if features is None:
             return self.item_biases, self.item_embeddings
-        features = sp.csr_matrix(features, dtype=CYTHON_DTYPE)
-        return features * self.item_biases, features * self.item_embeddings
+        return self._representations(0, features)
 
     def get_user_representations(self, features=None):
         """(biases, embeddings) of users (LFM:1020-1047)."""
         self._check_initialized()
         if features is None:
             return self.user_biases, self.user_embeddings
-        features = sp.csr_matrix(features, dtype=CYTHON_DTYPE)
-        return features * self.user_biases, features * self.user_embeddings
+        return self._representations(1, features)
 
     # ---------------------------------------------------------------- sklearn
 

@@ -9,21 +9,29 @@ max_waves          FIXED cap on interactions in flight, parallel mode; 0 = auto 
                    training history: at most (interactions trained on so far) / ramp_k in flight,
                    up to the whole chip.
 ramp_k             see max_waves; 0 = auto (32), < 0 = no ramp.
+shared_cap         steady-state bound on interactions in flight when feature rows are shared between
+                   items / users (hybrid models); 0 = auto, < 0 = none.
 history            interactions the model was already trained on, for the low-level epoch
                    functions (LightFM.fit_partial keeps count itself).
 update_mode        0 auto (= 3), 1 plain load/store Hogwild, 2 no writes (profiling),
                    3 atomic deltas (global_atomic_add_f32, the default).
 warp_kernel        0 auto (lane-group tile kernel where it applies), 1 force the generic
                    one-interaction-per-wavefront WARP kernel, 2 tile kernel with phase timers.
+feat_kernel        0 auto (the pipelined row-stream kernels for feature CSRs / BPR / k-OS / logistic
+                   where they apply), 1 force the generic one-interaction-per-wavefront kernels.
 debug              bits 0-2 force the tile kernel's interactions per wavefront pass (1, 2, 4).
 log_samples        record (negative, sampled) per shuffled position into last_logs.
 device_shuffle     LightFM.fit_partial, parallel mode: True (default) builds each epoch's shuffle
-                   on the device from two RandomState draws (lfm_session_device_shuffle); False
-                   draws numpy's random_state.shuffle(arange(n)) on the host like the reference
-                   (LFM:689-690) and uploads it.  Serial mode always uses the host shuffle.
+                   on the device from two RandomState draws (lfm_session_device_shuffle) -- unless
+                   the model was constructed with a RandomState INSTANCE, whose stream is always
+                   consumed exactly like the reference; False draws numpy's
+                   random_state.shuffle(arange(n)) on the host like the reference (LFM:689-690)
+                   and uploads it.  Serial mode always uses the host shuffle.
+host_positives     True: the positives lookup is built on the host (interactions.tocsr(), LFM:365-372)
+                   and uploaded; False (default): built on the device from the uploaded COO.
 
 Environment: LIGHTFM_AMD_MODE, _LAUNCHES, _FIRST_BATCH, _MAX_WAVES, _RAMP_K, _UPDATE_MODE,
-_WARP_KERNEL, _DEBUG, _DEVICE_SHUFFLE; LIGHTFM_AMD_TABLE_ALLOC / _TABLE_ALLOC_MASK select the
+_WARP_KERNEL, _FEAT_KERNEL, _DEBUG, _DEVICE_SHUFFLE; LIGHTFM_AMD_TABLE_ALLOC / _TABLE_ALLOC_MASK select the
 allocation flavour of the weight tables (csrc/session.hip).
 """
 import os
@@ -36,12 +44,14 @@ class _Options(object):
         self.first_batch = int(os.environ.get("LIGHTFM_AMD_FIRST_BATCH", "0"))
         self.max_waves = int(os.environ.get("LIGHTFM_AMD_MAX_WAVES", "0"))
         self.update_mode = int(os.environ.get("LIGHTFM_AMD_UPDATE_MODE", "0"))
-        self.occupancy = int(os.environ.get("LIGHTFM_AMD_OCCUPANCY", "0"))
+        self.feat_kernel = int(os.environ.get("LIGHTFM_AMD_FEAT_KERNEL", "0"))
         self.warp_kernel = int(os.environ.get("LIGHTFM_AMD_WARP_KERNEL", "0"))
         self.debug = int(os.environ.get("LIGHTFM_AMD_DEBUG", "0"))
         self.ramp_k = int(os.environ.get("LIGHTFM_AMD_RAMP_K", "0"))
+        self.shared_cap = int(os.environ.get("LIGHTFM_AMD_SHARED_CAP", "0"))
         self.history = 0
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
+        self.host_positives = os.environ.get("LIGHTFM_AMD_HOST_POSITIVES", "0") != "0"
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None

@@ -64,6 +64,63 @@ def make_interactions(n_users, n_items, nnz, seed=42, n_clusters=64, zipf=0.9, a
                          dtype=np.float32)
 
 
+def big_interactions(n_users, n_items, nnz, seed=4, zipf=0.9, sigma=1.0, chunk=8_000_000):
+    """Fast generator for the large synthetic shapes (BASELINE configs C4 / C5): ~nnz unique
+    (user, item) pairs, log-normal user activity, Zipf(zipf) item popularity drawn by inverse CDF
+    (continuous density ~ (rank + 1)^-zipf, ranks scattered over the id space by a multiplicative
+    permutation), no latent structure.  Users come out sorted (a COO in CSR order); duplicates
+    within a user are removed chunk by chunk so the host never sorts the whole list at once."""
+    rng = np.random.RandomState(seed)
+    act = rng.lognormal(mean=0.0, sigma=sigma, size=n_users)
+    counts = np.maximum(1, np.round(act / act.sum() * nnz * 1.03)).astype(np.int64)
+    counts = np.minimum(counts, max(1, n_items // 4))
+    a = 1.0 - zipf
+    top = (n_items + 1.0) ** a - 1.0
+    mult = 2654435761 % n_items
+    while np.gcd(mult, n_items) != 1:
+        mult += 1
+    rows, cols = [], []
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    u0 = 0
+    while u0 < n_users:
+        u1 = int(np.searchsorted(bounds, bounds[u0] + chunk, side="right"))
+        u1 = min(max(u1 - 1, u0 + 1), n_users)
+        c = counts[u0:u1]
+        users = np.repeat(np.arange(u0, u1, dtype=np.int64), c)
+        rank = np.floor((rng.rand(len(users)) * top + 1.0) ** (1.0 / a) - 1.0).astype(np.int64)
+        np.clip(rank, 0, n_items - 1, out=rank)
+        items = (rank * mult) % n_items
+        key = np.unique(users * n_items + items)
+        rows.append((key // n_items).astype(np.int32))
+        cols.append((key % n_items).astype(np.int32))
+        u0 = u1
+    u = np.concatenate(rows)
+    i = np.concatenate(cols)
+    return sp.coo_matrix((np.ones(len(u), np.float32), (u, i)), shape=(n_users, n_items), dtype=np.float32)
+
+
+def hashed_item_features(n_items, n_cols=1_000_000, mean_nnz=8, seed=5):
+    """Item feature CSR of config C5: one row per item over `n_cols` feature embeddings,
+    max(1, Poisson(mean_nnz)) random columns per row, values 1/nnz (no identity block)."""
+    rng = np.random.RandomState(seed)
+    counts = np.maximum(1, rng.poisson(mean_nnz, size=n_items)).astype(np.int64)
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    indices = rng.randint(0, n_cols, size=int(indptr[-1])).astype(np.int32)
+    data = np.repeat((1.0 / counts).astype(np.float32), counts)
+    return sp.csr_matrix((data, indices, indptr), shape=(n_items, n_cols), dtype=np.float32)
+
+
+def split_off_test(coo, n_train, seed=0):
+    """(train with exactly n_train interactions, test = the rest), disjoint by construction."""
+    rng = np.random.RandomState(seed)
+    perm = rng.permutation(coo.nnz)
+    tr, te = np.sort(perm[:n_train]), np.sort(perm[n_train:])
+
+    def sub(idx):
+        return sp.coo_matrix((coo.data[idx], (coo.row[idx], coo.col[idx])), shape=coo.shape, dtype=np.float32)
+    return sub(tr), sub(te)
+
+
 def named(name, seed=42, scale=1.0):
     """Synthetic data with the shape of a named dataset; scale < 1 keeps the tables
     full-size and sub-samples the interactions."""

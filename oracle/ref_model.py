@@ -5,6 +5,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/lfm_oracle.c).  Used by tests/, tools/ and
 bench.py's cpu_baseline leg to time / evaluate the reference CPU path on the same
 inputs, with the same host-side RNG consumption as lightfm/lightfm.py:668-759.
 """
+import time
+
 import numpy as np
 
 from lightfm_amd.lightfm import LightFM
@@ -32,6 +34,7 @@ class RefLightFM(LightFM):
                 self.no_components, int(self.learning_schedule == "adadelta"), self.learning_rate,
                 self.rho, self.epsilon, self.max_sampled)
             args = (C(item_features), C(user_features))
+            t_native = time.perf_counter()
             if loss == "warp":
                 ref.fit_warp(*args, positives, interactions.row, interactions.col,
                              interactions.data, sample_weight, shuffle, fl, self.learning_rate,
@@ -48,4 +51,6 @@ class RefLightFM(LightFM):
                 ref.fit_logistic(*args, interactions.row, interactions.col, interactions.data,
                                  sample_weight, shuffle, fl, self.learning_rate, self.item_alpha,
                                  self.user_alpha, num_threads)
+            if hasattr(self, "native_seconds"):  # bench.py: duration of the native epoch call alone
+                self.native_seconds.append(time.perf_counter() - t_native)
             self._check_finite()

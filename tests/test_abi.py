@@ -29,11 +29,28 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(lib, name), name
 
 
-def test_struct_layouts_match_header(native):
+def test_struct_layouts_match_header(native, tmp_path):
+    """The ctypes mirror has the layout gcc gives include/lfm_hip.h (sizes and every field offset)."""
     import ctypes as C
-    assert C.sizeof(native.LfmCSR) == 40
-    assert C.sizeof(native.LfmModel) == 12 * 8 + 4 * 4 + 3 * 4 + 4 + 2 * 8
-    assert C.sizeof(native.LfmOpts) == 16 + 16 + 32 + 4 + 4 + 4 + 8 + 4 + 64 + 8 + 16
+    import subprocess
+    exe = str(tmp_path / "abi_probe")
+    subprocess.check_call(["gcc", "-std=c11", "-o", exe, os.path.join(ROOT, "tests", "abi_probe.c")])
+    layout = dict(line.split() for line in subprocess.check_output([exe]).decode().splitlines())
+    mirror = {"lfm_csr": native.LfmCSR, "lfm_model": native.LfmModel, "lfm_opts": native.LfmOpts}
+    checked = 0
+    for key, value in layout.items():
+        if "." in key:
+            struct, field = key.split(".")
+            assert getattr(mirror[struct], field).offset == int(value), key
+            checked += 1
+        else:
+            assert C.sizeof(mirror[key]) == int(value), key
+    assert checked >= 35
+    # every field of the header's structs is mirrored (same count)
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lfm_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct lfm_opts \{(.*?)\} lfm_opts;", header, flags=re.S).group(1)
+    n_fields = sum(len(stmt.split(",")) for stmt in body.split(";") if stmt.strip())
+    assert n_fields == len(native.LfmOpts._fields_)
 
 
 def test_no_cpu_fallback_without_gpu(native):

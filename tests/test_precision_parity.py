@@ -1,0 +1,104 @@
+"""Production-mode parity gate (BASELINE.json north_star: precision@10 within +-0.002 of the
+reference): the HIP backend with its DEFAULT options (parallel Hogwild mode, concurrency ramp,
+device shuffle, device-built positives) and the reference's own compiled Cython/OpenMP build
+(oracle/_ref/fast, 16 threads -- what a user of the reference runs) are fit on the same
+synthetic train split from the same seeds; precision@10 is the reference's metric
+(lightfm/evaluation.py:14-87) on the same held-out split, all users.
+
+Cases: the C2 regime (WARP, d=64, identity features), the C3 regime (BPR, d=128, item features
+[identity | tags]), hybrid WARP and hybrid k-OS (shared tag rows) -- on scaled ML-20M-shaped data
+so that the reference finishes in tens of seconds.
+
+Hogwild training is not deterministic on either side, so the comparison is between MEANS over
+seeds; seeds are added (up to MAX_ROUNDS x SEEDS_PER_ROUND per side) while the gap is above the
+gate, and the final means must be within GATE.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GATE = 0.002
+SEEDS_PER_ROUND = 3
+MAX_ROUNDS = 3
+
+
+def _ref_threads():
+    return min(16, os.cpu_count() or 1)
+
+
+def _data(n_users, n_items, nnz, seed=11):
+    from lightfm_amd import synthetic
+    data = synthetic.make_interactions(n_users, n_items, nnz, seed=seed)
+    return synthetic.train_test_split(data, 0.1, seed=1)
+
+
+def _p10(model, train_csr, test_csr, feats):
+    from lightfm_amd.evaluation import precision_at_k
+    return float(precision_at_k(model, test_csr, train_interactions=train_csr, k=10,
+                                item_features=feats).mean())
+
+
+def _gap(loss, d, train, test, feats, epochs, **model_kw):
+    from lightfm_amd import LightFM, options
+    from oracle import oracle
+    from oracle.ref_model import RefLightFM
+    if not oracle.ref_available("fast"):
+        pytest.skip("oracle/_ref not built")
+    options.set(mode="parallel")
+    train_csr, test_csr = train.tocsr(), test.tocsr()
+    hip, ref = [], []
+    for rnd in range(MAX_ROUNDS):
+        for seed in range(1 + rnd * SEEDS_PER_ROUND, 1 + (rnd + 1) * SEEDS_PER_ROUND):
+            m = LightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
+            m.fit(train, item_features=feats, epochs=epochs)
+            hip.append(_p10(m, train_csr, test_csr, feats))
+            r = RefLightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
+            r.fit(train, item_features=feats, epochs=epochs, num_threads=_ref_threads())
+            ref.append(_p10(r, train_csr, test_csr, feats))
+        delta = float(np.mean(hip) - np.mean(ref))
+        print("%s d=%d: hip %.4f +- %.4f  ref %.4f +- %.4f  delta %+.4f  (n=%d per side)"
+              % (loss, d, np.mean(hip), np.std(hip), np.mean(ref), np.std(ref), delta, len(hip)))
+        if abs(delta) <= GATE:
+            break
+    assert np.mean(ref) > 0.02, "the reference did not learn this problem"
+    assert abs(delta) <= GATE, (hip, ref)
+    return delta
+
+
+@pytest.mark.timeout(900)
+def test_warp_identity_c2_regime():
+    """BASELINE configs[1] regime: WARP, no_components=64, identity features (the lane-group tile
+    kernel), 1/8 of the ML-20M users and interactions, half of its items."""
+    train, test = _data(17312, 13372, 2_500_000)
+    _gap("warp", 64, train, test, None, epochs=5)
+
+
+@pytest.mark.timeout(900)
+def test_bpr_tag_features_c3_regime():
+    """BASELINE configs[2] regime: BPR, no_components=128, item features [identity | 8 tags of 1128]."""
+    from lightfm_amd import synthetic
+    train, test = _data(8656, 13372, 1_000_000)
+    feats = synthetic.tag_item_features(13372, n_tags=1128, per_item=8)
+    _gap("bpr", 128, train, test, feats, epochs=3)
+
+
+@pytest.mark.timeout(900)
+def test_warp_shared_tag_rows():
+    """Hybrid WARP: 200 tag rows shared by ~2 % of the items each (the case that needs the
+    steady-state bound on interactions in flight, csrc/session.hip: shared_cap)."""
+    from lightfm_amd import synthetic
+    train, test = _data(8656, 6686, 1_000_000)
+    feats = synthetic.tag_item_features(6686, n_tags=200, per_item=4)
+    _gap("warp", 64, train, test, feats, epochs=5)
+
+
+@pytest.mark.timeout(900)
+def test_warp_kos_shared_tag_rows():
+    """Hybrid k-OS WARP (k=5, n=10) with shared tag rows."""
+    from lightfm_amd import synthetic
+    train, test = _data(4000, 3000, 300_000)
+    feats = synthetic.tag_item_features(3000, n_tags=100, per_item=4)
+    _gap("warp-kos", 64, train, test, feats, epochs=5)

@@ -19,6 +19,8 @@ epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 loss = sys.argv[4] if len(sys.argv) > 4 else "warp"
 caps = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0, 64, 256, 1024, 8192]
+SEEDS = [int(x) for x in os.environ.get("QUALITY_SEEDS", "1,2,3").split(",")]
+REF_THREADS = [int(x) for x in os.environ.get("QUALITY_REF_THREADS", "1,16").split(",")]
 
 if name in synthetic.SHAPES:
     data = synthetic.named(name)
@@ -39,23 +41,23 @@ def evaluate(m):
     return ptr, pte
 
 
-for threads in (1, min(16, os.cpu_count())):
+for threads in [min(t, os.cpu_count()) for t in REF_THREADS]:
     res = []
-    for seed in (1, 2, 3):
+    for seed in SEEDS:
         m = RefLightFM(no_components=d, loss=loss, random_state=seed)
         t = time.time()
         m.fit(train, item_features=item_features, epochs=epochs, num_threads=threads)
         dt = time.time() - t
         res.append(evaluate(m) + (dt,))
     r = np.array(res)
-    print("ref threads=%-3d p@10 train %.4f test %.4f (std %.4f)  %.2fs/fit  %.3g inter/s" % (
-        threads, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 2].mean(),
+    print("ref threads=%-3d p@10 train %.4f test %.4f (std %.4f, sem %.4f, n=%d)  %.2fs/fit  %.3g inter/s" % (
+        threads, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 1].std() / np.sqrt(len(r)), len(r), r[:, 2].mean(),
         train.nnz * epochs / r[:, 2].mean()), flush=True)
 
 modes = [int(x) for x in os.environ.get("QUALITY_MODES", "1,3").split(",")]
 for cap, um in [(c, u) for c in caps for u in modes]:
     res = []
-    for seed in (1, 2, 3):
+    for seed in SEEDS:
         options.set(mode="parallel", max_waves=cap, update_mode=um)
         m = LightFM(no_components=d, loss=loss, random_state=seed)
         m.fit(train, item_features=item_features, epochs=epochs, num_threads=1)
@@ -64,7 +66,7 @@ for cap, um in [(c, u) for c in caps for u in modes]:
         upd = sum(s["counters"][2] for s in m._last_epoch_stats)
         res.append(evaluate(m) + (ms, draws, upd))
     r = np.array(res)
-    print("hip update_mode=%d max_waves=%-5d p@10 train %.4f test %.4f (std %.4f)  kernel %.2f ms/epoch  %.3g inter/s  draws/inter %.2f upd/inter %.2f" % (
-        um, cap, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 2].mean() / epochs,
+    print("hip update_mode=%d max_waves=%-5d p@10 train %.4f test %.4f (std %.4f, sem %.4f, n=%d)  kernel %.2f ms/epoch  %.3g inter/s  draws/inter %.2f upd/inter %.2f" % (
+        um, cap, r[:, 0].mean(), r[:, 1].mean(), r[:, 1].std(), r[:, 1].std() / np.sqrt(len(r)), len(r), r[:, 2].mean() / epochs,
         train.nnz * epochs / (r[:, 2].mean() / 1e3), r[:, 3].mean() / (train.nnz * epochs),
         r[:, 4].mean() / (train.nnz * epochs)), flush=True)
