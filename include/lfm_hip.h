@@ -92,7 +92,7 @@ typedef struct lfm_opts {
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
                                    regularisation: 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
-                                   1 = force the generic one-interaction-per-wavefront kernel,
+                                   1 = do not use the tile kernel (the row-stream or generic kernels run),
                                    2 = tile kernel instrumented with per-phase cycle counters */
     int32_t debug;              /* kernel experiments; bits 0-2: force the tile kernel's
                                    interactions per wavefront pass (1, 2 or 4); 0 = auto */

@@ -23,6 +23,8 @@ constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr double MAX_REG_SCALE = 1000000.0;  // PYX:19
 constexpr double MAX_LOSS = 10.0;            // PYX:817
+// loss ids of include/lfm_hip.h (LFM_LOSS_*)
+constexpr int LFM_LOSS_LOGISTIC_ID = 0, LFM_LOSS_WARP_ID = 1, LFM_LOSS_BPR_ID = 2, LFM_LOSS_WARP_KOS_ID = 3;
 
 struct DCsr {
     const int32_t *indices;
@@ -65,6 +67,8 @@ struct FitArgs {
     uint32_t n_items_magic;  // floor(2^32 / n_items) + 1 (warp_tile.hip: fast_mod)
     int32_t k, n_pos;      // k-OS
     int32_t pair_cap;      // k-OS: LDS pair slots per wave
+    int32_t stage_rows;    // feat_kernel.hpp: rows of the wave's LDS-DMA staging area
+    int32_t cand_base;     // feat_kernel.hpp: first candidate-negative row of the representation tile
     int32_t *neg_log, *sampled_log;
     unsigned long long *counters;  // [4]
     double *scale_prod;            // [2] parallel mode: product of (1+alpha*avg_lr) of this launch

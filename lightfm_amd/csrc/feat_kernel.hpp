@@ -1,0 +1,484 @@
+// feat_kernel.hpp -- pipelined row-stream epoch kernels for every parallel-mode model the
+// lane-group WARP tile kernel (warp_tile_kernel.hpp) does not cover: feature CSRs on either side
+// (hybrid models), BPR, k-OS WARP and logistic.  BASELINE configs C3 (BPR, d = 128, item tags)
+// and C5 (k-OS, d = 128, 8 nnz item rows).  PYX = /root/reference/lightfm/_lightfm_fast.pyx.template
+//
+// One interaction per wavefront, like the generic kernels of fit_kernels.hip, but organised as
+// the tile kernel is -- every memory phase is ONE round trip for everything it needs:
+//
+//   jobs      the representations an interaction needs (user; positive item; ALL candidate
+//             negatives of a batch / the n sampled positives of k-OS) are "jobs", one per lane.
+//             Their CSR row bounds are fetched together (lane j reads indptr of job j), an
+//             exclusive scan lays their feature entries out in one flat list, and lane t fetches
+//             entry t: (feature, weight) of every job in one round trip.  An identity matrix
+//             contributes its implicit entry without touching memory.
+//   gather    the embedding rows of the flat list go memory -> LDS by LDS-DMA
+//             (global_load_lds_dwordx4: d/4 lanes x 16 B per row, 64/(d/4) rows = 1 KiB per wave
+//             instruction, no VGPRs, no ds_write), a whole chunk of rows in flight at once.
+//   reduce    lane c owns component c: it walks the staged rows in CSR order and accumulates
+//             w * row[c] in float32 exactly as compute_representation does (PYX:287-317); a job
+//             boundary flushes the accumulator into the wave's representation tile.
+//   score     lane r computes the reference's sequential float32 dot (PYX:320-334) of tile row r
+//             with the user row: the positive and every candidate of the batch in one pass.
+//   sample    as in the reference, with the position's own rand_r stream: WARP / k-OS take the first
+//             violator of the speculatively scored batch (PYX:857-899, 1014-1057), BPR draws its
+//             candidate negatives eight at a time and keeps the first non-positive (PYX:1123-1127);
+//             streams advance by exactly the draws the sequential loop would have made.
+//   update    the rows of the three (two) representations that are updated form one flat list
+//             again; their W rows AND G rows are DMA'd together, lane c evaluates the reference's
+//             float64 cell arithmetic (PYX:416-449) for its coordinate of every row and publishes
+//             new - old with global_atomic_add_f32; the rows' bias cells are handled one per lane.
+//
+// Scope: parallel mode, adagrad, no L2 regularisation, no_components a multiple of 4 up to 128.
+// Everything else (serial mode, adadelta, alpha != 0, wider models) runs the generic kernels.
+#pragma once
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace lfm {
+
+namespace {
+
+typedef __attribute__((address_space(3))) float lds_f32_t;
+
+}  // namespace
+
+// LOSS: LFM_LOSS_* (0 logistic, 1 WARP, 2 BPR, 3 k-OS WARP).  NC = ceil(d / 64).
+template <int LOSS, int NC>
+__global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), wib = uni((int)(threadIdx.x >> 6));
+    const int d = a.m.d, TS = a.tile_stride, RR = a.tile_rows, SR = a.stage_rows;
+    const int LPR = d >> 2, RPI = WAVE / LPR;  // lanes per row, rows per DMA instruction
+    const size_t wave_floats = (size_t)SR * d + (size_t)RR * TS + 3 * (size_t)a.pair_cap;
+    float *stage = smem + (size_t)wib * wave_floats;  // [SR][d] packed: what LDS-DMA deposits
+    float *reps = stage + (size_t)SR * d;              // [RR][TS] representations, bias in column d
+    int *pair_idx = reinterpret_cast<int *>(reps + (size_t)RR * TS);  // k-OS (PYX:109-111)
+    float *pair_val = reinterpret_cast<float *>(pair_idx + a.pair_cap);
+    int *pair_slot = reinterpret_cast<int *>(pair_val + a.pair_cap);
+    const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
+    const int um = a.update_mode;
+    const int max_sampled = a.m.max_sampled;
+    const int cand_base = a.cand_base, CB = RR - cand_base;  // candidate rows of the tile
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+
+    // ---- a list of jobs (lane j = job j): CSR extent of every job and the flat entry layout
+    auto job_extent = [&](int row, int side, int J, int &start, int &len, int &off, int &T) {
+        start = 0;
+        len = 0;
+        if (lane < J) {
+            const bool ident = side ? a.usf.identity : a.itf.identity;
+            if (ident) {
+                start = row;
+                len = 1;
+            } else {
+                const int32_t *ip = side ? a.usf.indptr : a.itf.indptr;
+                start = ip[row];
+                len = ip[row + 1] - start;
+            }
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int v = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += v;
+        }
+        off = incl - len;
+        T = read_lane(incl, WAVE - 1);
+    };
+    // entry r * 64 + lane of the flat list: which job, which feature row, which weight
+    auto round_entries = [&](int r, int J, int start, int len, int off, int side, int T, int &feat, float &w,
+                             int &job, int &eside) {
+        const int g = r * WAVE + lane;
+        job = 0;
+        for (int jj = 0; jj + 1 < J; ++jj) {  // jobs that end at or before g
+            const int end_jj = read_lane(off, jj) + read_lane(len, jj);
+            if (g >= end_jj) job = jj + 1;
+        }
+        const int js = __shfl(start, job, WAVE), jo = __shfl(off, job, WAVE);
+        eside = __shfl(side, job, WAVE);
+        const int k = js + (g - jo);
+        feat = 0;
+        w = 0.0f;
+        if (g < T) {
+            const bool ident = eside ? a.usf.identity : a.itf.identity;
+            if (ident) {
+                feat = k;
+                w = 1.0f;
+            } else {
+                feat = (eside ? a.usf.indices : a.itf.indices)[k];
+                w = (eside ? a.usf.data : a.itf.data)[k];
+            }
+        }
+    };
+    // rows of entries [c0e, c0e + nc) of the current round: memory -> dst[0 .. nc) by LDS-DMA
+    auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, bool gtab) {
+        const int rsub = lane / LPR, piece = lane - rsub * LPR;
+        for (int i0 = 0; i0 < nc; i0 += RPI) {
+            const int e = c0e + i0 + rsub;
+            const bool valid = rsub < RPI && (i0 + rsub) < nc;
+            const int fe = __shfl(feat, e & (WAVE - 1), WAVE), se = __shfl(eside, e & (WAVE - 1), WAVE);
+            const float *tab = gtab ? (se ? a.m.G[1] : a.m.G[0]) : (se ? a.m.W[1] : a.m.W[0]);
+            const float *src = tab + (size_t)fe * d + piece * 4;
+            if (valid) __builtin_amdgcn_global_load_lds(src, (lds_f32_t *)(dst + (size_t)i0 * d), 16, 0, 0);
+        }
+    };
+
+    // ---- representations of J jobs -> tile rows rrow[j]  (compute_representation, PYX:287-317)
+    auto build_reps = [&](int row, int side, int rrow, int J) {
+        for (int j = 0; j < J; ++j) {  // a job without entries keeps the zero representation
+            float *rp = reps + (size_t)read_lane(rrow, j) * TS;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = lane + WAVE * q;
+                if (c < d) rp[c] = 0.0f;
+            }
+            if (lane == 0) rp[d] = 0.0f;
+        }
+        int start, len, off, T;
+        job_extent(row, side, J, start, len, off, T);
+        int cur = -1;
+        float acc[NC], accb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+        auto flush = [&]() {
+            float *rp = reps + (size_t)read_lane(rrow, cur) * TS;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = lane + WAVE * q;
+                if (c < d) rp[c] = acc[q];
+            }
+            if (lane == 0) rp[d] = accb;
+        };
+        for (int r = 0; r * WAVE < T; ++r) {
+            int feat, job, eside;
+            float w;
+            round_entries(r, J, start, len, off, side, T, feat, w, job, eside);
+            const int n_r = min(WAVE, T - r * WAVE);
+            float bx = 0.0f;
+            if (lane < n_r) bx = (eside ? a.m.b[1] : a.m.b[0])[feat];
+            for (int ce = 0; ce < n_r; ce += SR) {
+                const int nc = min(SR, n_r - ce);
+                dma_rows(feat, eside, ce, nc, stage, false);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
+                wave_sync();
+                for (int t = ce; t < ce + nc; ++t) {
+                    const int jt = read_lane(job, t);
+                    if (jt != cur) {
+                        if (cur >= 0) flush();
+                        cur = jt;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+                        accb = 0.0f;
+                    }
+                    const float wt = read_lanef(w, t), bt = read_lanef(bx, t);
+                    const float *sr = stage + (size_t)(t - ce) * d;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        const float xv = c < d ? sr[c] : 0.0f;
+                        acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xv));
+                    }
+                    accb = __fadd_rn(accb, __fmul_rn(wt, bt));
+                }
+                wave_sync();  // the stage is rewritten by the next chunk
+            }
+        }
+        if (cur >= 0) flush();
+        wave_sync();
+    };
+
+    // ---- update of the rows of up to three representations (update / warp_update, PYX:454-649):
+    // job j's coordinate cells get g = gj * x[c] with x = xI for item-side rows and xU for
+    // user-side rows; its bias cells get g = gj.
+    auto update_rows = [&](int row, int side, int J, double g0, double g1, double g2, const float (&xI)[NC],
+                           const float (&xU)[NC]) {
+        int start, len, off, T;
+        job_extent(row, side, J, start, len, off, T);
+        const int SRh = SR >> 1;
+        float *stW = stage, *stG = stage + (size_t)SRh * d;
+        for (int r = 0; r * WAVE < T; ++r) {
+            int feat, job, eside;
+            float w;
+            round_entries(r, J, start, len, off, side, T, feat, w, job, eside);
+            const int n_r = min(WAVE, T - r * WAVE);
+            const bool on = lane < n_r;
+            float *bp = (eside ? a.m.b[1] : a.m.b[0]) + feat, *bgp = (eside ? a.m.bG[1] : a.m.bG[0]) + feat;
+            float obW = 0.0f, obG = 1.0f;
+            if (on) {  // bias cells: requested with the first rows, consumed after the last
+                obW = *bp;
+                obG = *bgp;
+            }
+            for (int ce = 0; ce < n_r; ce += SRh) {
+                const int nc = min(SRh, n_r - ce);
+                dma_rows(feat, eside, ce, nc, stW, false);
+                dma_rows(feat, eside, ce, nc, stG, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_sync();
+                for (int t = ce; t < ce + nc; ++t) {
+                    const int jt = read_lane(job, t), st_ = read_lane(eside, t), fe = read_lane(feat, t);
+                    const double wt = (double)read_lanef(w, t);
+                    const double gc = jt == 0 ? g0 : (jt == 1 ? g1 : g2);
+                    float *Wp = (st_ ? a.m.W[1] : a.m.W[0]) + (size_t)fe * d;
+                    float *Gp = (st_ ? a.m.G[1] : a.m.G[0]) + (size_t)fe * d;
+                    const float *sw = stW + (size_t)(t - ce) * d, *sg = stG + (size_t)(t - ce) * d;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        if (c < d) {
+                            const float oW = sw[c], oG = sg[c];
+                            const float x = st_ ? xU[q] : xI[q];
+                            float nW, nG, nM;
+                            double lr;
+                            cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, 0.0, nW, nG, nM, lr);
+                            publish(Wp + c, nW, oW, um);
+                            publish(Gp + c, nG, oG, um);
+                        }
+                    }
+                }
+                wave_sync();
+            }
+            {
+                const double gb = job == 0 ? g0 : (job == 1 ? g1 : g2);
+                float nW, nG, nM;
+                double lr;
+                cell_math(obW, obG, 0.0f, (double)w, gb, h, 0.0, nW, nG, nM, lr);
+                if (on) {
+                    publish(bp, nW, obW, um);
+                    publish(bgp, nG, obG, um);
+                }
+            }
+        }
+    };
+    auto rep_regs = [&](int r, float (&v)[NC]) {
+        const float *rp = reps + (size_t)r * TS;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = lane + WAVE * q;
+            v[q] = c < d ? rp[c] : 0.0f;
+        }
+    };
+    auto log_pos = [&](int64_t i, int neg, int sampled) {
+        if (lane == 0) {
+            if (a.neg_log) a.neg_log[i] = neg;
+            if (a.sampled_log) a.sampled_log[i] = sampled;
+        }
+    };
+
+    const int wpb = (int)(blockDim.x >> 6);  // 1, 2 or 4 wavefronts per workgroup (feat_plan)
+    const int64_t gw = (int64_t)blockIdx.x * wpb + wib;
+    const int64_t nw = (int64_t)gridDim.x * wpb;
+    const uint32_t base_seed = LOSS != LFM_LOSS_LOGISTIC_ID ? a.seeds[0] : 0u;
+    auto fetch = [&](int row) -> int4 {
+        if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) return make_int4(a.user_ids[row], 0, 0, 0);
+        else return a.recs[row];
+    };
+    int64_t i = a.begin + gw;
+    int4 cur = make_int4(0, 0, 0, 0);
+    int row1 = 0;
+    if (i < a.end) cur = fetch(a.shuffle[i]);
+    if (i + nw < a.end) row1 = a.shuffle[i + nw];
+    for (; i < a.end; i += nw) {
+        int4 nxt = make_int4(0, 0, 0, 0);
+        int row2 = 0;
+        if (i + 2 * nw < a.end) row2 = a.shuffle[i + 2 * nw];
+        if (i + nw < a.end) nxt = fetch(row1);
+        const int user = uni(cur.x), item = uni(cur.y);
+        const float y = unif(__int_as_float(cur.z)), wgt = unif(__int_as_float(cur.w));
+        cur = nxt;
+        row1 = row2;
+
+        if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
+            // fit_logistic, PYX:726-775
+            build_reps(lane == 0 ? user : item, lane == 0 ? 1 : 0, lane, 2);
+            float s = 0.0f;
+            if (lane == 1) s = tile_dot(reps, reps + TS, d);
+            s = read_lanef(s, 1);
+            float Uv[NC], Iv[NC];
+            rep_regs(0, Uv);
+            rep_regs(1, Iv);
+            wave_sync();
+            const double prediction = (double)sigmoidf_ref(s);  // PYX:745-747
+            const int yb = (y <= 0.0f) ? 0 : 1;                  // PYX:751-755
+            if (yb) c0++;
+            const double loss = (double)wgt * (prediction - (double)yb);
+            update_rows(lane == 0 ? item : user, lane == 0 ? 0 : 1, 2, loss, loss, 0.0, Uv, Iv);
+            c2++;
+            continue;
+        } else {
+            if constexpr (LOSS != LFM_LOSS_WARP_KOS_ID) {
+                if (!(y > 0.0f)) {  // PYX:831-832 / 1116-1117, before any RNG use
+                    log_pos(i, -1, 0);
+                    continue;
+                }
+            }
+            uint32_t state = position_seed(base_seed, (uint64_t)i);
+            const int lo = uni(a.pos.indptr[user]), hi = uni(a.pos.indptr[user + 1]);
+
+            if constexpr (LOSS == LFM_LOSS_BPR_ID) {
+                // fit_bpr, PYX:1118-1169
+                c0++;
+                const uint32_t n_examples = (uint32_t)a.n;
+                int neg = -1, draws = 0;
+                while (neg < 0) {
+                    uint32_t s = state;  // lane j: the stream after min(j + 1, 8) steps
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j <= lane) s = lcg(s);
+                    int cand = 0;
+                    if (lane < 8) cand = a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
+                    int used = 8;
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = read_lane(cand, j);
+                        c3++;
+                        const bool last = (int64_t)draws + j + 1 >= a.n;  // PYX:1123: at most no_examples draws
+                        if (last || !in_positives_range(a.pos, c, lo, hi, lane)) {
+                            neg = c;
+                            used = j + 1;
+                            break;
+                        }
+                    }
+                    draws += used;
+                    state = (uint32_t)read_lane((int)s, used - 1);
+                }
+                c1 += (unsigned long long)draws;
+                build_reps(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, lane, 3);
+                float sc = 0.0f;
+                if (lane == 1 || lane == 2) sc = tile_dot(reps, reps + (size_t)lane * TS, d);
+                const double pp = (double)read_lanef(sc, 1), np_ = (double)read_lanef(sc, 2);
+                float Uv[NC], Pv[NC], Nv[NC], diff[NC];
+                rep_regs(0, Uv);
+                rep_regs(1, Pv);
+                rep_regs(2, Nv);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(Nv[q], Pv[q]);
+                wave_sync();
+                // PYX:1158: weight * (1 - sigmoid(pp - np)); the difference is narrowed to float32
+                const double loss = (double)wgt * (1.0 - (double)sigmoidf_ref((float)(pp - np_)));
+                update_rows(lane == 0 ? item : (lane == 1 ? neg : user), lane == 2 ? 1 : 0, 3, -loss, loss, loss, Uv,
+                            diff);
+                c2++;
+                log_pos(i, neg, draws);
+                continue;
+            } else {
+                // fit_warp (PYX:826-904) and fit_warp_kos (PYX:958-1061) share the negative sampling
+                int pos_item = item, prow = 1;
+                double pp = 0.0;
+                bool have_pos = false;  // the positive's score is known (k-OS: before the negatives)
+                if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) {
+                    if (hi == lo) {  // PYX:971-972
+                        log_pos(i, -1, 0);
+                        continue;
+                    }
+                    c0++;
+                    const int no_pos = min(a.n_pos, hi - lo);  // PYX:975
+                    uint32_t s = state;                        // lane l: the stream after min(l, no_pos) steps
+                    for (int j = 0; j < no_pos; ++j)
+                        if (j < lane) s = lcg(s);
+                    int it = 0;
+                    if (lane >= 1 && lane <= no_pos)  // sample_range, PYX:84-90
+                        it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
+                    state = (uint32_t)read_lane((int)s, no_pos);
+                    build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos);
+                    if (lane >= 1 && lane <= no_pos) {
+                        pair_idx[lane - 1] = it;
+                        pair_val[lane - 1] = tile_dot(reps, reps + (size_t)lane * TS, d);
+                        pair_slot[lane - 1] = lane;
+                    }
+                    wave_sync();
+                    if (lane == 0) {  // qsort(reverse_pair_compare), PYX:997: stable descending insertion sort
+                        for (int x = 1; x < no_pos; ++x) {
+                            const int ki = pair_idx[x], ks = pair_slot[x];
+                            const float kv = pair_val[x];
+                            int yv = x - 1;
+                            while (yv >= 0 && (pair_val[yv] - kv) < 0.0f) {
+                                pair_idx[yv + 1] = pair_idx[yv];
+                                pair_val[yv + 1] = pair_val[yv];
+                                pair_slot[yv + 1] = pair_slot[yv];
+                                --yv;
+                            }
+                            pair_idx[yv + 1] = ki;
+                            pair_val[yv + 1] = kv;
+                            pair_slot[yv + 1] = ks;
+                        }
+                    }
+                    wave_sync();
+                    const int kk = min(a.k, no_pos) - 1;  // PYX:1002-1003
+                    pos_item = uni(pair_idx[kk]);
+                    pp = (double)unif(pair_val[kk]);
+                    prow = uni(pair_slot[kk]);
+                    have_pos = true;
+                    wave_sync();
+                } else {
+                    c0++;
+                }
+                int sampled = 0, chosen = -1, chosen_row = -1;
+                while (sampled < max_sampled && chosen < 0) {
+                    const int nb = min(max_sampled - sampled, min(sampled == 0 ? a.first_batch : CB, CB));
+                    uint32_t s = state;  // lane k: the stream after min(k + 1, nb) steps = draw #(sampled + k + 1)
+                    for (int j = 0; j < nb; ++j)
+                        if (j <= lane) s = lcg(s);
+                    const int myneg = (int)(draw(s) % (uint32_t)a.itf.rows);  // PYX:860-861
+                    if (!have_pos) {
+                        // the first batch gathers user, positive and candidates in one pass
+                        const int cand = __shfl(myneg, max(lane - 2, 0), WAVE);
+                        build_reps(lane == 0 ? user : (lane == 1 ? pos_item : cand), lane == 0 ? 1 : 0,
+                                   lane < 2 ? lane : cand_base + lane - 2, 2 + nb);
+                    } else {
+                        build_reps(myneg, 0, cand_base + lane, nb);
+                    }
+                    float sc = 0.0f;
+                    const bool mine = lane >= cand_base && lane < cand_base + nb;
+                    if (mine || (!have_pos && lane == prow)) sc = tile_dot(reps, reps + (size_t)lane * TS, d);
+                    if (!have_pos) {
+                        pp = (double)read_lanef(sc, prow);
+                        have_pos = true;
+                    }
+                    // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
+                    unsigned long long mask = __ballot(mine && ((double)sc > pp - 1.0));
+                    int used = nb;
+                    while (mask) {
+                        const int slot = __ffsll((long long)mask) - 1 - cand_base;
+                        mask &= mask - 1;
+                        const int neg = read_lane(myneg, slot);
+                        c3++;
+                        if (in_positives_range(a.pos, neg, lo, hi, lane)) continue;  // PYX:878-879, draw counted
+                        chosen = neg;
+                        chosen_row = cand_base + slot;
+                        used = slot + 1;
+                        break;
+                    }
+                    sampled += used;
+                    state = (uint32_t)read_lane((int)s, used - 1);
+                    wave_sync();
+                }
+                c1 += (unsigned long long)sampled;
+                if (chosen >= 0) {
+                    // PYX:881-885 (k-OS: PYX:1039-1043, no weight); log table from the host libm
+                    double loss = LOSS == LFM_LOSS_WARP_KOS_ID ? a.logtab[sampled] : (double)wgt * a.logtab[sampled];
+                    if (loss > MAX_LOSS) loss = MAX_LOSS;
+                    float Uv[NC], Pv[NC], Nv[NC], diff[NC];
+                    rep_regs(0, Uv);
+                    rep_regs(prow, Pv);
+                    rep_regs(chosen_row, Nv);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(Nv[q], Pv[q]);
+                    wave_sync();
+                    update_rows(lane == 0 ? pos_item : (lane == 1 ? chosen : user), lane == 2 ? 1 : 0, 3, -loss, loss,
+                                loss, Uv, diff);
+                    c2++;
+                }
+                log_pos(i, chosen, sampled);
+            }
+        }
+    }
+    if (lane == 0) {
+        if (c0) atomicAdd(a.counters + 0, c0);
+        if (c1) atomicAdd(a.counters + 1, c1);
+        if (c2) atomicAdd(a.counters + 2, c2);
+        if (c3) atomicAdd(a.counters + 3, c3);
+    }
+}
+
+}  // namespace lfm

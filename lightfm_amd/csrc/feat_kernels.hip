@@ -1,0 +1,91 @@
+// feat_kernels.hip -- instantiations, LDS geometry and launcher of the pipelined row-stream epoch
+// kernels (feat_kernel.hpp).
+#include <stdlib.h>
+
+#include "feat_kernel.hpp"
+
+namespace lfm {
+
+// LDS of one wavefront: [stage_rows][d] staging (LDS-DMA target) + [rr][d + 4] representations
+// (+ 3 * pair_cap k-OS slots).  The budget per wavefront decides how many wavefronts a CU holds
+// (160 KiB LDS): many rows in flight per wavefront against many wavefronts.
+bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p)
+{
+    if (d < 4 || d > 128 || (d & 3) != 0 || max_sampled < 0) return false;
+    FeatPlan g;
+    g.ts = d + 4;
+    g.pair_cap = 0;
+    int cb = std::max(1, std::min(max_sampled, 16));
+    switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: g.cand_base = 2; cb = 0; break;
+    case LFM_LOSS_BPR_ID: g.cand_base = 3; cb = 0; break;
+    case LFM_LOSS_WARP_ID: g.cand_base = 2; break;
+    case LFM_LOSS_WARP_KOS_ID:
+        if (n_positives < 1 || n_positives > 32) return false;
+        g.cand_base = 1 + n_positives;
+        g.pair_cap = ((n_positives + 3) / 4) * 4;
+        break;
+    default: return false;
+    }
+    static int budget_kb = -1, wpb_env = -1;
+    if (budget_kb < 0) {
+        const char *e = getenv("LIGHTFM_AMD_FEAT_LDS_KB");
+        budget_kb = e ? atoi(e) : 0;
+        const char *w = getenv("LIGHTFM_AMD_FEAT_WAVES_PER_BLOCK");
+        wpb_env = w ? atoi(w) : 0;
+    }
+    // default budget per wavefront: 7 wavefronts per CU for the wide models, 16 otherwise
+    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024 : (d > 64 ? 22 * 1024 : 10 * 1024);
+    g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : (d > 64 ? 1 : 2);
+    const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list
+    for (;; --cb) {
+        g.rr = g.cand_base + cb;
+        const size_t fixed = (size_t)g.rr * g.ts * 4 + 3 * (size_t)g.pair_cap * 4;
+        if (fixed < budget) {
+            int sr = (int)((budget - fixed) / ((size_t)d * 4));
+            sr = std::min(sr, want) & ~1;
+            if (sr >= 8 || (sr >= 4 && cb <= 1)) {
+                g.sr = sr;
+                break;
+            }
+        }
+        if (cb <= 1) return false;
+    }
+    if (g.rr > WAVE) return false;
+    g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : max_sampled, cb));
+    g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap) * 4;
+    *p = g;
+    return true;
+}
+
+template <int NC>
+static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                                 int *grid_used)
+{
+    void (*kernel)(FitArgs) = nullptr;
+    switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (cus > 0) {  // only resident workgroups: every wavefront runs its grid-stride loop from the start
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) == hipSuccess && per_cu > 0)
+            grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, block, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                           int *grid_used)
+{
+    if (a.m.d <= 64) return launch_feat_nc<1>(loss, a, grid, block, smem, st, cus, grid_used);
+    if (a.m.d <= 128) return launch_feat_nc<2>(loss, a, grid, block, smem, st, cus, grid_used);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lfm

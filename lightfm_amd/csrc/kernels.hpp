@@ -30,6 +30,16 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
 size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec);
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
                                 int cus, bool timed = false, int *grid_used = nullptr);
+// feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
+struct FeatPlan {
+    int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...
+    int waves_per_block;
+    size_t smem;  // LDS bytes per workgroup
+};
+// rows_hint: rows of a typical update list (f_user + 2 f_item), so that one chunk covers it
+bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p);
+hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                           int *grid_used = nullptr);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);

@@ -898,6 +898,25 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         }
     }
 
+    // Every other parallel-mode model without regularisation: the pipelined row-stream kernels
+    // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
+    FeatPlan fplan;
+    bool use_feat = false;
+    if (!serial && !use_tile && opts->feat_kernel != 1 && item_alpha == 0.0 && user_alpha == 0.0 && !s->adadelta &&
+        s->itf.rows >= 1 && s->n > 0) {
+        auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
+        const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
+        use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan);
+        if (use_feat && loss != LFM_LOSS_WARP_KOS) {
+            if (!s->recs_valid) {
+                LFM_TRY(s->recs.alloc((size_t)s->n));
+                HIP_TRY(launch_pack_records(a.user_ids, a.item_ids, a.Y, a.weight, s->n, s->recs.p, s->stream));
+                s->recs_valid = true;
+            }
+            a.recs = s->recs.p;
+        }
+    }
+
     if (opts->neg_log) { LFM_TRY(s->neg_log.alloc((size_t)s->n)); a.neg_log = s->neg_log.p; }
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
     if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
@@ -944,7 +963,17 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             }
             a = base;
             size_t lsmem = generic_smem;
-            int per_wave = 1;
+            int per_wave = 1, wpb = WAVES_PER_BLOCK;
+            if (use_feat) {
+                lsmem = fplan.smem;
+                wpb = fplan.waves_per_block;
+                a.tile_rows = fplan.rr;
+                a.tile_stride = fplan.ts;
+                a.stage_rows = fplan.sr;
+                a.cand_base = fplan.cand_base;
+                a.pair_cap = fplan.pair_cap;
+                a.first_batch = fplan.first_batch;
+            }
             if (ng) {
                 const TilePlan &t = tile[ng];
                 lsmem = t.smem;
@@ -953,18 +982,19 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 a.tile_stride = t.stride;
                 a.first_batch = t.first_batch;
             }
-            const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lsmem, 1)));
+            const size_t cu_blocks = use_feat ? (size_t)(16 / wpb) : 8;  // at most 16 wavefronts per CU
+            const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
-            const bool below_residency = allowed / (WAVES_PER_BLOCK * per_wave) < max_grid;
-            max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, allowed / (WAVES_PER_BLOCK * per_wave)));
+            const bool below_residency = allowed / (wpb * per_wave) < max_grid;
+            max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, allowed / (wpb * per_wave)));
             if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
-            const int64_t flight = (int64_t)max_grid * WAVES_PER_BLOCK * per_wave;
+            const int64_t flight = (int64_t)max_grid * wpb * per_wave;
             int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
-            const int grid = (int)std::min<int64_t>(max_grid, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            const int grid = (int)std::min<int64_t>(max_grid, (waves + wpb - 1) / wpb);
             int grid_used = grid;
             if (ng) {
                 // Scoring reads twelve 4-byte biases per interaction.  With uncached tables each
@@ -986,6 +1016,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2,
                                              &grid_used));
             }
+            else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used));
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
@@ -993,7 +1024,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             }
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp
-            in_flight = (int)std::min<int64_t>((int64_t)grid_used * WAVES_PER_BLOCK * per_wave, INT32_MAX);
+            in_flight = (int)std::min<int64_t>((int64_t)grid_used * wpb * per_wave, INT32_MAX);
             ng_used = ng;
             ++n_launches;
         }
@@ -1010,7 +1041,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
     opts->tile_ng = tile_ng_used;
-    opts->kernel_used = tile_ng_used ? 1 : 0;
+    opts->kernel_used = tile_ng_used ? 1 : (use_feat ? 2 : 0);
     opts->in_flight = in_flight;
     opts->launches = n_launches;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));

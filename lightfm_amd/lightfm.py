@@ -416,7 +416,11 @@ class LightFM(object):
                 session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts)
                 self._trained_interactions = getattr(self, "_trained_interactions", 0) + n
                 self._last_epoch_stats.append({"kernel_ms": float(opts.kernel_ms),
-                                               "counters": list(opts.counters)})
+                                               "counters": list(opts.counters),
+                                               "kernel_used": int(opts.kernel_used),
+                                               "tile_ng": int(opts.tile_ng),
+                                               "in_flight": int(opts.in_flight),
+                                               "launches": int(opts.launches)})
                 if not session.check_finite():  # LFM:664
                     session.sync_to_host(model)
                     raise ValueError(_NOT_FINITE)

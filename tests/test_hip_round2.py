@@ -1,0 +1,348 @@
+"""GPU tests of the round-2 surface: adadelta under full concurrency, parallel-mode L2
+regularisation, epoch segments, the device-built positives lookup, the merge arithmetic of the
+multi-GPU path (K sessions on one device) and device-side representations."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    from lightfm_amd.options import options
+    defaults = dict(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves=0, log_samples=False,
+                    warp_kernel=0, feat_kernel=0, ramp_k=0, update_mode=0, shared_cap=0, host_positives=False)
+    options.set(**defaults)
+    yield
+    options.set(**defaults)
+
+
+def _session(model, n_items, n_users, coo, item_f=None, user_f=None, host_positives=False):
+    from lightfm_amd._lightfm_fast import CSRMatrix
+    from lightfm_amd.lightfm import _Session
+    struct = model._get_lightfm_data()
+    s = _Session(struct, CSRMatrix(item_f if item_f is not None else H.identity_features(n_items)),
+                 CSRMatrix(user_f if user_f is not None else H.identity_features(n_users)))
+    pos = CSRMatrix(H.positives_csr(coo)) if host_positives else None
+    s.set_interactions(pos, np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col), coo.data, coo.data)
+    if not host_positives:
+        s.build_positives(*coo.shape)
+    return s, struct
+
+
+# ------------------------------------------------------------------ adadelta ---
+
+@pytest.mark.parametrize("loss", ["warp", "bpr", "logistic"])
+def test_adadelta_full_concurrency_skewed_item_stays_finite(loss):
+    """adadelta's moving-average accumulators under K concurrent writers.  One item holds
+    ~8 % of the interactions, the chip is full from the first launch (ramp disabled): weights must
+    stay finite and the accumulators non-negative (csrc/device.hpp: publish_adadelta)."""
+    from lightfm_amd import LightFM, options
+    rng = np.random.RandomState(5)
+    nu, ni, n = 6000, 500, 400000
+    u = rng.randint(0, nu, size=n)
+    i = rng.randint(0, ni, size=n)
+    i[rng.rand(n) < 0.08] = 7  # the hot item
+    key = np.unique(u.astype(np.int64) * ni + i)
+    coo = sp.coo_matrix((np.ones(len(key), np.float32), ((key // ni).astype(np.int32), (key % ni).astype(np.int32))),
+                        shape=(nu, ni), dtype=np.float32)
+    options.set(ramp_k=-1)
+    m = LightFM(no_components=64, loss=loss, learning_schedule="adadelta", random_state=3)
+    m.fit(coo, epochs=3)
+    for name in ("item_embeddings", "user_embeddings", "item_biases", "user_biases"):
+        assert np.isfinite(getattr(m, name)).all(), name
+    for name in ("item_embedding_gradients", "item_embedding_momentum", "item_bias_gradients",
+                 "item_bias_momentum", "user_embedding_gradients", "user_embedding_momentum"):
+        a = getattr(m, name)
+        assert np.isfinite(a).all() and a.min() >= 0.0, name
+    assert np.abs(m.item_embeddings[7]).max() < 50.0
+
+
+# ------------------------------------------------------------ regularisation ---
+
+def _labelled_problem(seed=2, nu=1500, ni=900, n_pos=60000):
+    """Positive interactions from the cluster model (label +1) plus as many uniformly random pairs
+    (label -1): the shape of the reference's binarised MovieLens-100k train / test sets."""
+    from lightfm_amd import synthetic
+    pos = synthetic.make_interactions(nu, ni, n_pos, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    nr, nc = rng.randint(0, nu, size=pos.nnz), rng.randint(0, ni, size=pos.nnz)
+    rows = np.concatenate([pos.row, nr]).astype(np.int32)
+    cols = np.concatenate([pos.col, nc]).astype(np.int32)
+    vals = np.concatenate([np.ones(pos.nnz), -np.ones(pos.nnz)]).astype(np.float32)
+    key, idx = np.unique(rows.astype(np.int64) * ni + cols, return_index=True)
+    rows, cols, vals = rows[idx], cols[idx], vals[idx]
+    mask = rng.rand(len(vals)) < 0.2
+
+    def sub(m):
+        return sp.coo_matrix((vals[m], (rows[m], cols[m])), shape=(nu, ni), dtype=np.float32)
+    return sub(~mask), sub(mask)
+
+
+def _auc(model, coo):
+    from sklearn.metrics import roc_auc_score
+    return roc_auc_score(coo.data > 0, model.predict(coo.row, coo.col))
+
+
+@pytest.mark.parametrize("loss", ["logistic", "warp", "bpr", "warp-kos"])
+def test_excessive_regularisation_parallel_mode(loss):
+    """tests/test_movielens.py:549-569 of the reference: alpha = 1 must flatten the model (AUC near
+    chance) without the lazy scale accumulating to infinity -- here in PARALLEL mode (the per-launch
+    fold of csrc/fit_kernels.hip: fold_scales_kernel + regularize_kernel)."""
+    from lightfm_amd import LightFM
+    train, test = _labelled_problem()
+    m = LightFM(no_components=10, item_alpha=1.0, user_alpha=1.0, loss=loss, random_state=10)
+    m.fit_partial(train, epochs=10, num_threads=4)
+    for name in ("item_embeddings", "user_embeddings", "item_biases", "user_biases"):
+        assert np.isfinite(getattr(m, name)).all(), name
+    assert _auc(m, train) < 0.65
+    assert _auc(m, test) < 0.65
+
+
+def test_moderate_regularisation_parallel_mode_matches_the_reference():
+    """tests/test_movielens.py:587-599: alpha = 1e-4, no_components=50, 30 epochs generalises (the
+    unregularised model of :572-584 overfits).  The compiled reference is fit beside it on the same
+    data; train / test AUC must agree within 0.02 and show the same ordering against overfitting."""
+    from lightfm_amd import LightFM
+    from oracle.ref_model import RefLightFM
+    if not oracle.ref_available("fast"):
+        pytest.skip("oracle/_ref not built")
+    train, test = _labelled_problem()
+    res = {}
+    for name, cls in (("hip", LightFM), ("ref", RefLightFM)):
+        reg = cls(no_components=50, item_alpha=0.0001, user_alpha=0.0001, random_state=10)
+        reg.fit_partial(train, epochs=30)
+        over = cls(no_components=50, random_state=10)
+        over.fit_partial(train, epochs=30)
+        res[name] = (_auc(reg, train), _auc(reg, test), _auc(over, train), _auc(over, test))
+    print(res)
+    for j in range(4):
+        assert abs(res["hip"][j] - res["ref"][j]) < 0.02, (j, res)
+    assert res["hip"][2] > res["hip"][0]          # the unregularised model fits the train set better ...
+    assert res["hip"][1] > res["hip"][3] - 0.005  # ... and does not generalise better
+
+
+@pytest.mark.parametrize("loss", ["logistic", "warp", "bpr"])
+def test_frozen_weight_scale_folding_matches_the_oracle(loss):
+    """sample_weight = 0 freezes every gradient, so with alpha != 0 only the lazy regularisation
+    acts: each visited interaction multiplies the global scale by (1 + alpha * avg_lr) and its cells
+    by (1 + alpha * lr) (PYX:640-691).  Multiplications commute, so the parallel fold
+    (atomic_mul_double per wavefront, fold per launch, one division at the end) must reproduce the
+    serial oracle up to rounding."""
+    from lightfm_amd import options
+    import lightfm_amd._lightfm_fast as fast
+    coo = H.make_interactions(300, 200, 8000, seed=4)
+    item_f, user_f = H.tag_features(200, 12, 3, seed=1), H.identity_features(300)
+    rng = np.random.RandomState(0)
+    st = oracle.State(item_f.shape[1], 300, 16, rng)
+    a, b = st.copy(), st.copy()
+    shuffle, seeds = H.epoch_inputs(coo, rng)
+    zeros = np.zeros_like(coo.data)
+    alpha = 0.001
+    Cm = fast.CSRMatrix
+    fl = fast.FastLightFM(*a.arrays(), a.d, 0, a.lr, a.rho, a.eps, a.max_sampled)
+    pos = H.positives_csr(coo)
+    options.set(mode="parallel", launches_per_epoch=3)
+    if loss == "warp":
+        fast.fit_warp(Cm(item_f), Cm(user_f), Cm(pos), coo.row, coo.col, coo.data, zeros, shuffle, fl, 0.05,
+                      alpha, alpha * 2, 1, H.FixedRandom(seeds))
+        oracle.fit_warp(item_f, user_f, pos, coo.row, coo.col, coo.data, zeros, shuffle, b, alpha, alpha * 2,
+                        seeds, oracle.Opts(len(shuffle), rng_mode=1))
+    elif loss == "bpr":
+        fast.fit_bpr(Cm(item_f), Cm(user_f), Cm(pos), coo.row, coo.col, coo.data, zeros, shuffle, fl, 0.05,
+                     alpha, alpha * 2, 1, H.FixedRandom(seeds))
+        oracle.fit_bpr(item_f, user_f, pos, coo.row, coo.col, coo.data, zeros, shuffle, b, alpha, alpha * 2,
+                       seeds, oracle.Opts(len(shuffle), rng_mode=1))
+    else:
+        fast.fit_logistic(Cm(item_f), Cm(user_f), coo.row, coo.col, coo.data, zeros, shuffle, fl, 0.05, alpha,
+                          alpha * 2, 1)
+        oracle.fit_logistic(item_f, user_f, coo.row, coo.col, coo.data, zeros, shuffle, b, alpha, alpha * 2)
+    assert not np.array_equal(b.item_embeddings, st.item_embeddings)  # the regularisation did act
+    H.assert_states_equal(a, b, exact=False, rtol=2e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------- epoch segments ---
+
+def test_epoch_as_segments_visits_every_position_once():
+    """lfm_opts.pos_begin / pos_end: three segments == one epoch.  With frozen weights the per-position
+    (negative, sampled) logs of the segments tile the logs of the single call exactly."""
+    from lightfm_amd import LightFM
+    from lightfm_amd._lightfm_fast import make_opts
+    coo = H.make_interactions(400, 300, 9000, seed=6)
+    m = LightFM(no_components=32, loss="warp", random_state=1)
+    m._initialize(32, 300, 400)
+    s, struct = _session(m, 300, 400, coo)
+    try:
+        # frozen: re-upload the interactions with zero sample weights
+        s.set_interactions(None, np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col), coo.data,
+                           np.zeros_like(coo.data))
+        s.build_positives(400, 300)
+        s.device_shuffle(3, 4)
+        seeds = np.array([77], np.uint32)
+        n = coo.nnz
+        whole, wl = make_opts(n, want_log=True)
+        s.epoch("warp", 0.0, 0.0, 5, 10, seeds, whole)
+        neg = np.full(n, -1, np.int32)
+        sampled = np.zeros(n, np.int32)
+        total = np.zeros(4, np.int64)
+        for b, e in ((0, 2500), (2500, 2501), (2501, n)):
+            o, logs = make_opts(n, want_log=True)
+            o.pos_begin, o.pos_end = b, e
+            s.epoch("warp", 0.0, 0.0, 5, 10, seeds, o)
+            assert o.counters[0] == e - b
+            neg[b:e], sampled[b:e] = logs[0][b:e], logs[1][b:e]
+            total += np.array(list(o.counters))
+        assert np.array_equal(neg, wl[0]) and np.array_equal(sampled, wl[1])
+        assert list(total) == list(whole.counters)
+    finally:
+        s.close()
+
+
+# ------------------------------------------------------- device positives ---
+
+@pytest.mark.parametrize("shape", [(50, 40, 900), (3000, 70000, 200000), (7, 5, 0)])
+def test_device_positives_equal_host_tocsr(shape):
+    """lfm_session_build_positives == interactions.tocsr() with sorted indices (LFM:365-372), with
+    duplicate COO entries (tocsr sums them into one), empty rows and an empty matrix."""
+    from lightfm_amd import LightFM
+    nu, ni, n = shape
+    rng = np.random.RandomState(1)
+    rows = rng.randint(0, nu, size=n).astype(np.int32)
+    cols = rng.randint(0, ni, size=n).astype(np.int32)
+    if n:
+        rows[: n // 10], cols[: n // 10] = rows[n // 10: 2 * (n // 10)], cols[n // 10: 2 * (n // 10)]  # duplicates
+    coo = sp.coo_matrix((np.ones(n, np.float32), (rows, cols)), shape=(nu, ni), dtype=np.float32)
+    want = coo.tocsr()
+    want.sort_indices()
+    m = LightFM(no_components=8, loss="warp", random_state=1)
+    m._initialize(8, ni, nu)
+    s, _ = _session(m, ni, nu, coo)
+    try:
+        indptr, indices = s.download_positives(nu)
+    finally:
+        s.close()
+    assert np.array_equal(indptr, want.indptr)
+    assert np.array_equal(indices, want.indices)
+
+
+def test_fit_with_device_and_host_positives_agree():
+    """Serial mode is bit-exact either way; the lookup matrices are the same matrix."""
+    from lightfm_amd import LightFM, options
+    coo = H.make_interactions(200, 150, 4000, seed=9)
+    out = []
+    for host in (False, True):
+        options.set(mode="serial", host_positives=host)
+        m = LightFM(no_components=16, loss="warp", random_state=4)
+        m.fit(coo, epochs=2)
+        out.append(m)
+    options.set(host_positives=False)
+    assert np.array_equal(out[0].item_embeddings, out[1].item_embeddings)
+    assert np.array_equal(out[0].user_embeddings, out[1].user_embeddings)
+
+
+# ------------------------------------------------------------ merge (local) ---
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "adagrad"])
+def test_local_merge_matches_numpy(mode):
+    """lfm_sessions_merge_local over K = 3 sessions == the numpy restatement of the merge the RCCL
+    path performs (csrc/session.hip: merge_group)."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import make_opts
+    from lightfm_amd.distributed import local_shard
+    from lightfm_amd.lightfm import _Session
+    K, nu, ni, d = 3, 240, 160, 32
+    coo = H.make_interactions(nu, ni, 9000, seed=12)
+    models, sessions, structs = [], [], []
+    base = LightFM(no_components=d, loss="warp", random_state=2)
+    base._initialize(d, ni, nu)
+    start = {n: getattr(base, n).copy() for n in ("item_embeddings", "item_embedding_gradients", "item_biases",
+                                                  "item_bias_gradients")}
+    try:
+        for r in range(K):
+            shard, _ = local_shard(coo, r, K)
+            m = LightFM(no_components=d, loss="warp", random_state=2)
+            m._initialize(d, ni, nu)
+            s, st = _session(m, ni, nu, shard)
+            s.merge_begin(1)
+            s.device_shuffle(10 + r, 20 + r)
+            o, _ = make_opts()
+            o.history = 1 << 30
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([5 + r], np.uint32), o)
+            s.sync_to_host(st)
+            models.append({n: getattr(m, n).copy() for n in start})
+            sessions.append(s)
+            structs.append((m, st))
+        _Session.merge_local(sessions, 1, N.MERGE_MODES[mode])
+        for (m, st), s in zip(structs, sessions):
+            s.sync_to_host(st)
+    finally:
+        for s in sessions:
+            s.close()
+    dW = [mm["item_embeddings"] - start["item_embeddings"] for mm in models]
+    dG = [mm["item_embedding_gradients"] - start["item_embedding_gradients"] for mm in models]
+    db = [mm["item_biases"] - start["item_biases"] for mm in models]
+    dbG = [mm["item_bias_gradients"] - start["item_bias_gradients"] for mm in models]
+    G = start["item_embedding_gradients"] + sum(dG)
+    bG = start["item_bias_gradients"] + sum(dbG)
+    if mode == "sum":
+        W, b = start["item_embeddings"] + sum(dW), start["item_biases"] + sum(db)
+    elif mode == "mean":
+        W, b = start["item_embeddings"] + sum(dW) / K, start["item_biases"] + sum(db) / K
+    else:
+        def rescaled(dx, dg, g0):
+            tot = sum(dg)
+            return sum(x * np.sqrt((g0 + 0.5 * g) / (g0 + 0.5 * tot)) for x, g in zip(dx, dg))
+        W = start["item_embeddings"] + rescaled(dW, dG, start["item_embedding_gradients"])
+        b = start["item_biases"] + rescaled(db, dbG, start["item_bias_gradients"])
+    assert any(np.abs(x).max() > 0 for x in dW)
+    for m, _ in structs:  # every replica holds the merged item tables; user tables are untouched
+        np.testing.assert_allclose(m.item_embeddings, W, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(m.item_embedding_gradients, G, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(m.item_biases, b, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(m.item_bias_gradients, bG, rtol=2e-5, atol=1e-7)
+
+
+def test_load_model_roundtrip():
+    from lightfm_amd import LightFM
+    coo = H.make_interactions(100, 80, 1500, seed=3)
+    m = LightFM(no_components=16, loss="warp", random_state=1)
+    m._initialize(16, 80, 100)
+    s, st = _session(m, 80, 100, coo)
+    try:
+        want = m.item_embeddings.copy() * 3.0
+        m.item_embeddings[...] = want
+        s.load_model(st)
+        m.item_embeddings[...] = 0
+        s.sync_to_host(st)
+    finally:
+        s.close()
+    assert np.array_equal(m.item_embeddings, want)
+
+
+# ---------------------------------------------------------- representations ---
+
+@pytest.mark.parametrize("d", [10, 64, 130])
+def test_representations_match_scipy_products(d):
+    """get_item_representations / get_user_representations with a feature matrix (LFM:991-1047) ==
+    the reference's `features * biases`, `features * embeddings`."""
+    from lightfm_amd import LightFM
+    coo = H.make_interactions(120, 90, 2500, seed=2)
+    item_f = H.tag_features(90, 25, 4, seed=3)
+    user_f = H.tag_features(120, 10, 2, seed=4, normalise=True)
+    m = LightFM(no_components=d, loss="warp", random_state=5)
+    m.fit(coo, item_features=item_f, user_features=user_f, epochs=1)
+    for feats, getter, emb, bias in ((item_f, m.get_item_representations, m.item_embeddings, m.item_biases),
+                                     (user_f, m.get_user_representations, m.user_embeddings, m.user_biases)):
+        b, e = getter(feats)
+        assert e.shape == (feats.shape[0], d) and b.shape == (feats.shape[0],)
+        assert e.dtype == np.float32 and b.dtype == np.float32
+        np.testing.assert_allclose(e, feats * emb, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b, feats * bias, rtol=1e-5, atol=1e-7)
+        b0, e0 = getter()
+        assert b0 is bias and e0 is emb
+    with pytest.raises(ValueError):
+        m.get_item_representations(sp.identity(7, dtype=np.float32, format="csr"))

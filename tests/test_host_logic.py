@@ -119,3 +119,35 @@ def test_fit_without_a_gpu_fails_loudly():
     train = sp.rand(20, 30, density=0.2, format="coo", random_state=1)
     with pytest.raises(_native.HipBackendError):
         LightFM(loss="warp").fit(train)
+
+
+def test_merge_schedule_is_global_and_grows_with_history():
+    """Every rank derives the same segment list from global numbers; the interval between merges
+    grows with the training history from merge_min to merge_max."""
+    from lightfm_amd.distributed import MergePolicy, merge_schedule, segment_positions
+    pol = MergePolicy(merge_k=4, merge_min=1000, merge_max=50000)
+    fr = merge_schedule(0, 200000, 4, pol)
+    assert fr[0] == 0.0 and fr[-1] == 1.0 and np.all(np.diff(fr) > 0)
+    seg = np.diff(fr) * 200000
+    assert abs(seg[0] - 1000) < 1 and seg.max() <= 50000 + 1
+    assert np.all(np.diff(seg[:-1]) >= -1)            # never shrinks (the last one is the remainder)
+    late = merge_schedule(10_000_000, 200000, 4, pol)  # a trained model: merge_max from the start
+    assert len(late) == 5
+    # ranks of different shard sizes get the same NUMBER of segments, covering their shard exactly
+    for n_local in (49999, 50001, 7):
+        pos = segment_positions(fr, n_local)
+        assert len(pos) == len(fr) and pos[0] == 0 and pos[-1] == n_local and np.all(np.diff(pos) >= 0)
+    assert list(merge_schedule(0, 0, 2, pol)) == [0.0, 1.0]
+    auto = merge_schedule(1 << 40, 10 << 20, 8, MergePolicy())  # default merge_max: one launch per rank
+    assert len(auto) == 3  # 10 Mi interactions / (8 * 2^20) -> 2 segments
+
+
+def test_local_shard_rebased_ids():
+    from lightfm_amd.distributed import local_shard
+    from tests import helpers as H
+    coo = H.make_interactions(200, 90, 4000, seed=1)
+    full, bounds = local_shard(coo, 1, 3)
+    reb, b2 = local_shard(coo, 1, 3, rebase=True)
+    assert np.array_equal(bounds, b2)
+    assert reb.shape == (bounds[2] - bounds[1], 90) and reb.nnz == full.nnz
+    assert np.array_equal(reb.row + bounds[1], full.row) and np.array_equal(reb.col, full.col)
