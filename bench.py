@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--merge-k", type=int, default=None)
     ap.add_argument("--merge-max", type=int, default=None)
     for knob in ("update_mode", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "feat_kernel",
-                 "debug", "ramp_k"):
+                 "debug", "ramp_k", "shared_cap"):
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     args = ap.parse_args()
 
@@ -227,7 +227,7 @@ def main():
     from lightfm_amd.options import options
 
     tuned = {k: getattr(args, k) for k in ("update_mode", "first_batch", "launches_per_epoch", "max_waves",
-                                           "warp_kernel", "feat_kernel", "debug", "ramp_k")
+                                           "warp_kernel", "feat_kernel", "debug", "ramp_k", "shared_cap")
              if getattr(args, k) is not None}
     options.set(**tuned)
     policy = MergePolicy()

@@ -127,6 +127,8 @@ typedef struct lfm_opts {
 #define LFM_LOSS_WARP_KOS 3
 
 const char *lfm_last_error(void);
+/* device time (HIP events, ms) of the kernels of this thread's last lfm_*predict_ranks call */
+float lfm_last_kernel_ms(void);
 int lfm_device_count(void);
 /* name (<=255 chars) and CU count of a device; used by bench.py */
 int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hbm_bytes);

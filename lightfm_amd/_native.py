@@ -55,7 +55,7 @@ class LfmOpts(C.Structure):
 
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)
 EXPORTS = (
-    "lfm_last_error", "lfm_device_count", "lfm_device_info",
+    "lfm_last_error", "lfm_last_kernel_ms", "lfm_device_count", "lfm_device_info",
     "lfm_fit_warp", "lfm_fit_bpr", "lfm_fit_logistic", "lfm_fit_warp_kos",
     "lfm_predict", "lfm_predict_ranks", "lfm_auc_from_rank", "lfm_in_positives",
     "lfm_session_create", "lfm_session_set_interactions", "lfm_session_upload_shuffle",
@@ -83,8 +83,9 @@ def lib():
                 "(the HIP backend has no CPU fallback)" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
         l.lfm_last_error.restype = C.c_char_p
+        l.lfm_last_kernel_ms.restype = C.c_float
         for name in EXPORTS:
-            if name != "lfm_last_error":
+            if name not in ("lfm_last_error", "lfm_last_kernel_ms"):
                 getattr(l, name).restype = C.c_int
         _lib = l
     return _lib

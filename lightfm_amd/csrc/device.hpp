@@ -767,8 +767,18 @@ __device__ __forceinline__ int row_len(const DCsr &f, int row)
 struct Scales {
     double item, user;    // scales used when computing representations
     double prod_i, prod_u;  // parallel mode: this wave's pending (1+alpha*avg) factors
+    double item0, user0;  // parallel mode: the global scales at the start of the launch
+    double nwaves;        // parallel mode: wavefronts sharing the launch
 };
 
+// The reference's scale grows with EVERY interaction (PYX:648-649) and multiplies every
+// representation computed afterwards (PYX:311).  In parallel mode the exact factors are folded
+// into the global scale at the launch boundary (wave_end), but the representations inside the
+// launch must not keep using the launch-start value: at alpha = 1e-4 the scale grows ~20 % per
+// 100 k interactions.  Every wavefront sees a statistically identical stream, so after its own
+// factors have multiplied up to P, the factors of all nwaves wavefronts have multiplied up to
+// about P^nwaves: that estimate scales the representations (capped where the reference would have
+// folded the scale into the weights, PYX:678-691).
 __device__ __forceinline__ void apply_scale_step(Scales &sc, double avg, double ia, double ua,
                                                  bool serial)
 {
@@ -779,6 +789,8 @@ __device__ __forceinline__ void apply_scale_step(Scales &sc, double avg, double 
     } else {
         sc.prod_i *= (1.0 + ia * avg);
         sc.prod_u *= (1.0 + ua * avg);
+        sc.item = fmin(sc.item0 * pow(sc.prod_i, sc.nwaves), MAX_REG_SCALE);
+        sc.user = fmin(sc.user0 * pow(sc.prod_u, sc.nwaves), MAX_REG_SCALE);
     }
 }
 

@@ -41,6 +41,15 @@ namespace {
 
 typedef __attribute__((address_space(3))) float lds_f32_t;
 
+// One round (<= 64 entries) of a flat entry list: lane t holds entry t.
+struct Entries {
+    int feat;    // feature (embedding row) of the entry
+    float w;     // its weight in the representation
+    int job;     // which job of the list it belongs to
+    int eside;   // 0 item-side tables, 1 user-side tables
+    int n;       // entries in the round (wave-uniform)
+};
+
 }  // namespace
 
 // LOSS: LFM_LOSS_* (0 logistic, 1 WARP, 2 BPR, 3 k-OS WARP).  NC = ceil(d / 64).
@@ -125,8 +134,10 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         }
     };
 
-    // ---- representations of J jobs -> tile rows rrow[j]  (compute_representation, PYX:287-317)
-    auto build_reps = [&](int row, int side, int rrow, int J) {
+    // ---- representations of J jobs -> tile rows rrow[j]  (compute_representation, PYX:287-317).
+    // When the whole flat list fits one round (<= 64 entries) it is handed back in `keep` so that
+    // an update of the same jobs need not fetch it again.
+    auto build_reps = [&](int row, int side, int rrow, int J, Entries *keep) {
         for (int j = 0; j < J; ++j) {  // a job without entries keeps the zero representation
             float *rp = reps + (size_t)read_lane(rrow, j) * TS;
 #pragma unroll
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         }
         int start, len, off, T;
         job_extent(row, side, J, start, len, off, T);
+        if (keep) keep->n = -1;
         int cur = -1;
         float acc[NC], accb = 0.0f;
 #pragma unroll
@@ -152,19 +164,19 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             if (lane == 0) rp[d] = accb;
         };
         for (int r = 0; r * WAVE < T; ++r) {
-            int feat, job, eside;
-            float w;
-            round_entries(r, J, start, len, off, side, T, feat, w, job, eside);
-            const int n_r = min(WAVE, T - r * WAVE);
+            Entries e;
+            round_entries(r, J, start, len, off, side, T, e.feat, e.w, e.job, e.eside);
+            e.n = min(WAVE, T - r * WAVE);
+            if (keep && T <= WAVE) *keep = e;
             float bx = 0.0f;
-            if (lane < n_r) bx = (eside ? a.m.b[1] : a.m.b[0])[feat];
-            for (int ce = 0; ce < n_r; ce += SR) {
-                const int nc = min(SR, n_r - ce);
-                dma_rows(feat, eside, ce, nc, stage, false);
+            if (lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
+            for (int ce = 0; ce < e.n; ce += SR) {
+                const int nc = min(SR, e.n - ce);
+                dma_rows(e.feat, e.eside, ce, nc, stage, false);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 for (int t = ce; t < ce + nc; ++t) {
-                    const int jt = read_lane(job, t);
+                    const int jt = read_lane(e.job, t);
                     if (jt != cur) {
                         if (cur >= 0) flush();
                         cur = jt;
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
                         accb = 0.0f;
                     }
-                    const float wt = read_lanef(w, t), bt = read_lanef(bx, t);
+                    const float wt = read_lanef(e.w, t), bt = read_lanef(bx, t);
                     const float *sr = stage + (size_t)(t - ce) * d;
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
@@ -189,36 +201,48 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         wave_sync();
     };
 
-    // ---- update of the rows of up to three representations (update / warp_update, PYX:454-649):
-    // job j's coordinate cells get g = gj * x[c] with x = xI for item-side rows and xU for
-    // user-side rows; its bias cells get g = gj.
-    auto update_rows = [&](int row, int side, int J, double g0, double g1, double g2, const float (&xI)[NC],
-                           const float (&xU)[NC]) {
-        int start, len, off, T;
-        job_extent(row, side, J, start, len, off, T);
+    // ---- update of the feature rows of one round of a flat list (update / warp_update,
+    // PYX:454-649): job j's coordinate cells get g = gj * x[c] with x = xI for item-side rows and
+    // xU for user-side rows; its bias cells get g = gj.
+    // The reference updates the rows of an interaction one after the other.  Entries that name
+    // DIFFERENT rows commute, so they are all fetched, computed and published together.  A row
+    // that occurs twice (a tag shared by the positive and the negative item; a repeated column)
+    // must see its earlier update: such entries get a "generation" (how many earlier entries name
+    // the same row) and the generations are processed one after the other with a device-scope
+    // fence in between -- rare, and exactly the sequential result.
+    auto update_round = [&](const Entries &e, double g0, double g1, double g2, const float (&xI)[NC],
+                            const float (&xU)[NC]) {
         const int SRh = SR >> 1;
         float *stW = stage, *stG = stage + (size_t)SRh * d;
-        for (int r = 0; r * WAVE < T; ++r) {
-            int feat, job, eside;
-            float w;
-            round_entries(r, J, start, len, off, side, T, feat, w, job, eside);
-            const int n_r = min(WAVE, T - r * WAVE);
-            const bool on = lane < n_r;
-            float *bp = (eside ? a.m.b[1] : a.m.b[0]) + feat, *bgp = (eside ? a.m.bG[1] : a.m.bG[0]) + feat;
+        const bool on = lane < e.n;
+        int gen = 0;
+        for (int t = 0; t + 1 < e.n; ++t) {
+            const int ft = read_lane(e.feat, t), st_ = read_lane(e.eside, t);
+            if (on && lane > t && e.feat == ft && e.eside == st_) ++gen;
+        }
+        float *bp = (e.eside ? a.m.b[1] : a.m.b[0]) + e.feat, *bgp = (e.eside ? a.m.bG[1] : a.m.bG[0]) + e.feat;
+        const double gb = e.job == 0 ? g0 : (e.job == 1 ? g1 : g2);
+        for (int g = 0;; ++g) {
+            const unsigned long long live = __ballot(on && gen == g);
+            if (live == 0ull) break;
+            if (g > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the earlier generation is visible
+            const bool mine = on && gen == g;
             float obW = 0.0f, obG = 1.0f;
-            if (on) {  // bias cells: requested with the first rows, consumed after the last
+            if (mine) {  // bias cells: requested with the first rows, consumed after the last
                 obW = *bp;
                 obG = *bgp;
             }
-            for (int ce = 0; ce < n_r; ce += SRh) {
-                const int nc = min(SRh, n_r - ce);
-                dma_rows(feat, eside, ce, nc, stW, false);
-                dma_rows(feat, eside, ce, nc, stG, true);
+            for (int ce = 0; ce < e.n; ce += SRh) {
+                const int nc = min(SRh, e.n - ce);
+                if (((live >> ce) & ((nc >= 64) ? ~0ull : ((1ull << nc) - 1ull))) == 0ull) continue;
+                dma_rows(e.feat, e.eside, ce, nc, stW, false);
+                dma_rows(e.feat, e.eside, ce, nc, stG, true);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 wave_sync();
                 for (int t = ce; t < ce + nc; ++t) {
-                    const int jt = read_lane(job, t), st_ = read_lane(eside, t), fe = read_lane(feat, t);
-                    const double wt = (double)read_lanef(w, t);
+                    if (!((live >> t) & 1ull)) continue;
+                    const int jt = read_lane(e.job, t), st_ = read_lane(e.eside, t), fe = read_lane(e.feat, t);
+                    const double wt = (double)read_lanef(e.w, t);
                     const double gc = jt == 0 ? g0 : (jt == 1 ? g1 : g2);
                     float *Wp = (st_ ? a.m.W[1] : a.m.W[0]) + (size_t)fe * d;
                     float *Gp = (st_ ? a.m.G[1] : a.m.G[0]) + (size_t)fe * d;
@@ -231,7 +255,13 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                             const float x = st_ ? xU[q] : xI[q];
                             float nW, nG, nM;
                             double lr;
-                            cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, 0.0, nW, nG, nM, lr);
+                            if (a.debug & 8) {  // experiment: float32 cell arithmetic (NOT the reference's)
+                                const float gg = (float)gc * x * (float)wt;
+                                nW = oW - h.lr * rsqrtf(oG) * gg;
+                                nG = oG + gg * gg;
+                            } else {
+                                cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, 0.0, nW, nG, nM, lr);
+                            }
                             publish(Wp + c, nW, oW, um);
                             publish(Gp + c, nG, oG, um);
                         }
@@ -240,15 +270,27 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 wave_sync();
             }
             {
-                const double gb = job == 0 ? g0 : (job == 1 ? g1 : g2);
                 float nW, nG, nM;
                 double lr;
-                cell_math(obW, obG, 0.0f, (double)w, gb, h, 0.0, nW, nG, nM, lr);
-                if (on) {
+                cell_math(obW, obG, 0.0f, (double)e.w, gb, h, 0.0, nW, nG, nM, lr);
+                if (mine) {
                     publish(bp, nW, obW, um);
                     publish(bgp, nG, obG, um);
                 }
             }
+        }
+    };
+    // the same for a list of jobs given as rows (fetches the flat list round by round)
+    auto update_rows = [&](int row, int side, int J, double g0, double g1, double g2, const float (&xI)[NC],
+                           const float (&xU)[NC]) {
+        int start, len, off, T;
+        job_extent(row, side, J, start, len, off, T);
+        for (int r = 0; r * WAVE < T; ++r) {
+            Entries e;
+            round_entries(r, J, start, len, off, side, T, e.feat, e.w, e.job, e.eside);
+            e.n = min(WAVE, T - r * WAVE);
+            if (r > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // rounds are sequential
+            update_round(e, g0, g1, g2, xI, xU);
         }
     };
     auto rep_regs = [&](int r, float (&v)[NC]) {
@@ -291,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
 
         if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
             // fit_logistic, PYX:726-775
-            build_reps(lane == 0 ? user : item, lane == 0 ? 1 : 0, lane, 2);
+            Entries el;
+            build_reps(lane == 0 ? user : item, lane == 0 ? 1 : 0, lane, 2, &el);
             float s = 0.0f;
             if (lane == 1) s = tile_dot(reps, reps + TS, d);
             s = read_lanef(s, 1);
@@ -303,7 +346,9 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             const int yb = (y <= 0.0f) ? 0 : 1;                  // PYX:751-755
             if (yb) c0++;
             const double loss = (double)wgt * (prediction - (double)yb);
-            update_rows(lane == 0 ? item : user, lane == 0 ? 0 : 1, 2, loss, loss, 0.0, Uv, Iv);
+            // jobs in the order of the representation list: user row (x = item), item row (x = user)
+            if (el.n >= 0) update_round(el, loss, loss, 0.0, Uv, Iv);
+            else update_rows(lane == 0 ? user : item, lane == 0 ? 1 : 0, 2, loss, loss, 0.0, Uv, Iv);
             c2++;
             continue;
         } else {
@@ -314,13 +359,14 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 }
             }
             uint32_t state = position_seed(base_seed, (uint64_t)i);
-            const int lo = uni(a.pos.indptr[user]), hi = uni(a.pos.indptr[user + 1]);
+            // requested now, made wave-uniform where first needed (so that it travels with later loads)
+            const int lo_v = a.pos.indptr[user], hi_v = a.pos.indptr[user + 1];
 
             if constexpr (LOSS == LFM_LOSS_BPR_ID) {
                 // fit_bpr, PYX:1118-1169
                 c0++;
                 const uint32_t n_examples = (uint32_t)a.n;
-                int neg = -1, draws = 0;
+                int neg = -1, draws = 0, lo = 0, hi = 0;
                 while (neg < 0) {
                     uint32_t s = state;  // lane j: the stream after min(j + 1, 8) steps
 #pragma unroll
@@ -328,6 +374,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         if (j <= lane) s = lcg(s);
                     int cand = 0;
                     if (lane < 8) cand = a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
+                    lo = uni(lo_v);
+                    hi = uni(hi_v);
                     int used = 8;
                     for (int j = 0; j < 8; ++j) {
                         const int c = read_lane(cand, j);
@@ -343,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     state = (uint32_t)read_lane((int)s, used - 1);
                 }
                 c1 += (unsigned long long)draws;
-                build_reps(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, lane, 3);
+                Entries el;
+                build_reps(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, lane, 3, &el);
                 float sc = 0.0f;
                 if (lane == 1 || lane == 2) sc = tile_dot(reps, reps + (size_t)lane * TS, d);
                 const double pp = (double)read_lanef(sc, 1), np_ = (double)read_lanef(sc, 2);
@@ -356,8 +405,11 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 wave_sync();
                 // PYX:1158: weight * (1 - sigmoid(pp - np)); the difference is narrowed to float32
                 const double loss = (double)wgt * (1.0 - (double)sigmoidf_ref((float)(pp - np_)));
-                update_rows(lane == 0 ? item : (lane == 1 ? neg : user), lane == 2 ? 1 : 0, 3, -loss, loss, loss, Uv,
-                            diff);
+                // jobs in the order of the representation list: user (+loss, x = neg - pos), positive
+                // (-loss, x = user), negative (+loss, x = user)
+                if (el.n >= 0) update_round(el, loss, -loss, loss, Uv, diff);
+                else update_rows(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, 3, loss, -loss, loss,
+                                 Uv, diff);
                 c2++;
                 log_pos(i, neg, draws);
                 continue;
@@ -366,7 +418,10 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 int pos_item = item, prow = 1;
                 double pp = 0.0;
                 bool have_pos = false;  // the positive's score is known (k-OS: before the negatives)
+                int lo = 0, hi = 0;
                 if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) {
+                    lo = uni(lo_v);
+                    hi = uni(hi_v);
                     if (hi == lo) {  // PYX:971-972
                         log_pos(i, -1, 0);
                         continue;
@@ -380,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if (lane >= 1 && lane <= no_pos)  // sample_range, PYX:84-90
                         it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
                     state = (uint32_t)read_lane((int)s, no_pos);
-                    build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos);
+                    build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos, nullptr);
                     if (lane >= 1 && lane <= no_pos) {
                         pair_idx[lane - 1] = it;
                         pair_val[lane - 1] = tile_dot(reps, reps + (size_t)lane * TS, d);
@@ -424,9 +479,11 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         // the first batch gathers user, positive and candidates in one pass
                         const int cand = __shfl(myneg, max(lane - 2, 0), WAVE);
                         build_reps(lane == 0 ? user : (lane == 1 ? pos_item : cand), lane == 0 ? 1 : 0,
-                                   lane < 2 ? lane : cand_base + lane - 2, 2 + nb);
+                                   lane < 2 ? lane : cand_base + lane - 2, 2 + nb, nullptr);
+                        lo = uni(lo_v);
+                        hi = uni(hi_v);
                     } else {
-                        build_reps(myneg, 0, cand_base + lane, nb);
+                        build_reps(myneg, 0, cand_base + lane, nb, nullptr);
                     }
                     float sc = 0.0f;
                     const bool mine = lane >= cand_base && lane < cand_base + nb;

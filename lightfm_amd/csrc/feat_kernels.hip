@@ -34,8 +34,8 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
         const char *w = getenv("LIGHTFM_AMD_FEAT_WAVES_PER_BLOCK");
         wpb_env = w ? atoi(w) : 0;
     }
-    // default budget per wavefront: 7 wavefronts per CU for the wide models, 16 otherwise
-    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024 : (d > 64 ? 22 * 1024 : 10 * 1024);
+    // default budget per wavefront: 13 wavefronts per CU for the wide models, 16 otherwise
+    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024 : (d > 64 ? 12 * 1024 : 6 * 1024);
     g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : (d > 64 ? 1 : 2);
     const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list
     for (;; --cb) {

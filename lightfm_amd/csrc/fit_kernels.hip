@@ -78,6 +78,9 @@ __device__ __forceinline__ void wave_begin(const FitArgs &a, WaveCtx &w, Scales 
     sc.user = a.m.scales[1];
     sc.prod_i = 1.0;
     sc.prod_u = 1.0;
+    sc.item0 = sc.item;
+    sc.user0 = sc.user;
+    sc.nwaves = (double)gridDim.x * (double)(blockDim.x >> 6);
 }
 
 __device__ __forceinline__ void wave_end(const FitArgs &a, WaveCtx &w, Scales &sc)

@@ -20,6 +20,8 @@ struct RanksArgs {
     int32_t rs, d;
     DCsr test, train;
     float *ranks;           // aligned with test.data
+    const int32_t *ulist;   // ranks_mfma_kernel: users that have test interactions
+    int32_t n_ulist;
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)
@@ -57,6 +59,9 @@ hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids,
                                int32_t n_items, int32_t *indices_out, int32_t *indptr_out, int64_t *nnz_out,
                                hipStream_t st);
 hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
+// MFMA pre-filtered variant (d <= 128): false if the shape is outside what it supports
+bool ranks_mfma_supported(int d);
+hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus);
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);
 

@@ -138,6 +138,154 @@ __global__ __launch_bounds__(256) void ranks_kernel(RanksArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// predict_ranks as a tiled dense pass (the "predict-all-items" path): one wavefront owns 32 users
+// and sweeps the item table in tiles of 32; the 32 x 32 scores of a tile come from 32 (d = 64)
+// v_mfma_f32_32x32x2_f32 whose accumulators start at (user bias + item bias) and run over the
+// components in the reference's order.  An MFMA step is a FUSED multiply-add, the reference
+// (PYX:320-334, -ffp-contract=off) rounds every product: the two chains differ by at most
+// eps(u, j) = 4 (d + 2) 2^-24 (|b_u| + |b_j| + |u| |v_j|).  So the MFMA score only PRE-FILTERS: a
+// comparison against a test item's (exact, sequential-dot) score that lands inside +-eps is
+// re-decided with the exact sequential dot.  Ranks therefore stay integer-identical to the
+// reference's.  Train positives are masked by walking each user's sorted train row alongside the
+// item sweep (one 32-bit mask per user and tile) instead of a binary search per (user, item).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MT>
+__global__ __launch_bounds__(64) void ranks_mfma_kernel(RanksArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    const int d = a.d, AS = d + 1, I = a.test.cols;
+    float *A = smem;                                     // [32][AS] user representations, bias at [d]
+    float *thr = A + 32 * AS;                            // [32][MT] exact scores of the test items
+    int *tid = reinterpret_cast<int *>(thr + 32 * MT);   // [32][MT] their item ids
+    int *cnt = tid + 32 * MT;                            // [32][MT] items ranked at or above them
+    float *unorm = reinterpret_cast<float *>(cnt + 32 * MT);  // [32] |u|
+    int *ucnt = reinterpret_cast<int *>(unorm + 32);          // [32] test items of the user in this pass
+    const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
+    const float *vT = a.item_rep;
+    for (int tile = blockIdx.x; tile * 32 < a.n_ulist; tile += gridDim.x) {
+        wave_sync();
+        for (int idx = lane; idx < 32 * AS; idx += WAVE) {
+            const int r = idx / AS, c = idx - r * AS, ui = tile * 32 + r;
+            A[idx] = ui < a.n_ulist ? a.user_rep[(size_t)a.ulist[ui] * a.rs + c] : 0.0f;
+        }
+        wave_sync();
+        const int ui = tile * 32 + col;
+        const bool uok = ui < a.n_ulist;
+        const int user = uok ? a.ulist[ui] : 0;
+        int t_lo = 0, t_hi = 0;
+        if (uok && half == 0) {
+            t_lo = a.test.indptr[user];
+            t_hi = a.test.indptr[user + 1];
+            float n2 = 0.0f;
+            for (int c = 0; c < d; ++c) n2 += A[col * AS + c] * A[col * AS + c];
+            unorm[col] = sqrtf(n2) * 1.0000005f;
+        }
+        int m_max = t_hi - t_lo;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m_max = max(m_max, __shfl_xor(m_max, off, WAVE));
+        for (int p0 = 0; p0 < m_max; p0 += MT) {
+            // ---- this pass's test items: ids and exact scores (PYX:1278-1293)
+            wave_sync();
+            if (half == 0) {
+                const int m = uok ? max(0, min(MT, (t_hi - t_lo) - p0)) : 0;
+                ucnt[col] = m;
+                for (int t = 0; t < m; ++t) {
+                    const int it = a.test.indices[t_lo + p0 + t];
+                    tid[col * MT + t] = it;
+                    thr[col * MT + t] = dense_dot(A + col * AS, vT, (size_t)I, it, d);
+                    cnt[col * MT + t] = 0;
+                }
+            }
+            wave_sync();
+            // train row cursor of the user (lanes 0..31)
+            int tp = 0, tend = 0, next = 0x7fffffff;
+            if (uok && half == 0) {
+                tp = a.train.indptr[user];
+                tend = a.train.indptr[user + 1];
+                if (tp < tend) next = a.train.indices[tp];
+            }
+            for (int j0 = 0; j0 < I; j0 += 32) {
+                const int j = j0 + col;
+                const bool jok = j < I;
+                const float bj = jok ? vT[(size_t)d * I + j] : 0.0f;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    acc[r] = __fadd_rn(A[i * AS + d], bj);
+                }
+                float n2 = 0.0f;
+                for (int k0 = 0; k0 < d; k0 += 2) {
+                    const int k = k0 + half;
+                    const bool kok = k < d;
+                    const float av = kok ? A[col * AS + k] : 0.0f;
+                    const float bv = (kok && jok) ? vT[(size_t)k * I + j] : 0.0f;
+                    n2 += bv * bv;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
+                n2 += __shfl_xor(n2, 32, WAVE);
+                const float nj = sqrtf(n2) * 1.0000005f;
+                // train positives inside [j0, j0 + 32) (PYX:1303-1304)
+                unsigned tmask = 0u;
+                while (next < j0 + 32) {
+                    tmask |= 1u << (next - j0);
+                    ++tp;
+                    next = tp < tend ? a.train.indices[tp] : 0x7fffffff;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int iA = (r & 3) + 8 * (r >> 2), iB = iA + 4, i = half ? iB : iA;
+                    const unsigned um = half ? (unsigned)read_lane((int)tmask, iB) : (unsigned)read_lane((int)tmask, iA);
+                    const int mtA = uni(ucnt[iA]), mtB = uni(ucnt[iB]);
+                    const int mt = max(mtA, mtB), mine = half ? mtB : mtA;
+                    if (mt == 0) continue;
+                    const bool valid = jok && !((um >> col) & 1u);
+                    const float eps = kappa * (fabsf(A[i * AS + d]) + fabsf(bj) + unorm[i] * nj);
+                    const float sc = acc[r];
+                    for (int t = 0; t < mt; ++t) {
+                        const float th = thr[i * MT + t];
+                        const int id = tid[i * MT + t];
+                        const bool live = valid && t < mine && j != id;  // PYX:1317-1319
+                        const float df = sc - th;
+                        bool hit = live && df > eps;
+                        const bool band = live && !(df > eps) && !(df < -eps);
+                        if (__ballot(band) != 0ull) {
+                            if (band) hit = dense_dot(A + i * AS, vT, (size_t)I, j, d) >= th;
+                        }
+                        const unsigned long long hm = __ballot(hit);
+                        const int c = half ? __popc((unsigned)(hm >> 32)) : __popc((unsigned)hm);
+                        if (col == 0 && c) cnt[i * MT + t] += c;
+                    }
+                }
+            }
+            wave_sync();
+            if (half == 0) {
+                const int m = ucnt[col];
+                for (int t = 0; t < m; ++t) a.ranks[t_lo + p0 + t] += (float)cnt[col * MT + t];
+            }
+        }
+    }
+}
+
+bool ranks_mfma_supported(int d) { return d >= 1 && d <= 128; }
+
+hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus)
+{
+    if (a.n_ulist <= 0) return hipSuccess;
+    constexpr int MT = 16;
+    const size_t smem = sizeof(float) * ((size_t)32 * (a.d + 1) + 3 * 32 * MT + 64);
+    const int tiles = (a.n_ulist + 31) / 32;
+    int per_cu = 0;
+    int grid = tiles;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma_kernel<MT>, 64, smem) == hipSuccess && per_cu > 0)
+        grid = std::min(tiles, per_cu * std::max(cus, 1));
+    ranks_mfma_kernel<MT><<<grid, 64, smem, st>>>(a);
+    return hipGetLastError();
+}
+
 __device__ void heap_sift(float *x, int start, int end)
 {
     int root = start;

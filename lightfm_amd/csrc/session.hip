@@ -47,6 +47,9 @@ static int fail(int code, const std::string &msg)
 
 extern "C" const char *lfm_last_error(void) { return g_err.c_str(); }
 
+static thread_local float g_kernel_ms = 0.0f;
+extern "C" float lfm_last_kernel_ms(void) { return g_kernel_ms; }
+
 extern "C" int lfm_device_count(void)
 {
     int n = 0;
@@ -1212,6 +1215,7 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     LFM_TRY(urep.alloc((size_t)usf.rows * rs));
     LFM_TRY(irep.alloc((size_t)itf.rows * rs));
     LFM_TRY(dranks.upload(ranks, (size_t)test->nnz));
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
     HIP_TRY(launch_rep_rows(usf, s->tab[1][0].p, s->tab[1][3].p, s->d, rs, urep.p, s->stream));
     HIP_TRY(launch_rep_rows(itf, s->tab[0][0].p, s->tab[0][3].p, s->d, rs, irep.p, s->stream, 1));
     RanksArgs a;
@@ -1222,8 +1226,25 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.test = dtest.view();
     a.train = dtrain.view();
     a.ranks = dranks.p;
-    HIP_TRY(launch_ranks(a, s->stream));
+    a.ulist = nullptr;
+    a.n_ulist = 0;
+    static const bool mfma_ok = getenv("LIGHTFM_AMD_RANKS_MFMA") == nullptr || atoi(getenv("LIGHTFM_AMD_RANKS_MFMA")) != 0;
+    DBuf<int32_t> ulist;
+    if (mfma_ok && ranks_mfma_supported(s->d)) {
+        // users with test interactions, in tiles of 32 per wavefront
+        std::vector<int32_t> ul;
+        for (int32_t u = 0; u < test->rows; ++u)
+            if (test->indptr[u + 1] > test->indptr[u]) ul.push_back(u);
+        LFM_TRY(ulist.upload(ul.data(), ul.size()));
+        a.ulist = ulist.p;
+        a.n_ulist = (int32_t)ul.size();
+        HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
+    } else {
+        HIP_TRY(launch_ranks(a, s->stream));
+    }
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipEventElapsedTime(&g_kernel_ms, s->ev0, s->ev1));
     return dranks.download(ranks);
 }
 

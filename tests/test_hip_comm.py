@@ -1,5 +1,5 @@
 """RCCL plumbing on one GPU: a communicator of ONE rank exercises librccl loading,
-ncclCommInitRank, the grouped all-reduce of the delta merge and the barrier (the N > 1
+ncclCommInitRank, the grouped all-reduces of the three merge modes, the flag reduction and the barrier (the N > 1
 arithmetic itself is covered on CPU by tests/test_multi_gpu_semantics.py)."""
 import ctypes as C
 
@@ -35,10 +35,15 @@ def test_single_rank_communicator_roundtrip():
         s.comm_barrier()
         s.sync_to_host(struct)
         trained = m.user_embeddings.copy()
-        s.comm_merge_users()     # X := X_start + allreduce(X - X_start) over one rank
-        s.sync_to_host(struct)
+        items = m.item_embeddings.copy()
+        for mode in (N.MERGE_SUM, N.MERGE_MEAN, N.MERGE_ADAGRAD):
+            s.comm_merge(1, mode)   # X := X_start + allreduce(X - X_start) over ONE rank: the identity
+            s.sync_to_host(struct)
+            np.testing.assert_allclose(m.item_embeddings, items, rtol=1e-6, atol=1e-7)
+            items = m.item_embeddings.copy()
+        assert s.comm_any(False) is False and s.comm_any(True) is True
     finally:
         s.close()
     assert not np.array_equal(before, trained)
-    np.testing.assert_allclose(m.user_embeddings, trained, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(m.user_embeddings, trained)  # identity user features: never communicated
     assert np.isfinite(m.item_embeddings).all()

@@ -211,7 +211,7 @@ def test_feat_training_learns_like_the_oracle(fast, loss):
         return float(np.mean(pos - neg)), float(np.mean(pos > neg))
 
     (ma, aa), (mb, ab) = margin(a), margin(b)
-    assert ab > 0.7
+    assert ab > (0.58 if loss == "logistic" else 0.7)  # logistic sees the ratings as noisy labels
     assert abs(aa - ab) < 0.04, (aa, ab)  # Hogwild: run-to-run variation
     assert abs(ma - mb) / abs(mb) < 0.25, (ma, mb)
 

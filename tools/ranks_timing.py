@@ -1,19 +1,25 @@
-"""Wall time of predict_rank / precision_at_k at the ML-20M shape on a subset of users."""
+"""Wall and device time of predict_rank / precision_at_k at the ML-20M shape.
+
+    python tools/ranks_timing.py [n_users (default: all 138,493)]     env LIGHTFM_AMD_RANKS_MFMA=0: scalar kernel
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
-from lightfm_amd import LightFM, synthetic
+from lightfm_amd import LightFM, synthetic, _native as N
 from lightfm_amd.evaluation import precision_at_k
-n_eval = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 data = synthetic.named("ml-20m")
+n_eval = int(sys.argv[1]) if len(sys.argv) > 1 else data.shape[0]
 train, test = synthetic.train_test_split(data, 0.1, seed=1)
 users = np.sort(np.random.RandomState(0).choice(data.shape[0], size=n_eval, replace=False))
 mask = np.zeros(data.shape[0], bool); mask[users] = True
 keep = mask[test.row]
 test_sub = sp.coo_matrix((test.data[keep], (test.row[keep], test.col[keep])), shape=test.shape, dtype=np.float32).tocsr()
-m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=1)
+m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=2)
 train_csr = train.tocsr()
-for _ in range(2):
-    t = time.time(); p = precision_at_k(m, test_sub, train_interactions=train_csr, k=10).mean(); dt = time.time() - t
-    print("precision_at_k over %d users x %d items: %.2fs (%.1f M user-item scores/s), p@10 %.4f" % (
-        n_eval, data.shape[1], dt, n_eval * data.shape[1] / dt / 1e6, p), flush=True)
+for _ in range(3):
+    t = time.time(); p = precision_at_k(m, test_sub, train_interactions=train_csr, k=10, check_intersections=False).mean(); dt = time.time() - t
+    kms = N.lib().lfm_last_kernel_ms()
+    pairs = float(n_eval) * data.shape[1]
+    print("precision_at_k over %d users x %d items (%d test interactions): wall %.2fs, kernels %.1f ms = %.1f G user-item "
+          "scores/s (%.2f TFLOP/s of 2*d flops), p@10 %.4f" % (n_eval, data.shape[1], test_sub.nnz, dt, kms,
+          pairs / kms / 1e6, 2 * 64 * pairs / kms / 1e9, p), flush=True)
