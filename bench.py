@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the interactions (debug)")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="debug, N = 1: run rank 0's row shard of a K-way strong-scaling split on this one GPU")
     ap.add_argument("--epochs-per-step", type=int, default=0, help="0 = calibrate so the timed region is >= ~6 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
@@ -245,6 +247,10 @@ def main():
     want_quality = world == 1 and not args.no_quality and cfg["shape"] == "ml-20m"
     train, feats, test, global_n, n_users, n_items = build_workload(args.config, rank, world, scaling, args.scale,
                                                                      want_quality)
+    if args.emulate_shard > 1 and world == 1:
+        from lightfm_amd.distributed import local_shard
+        train, _ = local_shard(train, 0, args.emulate_shard, rebase=True)
+        n_users, global_n, want_quality = train.shape[0], train.nnz, False
     log("generated %d interactions (%d x %d) in %.1fs" % (train.nnz, n_users, n_items, time.time() - t0))
     loss, d = cfg["loss"], cfg["d"]
     n_item_feat = feats.shape[1] if feats is not None else n_items

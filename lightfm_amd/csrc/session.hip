@@ -994,6 +994,17 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const int64_t flight = (int64_t)max_grid * wpb * per_wave;
             int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
+            if (reg) {
+                // The reference folds the lazy-regularisation scale into the weights as soon as it
+                // passes MAX_REG_SCALE (locked_regularize, PYX:678-691, tested after EVERY
+                // interaction).  Here that test runs at launch boundaries, so a launch must not let
+                // the scale grow by more than that: every interaction multiplies it by at most
+                // (1 + alpha * lr) (adagrad: lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
+                const double lr_max = s->adadelta ? 1.0 : (double)s->lr;
+                const double step = std::max(item_alpha, user_alpha) * std::max(lr_max, 1e-12);
+                const double max_len = log(MAX_REG_SCALE) / log1p(step);
+                if (max_len < (double)len) len = std::max<int64_t>(1, (int64_t)max_len);
+            }
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
@@ -1228,7 +1239,8 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.ranks = dranks.p;
     a.ulist = nullptr;
     a.n_ulist = 0;
-    static const bool mfma_ok = getenv("LIGHTFM_AMD_RANKS_MFMA") == nullptr || atoi(getenv("LIGHTFM_AMD_RANKS_MFMA")) != 0;
+    const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");  // 0: the scalar kernel (tests compare the two)
+    const bool mfma_ok = mfma_env == nullptr || atoi(mfma_env) != 0;
     DBuf<int32_t> ulist;
     if (mfma_ok && ranks_mfma_supported(s->d)) {
         // users with test interactions, in tiles of 32 per wavefront

@@ -96,3 +96,36 @@ def test_intersecting_train_and_test_is_rejected(fitted):
     with pytest.raises(ValueError):
         precision_at_k(model, train, train_interactions=train)
     precision_at_k(model, train, train_interactions=train, check_intersections=False)
+
+
+def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
+    """predict_ranks through the MFMA pre-filter (csrc/predict_kernels.hip: ranks_mfma_kernel) and
+    through the scalar sequential-dot kernel on a TRAINED model at the ML-20M item count: every rank
+    identical (the MFMA score only decides comparisons outside its rounding band)."""
+    import os
+    import scipy.sparse as sp
+    from lightfm_amd import LightFM, synthetic
+    data = synthetic.make_interactions(6000, 26744, 900000, seed=5)
+    train, test = synthetic.train_test_split(data, 0.1, seed=1)
+    m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=3)
+    ranks = {}
+    try:
+        for name, env in (("mfma", "1"), ("scalar", "0")):
+            os.environ["LIGHTFM_AMD_RANKS_MFMA"] = env
+            ranks[name] = m.predict_rank(test, train_interactions=train, check_intersections=False)
+    finally:
+        os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
+    assert ranks["mfma"].nnz == test.nnz and ranks["mfma"].data.max() > 100
+    assert np.array_equal(ranks["mfma"].data, ranks["scalar"].data)
+    # heavy users (more test items than one pass of the kernel holds) and an odd no_components
+    m2 = LightFM(no_components=33, loss="bpr", random_state=2).fit(train, epochs=1)
+    heavy = sp.coo_matrix((np.ones(300, np.float32), (np.repeat([3, 4000], 150), np.tile(np.arange(150) * 7, 2))),
+                          shape=test.shape, dtype=np.float32)
+    out = {}
+    try:
+        for name, env in (("mfma", "1"), ("scalar", "0")):
+            os.environ["LIGHTFM_AMD_RANKS_MFMA"] = env
+            out[name] = m2.predict_rank(heavy, check_intersections=False)
+    finally:
+        os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
+    assert np.array_equal(out["mfma"].data, out["scalar"].data)

@@ -1,7 +1,7 @@
 """N > 1 path on CPU: two processes over gloo.  Checks the host logic of
-lightfm_amd/distributed.py (shard plan, per-rank seeds) and the per-epoch merge semantics the
-device code implements with RCCL (csrc/session.hip: merge_side) -- here with the CPU oracle
-running each rank's epoch and torch.distributed(gloo) carrying the delta all-reduce.
+lightfm_amd/distributed.py (shard plan, per-rank seeds, the global merge schedule) and the merge
+semantics the device code implements with RCCL (csrc/session.hip: merge_group) -- here with the
+CPU oracle running each rank's segments and torch.distributed(gloo) carrying the all-reduces.
 """
 import os
 import socket
@@ -49,6 +49,67 @@ def _free_port():
     return port
 
 
+def _merge(mode, start, local_list_or_none, local, allsum, world):
+    """numpy restatement of csrc/session.hip merge_group for the item side (one rank's view)."""
+    dW = {n: (local[n] - start[n]).astype(np.float32) for n in start}
+    out = {}
+    G_names = {"item_embeddings": "item_embedding_gradients", "item_biases": "item_bias_gradients"}
+    if mode == "adagrad":
+        tot = {g: allsum(dW[g]) for g in G_names.values()}
+        for w, g in G_names.items():
+            num = start[g] + 0.5 * dW[g]
+            den = start[g] + 0.5 * tot[g]
+            scale = np.where(den > num, np.sqrt(num / den), 1.0).astype(np.float32)
+            out[w] = (start[w] + allsum((dW[w] * scale).astype(np.float32))).astype(np.float32)
+            out[g] = (start[g] + tot[g]).astype(np.float32)
+    else:
+        for n in start:
+            total = allsum(dW[n])
+            if mode == "mean" and n in G_names:
+                total = total / np.float32(world)
+            out[n] = (start[n] + total).astype(np.float32)
+    return out
+
+
+ITEM_NAMES = ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients")
+USER_NAMES = ("user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients")
+
+
+def _policy():
+    from lightfm_amd.distributed import MergePolicy
+    return MergePolicy(merge_k=2, merge_min=150, merge_max=900, mode="adagrad")
+
+
+def _rank_epochs(rank, world, coo, st, allsum, epochs=2):
+    """What DistributedFit.run does on one rank, with the CPU oracle as the epoch engine: segments of
+    the rank's shuffled shard from the GLOBAL schedule, a merge of the item tables after each."""
+    from lightfm_amd.distributed import local_shard, merge_schedule, rank_seed, segment_positions
+    from oracle import oracle
+    from tests import helpers as H
+    nu, ni = coo.shape
+    shard, bounds = local_shard(coo, rank, world)
+    item_f, user_f = H.identity_features(ni), H.identity_features(nu)
+    rng = np.random.RandomState(rank_seed(11, rank))
+    pol = _policy()
+    history, merges = 0, 0
+    pos_csr = H.positives_csr(shard)
+    for _ in range(epochs):
+        shuffle, seeds = H.epoch_inputs(shard, rng)
+        pos = segment_positions(merge_schedule(history, coo.nnz, world, pol), shard.nnz)
+        for j in range(len(pos) - 1):
+            start = {n: getattr(st, n).copy() for n in ITEM_NAMES}
+            sub = np.ascontiguousarray(shuffle[pos[j]:pos[j + 1]])
+            if len(sub):
+                oracle.fit_warp(item_f, user_f, pos_csr, shard.row, shard.col, shard.data, shard.data, sub, st,
+                                0.0, 0.0, seeds)
+            merged = _merge(pol.mode, start, None, {n: getattr(st, n) for n in ITEM_NAMES}, allsum, world)
+            for n in ITEM_NAMES:
+                getattr(st, n)[...] = merged[n]
+            merges += 1
+        history += coo.nnz
+    return bounds, merges
+
+
 def _worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
@@ -56,82 +117,90 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from lightfm_amd.distributed import local_shard, merge_deltas, rank_seed
         from oracle import oracle
         from tests import helpers as H
         nu, ni, d = 120, 80, 16
         coo = H.make_interactions(nu, ni, 3000, seed=5)
-        shard, bounds = local_shard(coo, rank, world)
         st = oracle.State(ni, nu, d, np.random.RandomState(3))  # identical start on all ranks
-        item_f, user_f = H.identity_features(ni), H.identity_features(nu)
-        rng = np.random.RandomState(rank_seed(11, rank))
 
         def allsum(x):
-            t = torch.from_numpy(np.ascontiguousarray(x))
+            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32).copy())
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return t.numpy()
 
-        item_names = ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients")
-        user_names = ("user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients")
-        user_start = {n: getattr(st, n).copy() for n in user_names}
-        for _ in range(2):
-            start = {n: getattr(st, n).copy() for n in item_names}
-            shuffle, seeds = H.epoch_inputs(shard, rng)
-            oracle.fit_warp(item_f, user_f, H.positives_csr(shard), shard.row, shard.col, shard.data,
-                            shard.data, shuffle, st, 0.0, 0.0, seeds)
-            for n in item_names:  # per-epoch merge of the replicated item side
-                getattr(st, n)[...] = merge_deltas(start[n], getattr(st, n), allsum)
-        for n in user_names:  # final union of the partitioned user side
-            getattr(st, n)[...] = merge_deltas(user_start[n], getattr(st, n), allsum)
-        np.savez(out % rank, bounds=bounds, **{n: getattr(st, n) for n in item_names + user_names})
+        bounds, merges = _rank_epochs(rank, world, coo, st, allsum)
+        # the user rows of the other rank arrive once at the end (host plane): DistributedFit.gather_users
+        for n in USER_NAMES:
+            a = getattr(st, n)
+            for r in range(world):
+                b0, b1 = int(bounds[r]), int(bounds[r + 1])
+                t = torch.from_numpy(np.ascontiguousarray(a[b0:b1]))
+                dist.broadcast(t, src=r)
+                a[b0:b1] = t.numpy()
+        np.savez(out % rank, bounds=bounds, merges=merges, **{n: getattr(st, n) for n in ITEM_NAMES + USER_NAMES})
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_merge_matches_single_process_emulation(tmp_path):
+def test_two_rank_gloo_schedule_matches_single_process_emulation(tmp_path):
     """World size 2 over gloo == the same algorithm emulated in one process: both replicas start
-    from the same tables, train their shard, item-side deltas are summed per epoch, user rows
-    are a disjoint union."""
+    from the same tables, train the segments of the global merge schedule on their shard, the item
+    tables are merged after every segment (LFM_MERGE_ADAGRAD arithmetic), user rows are a disjoint
+    union.  Both ranks must make the same number of collective calls (else this test hangs)."""
     import torch.multiprocessing as mp
-    from lightfm_amd.distributed import local_shard, rank_seed
+    from lightfm_amd.distributed import local_shard
     from oracle import oracle
     from tests import helpers as H
     world, port = 2, _free_port()
     out = str(tmp_path / "rank%d.npz")
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = [np.load(out % r) for r in range(world)]
+    assert int(got[0]["merges"]) == int(got[1]["merges"]) > 4
 
+    # single-process emulation: the ranks advance segment by segment in lockstep
+    import threading
     nu, ni, d = 120, 80, 16
     coo = H.make_interactions(nu, ni, 3000, seed=5)
-    item_f, user_f = H.identity_features(ni), H.identity_features(nu)
-    item_names = ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients")
-    user_names = ("user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients")
     states = [oracle.State(ni, nu, d, np.random.RandomState(3)) for _ in range(world)]
-    rngs = [np.random.RandomState(rank_seed(11, r)) for r in range(world)]
-    shards = [local_shard(coo, r, world)[0] for r in range(world)]
-    ustart = {n: getattr(states[0], n).copy() for n in user_names}
-    for _ in range(2):
-        start = {n: getattr(states[0], n).copy() for n in item_names}
-        for r in range(world):
-            shuffle, seeds = H.epoch_inputs(shards[r], rngs[r])
-            oracle.fit_warp(item_f, user_f, H.positives_csr(shards[r]), shards[r].row, shards[r].col,
-                            shards[r].data, shards[r].data, shuffle, states[r], 0.0, 0.0, seeds)
-        for n in item_names:
-            total = sum((getattr(s, n) - start[n]).astype(np.float32) for s in states)
-            merged = (start[n] + total).astype(np.float32)
-            for s in states:
-                getattr(s, n)[...] = merged
-    for n in user_names:
-        total = sum((getattr(s, n) - ustart[n]).astype(np.float32) for s in states)
-        for s in states:
-            getattr(s, n)[...] = (ustart[n] + total).astype(np.float32)
+    barrier = threading.Barrier(world)
+    pending, results = {}, {}
+    lock = threading.Lock()
 
+    def make_allsum(rank):
+        calls = [0]
+
+        def allsum(x):
+            key = calls[0]
+            calls[0] += 1
+            with lock:
+                pending.setdefault(key, []).append(np.asarray(x, np.float32).copy())
+            barrier.wait()
+            with lock:
+                if key not in results:
+                    results[key] = np.sum(pending[key], axis=0, dtype=np.float32)
+            barrier.wait()
+            return results[key].copy()
+        return allsum
+
+    threads = [threading.Thread(target=_rank_epochs, args=(r, world, coo, states[r], make_allsum(r)))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    bounds = local_shard(coo, 0, world)[1]
     for r in range(world):
-        assert np.array_equal(got[r]["bounds"], local_shard(coo, r, world)[1])
-        for n in item_names + user_names:
+        assert np.array_equal(got[r]["bounds"], bounds)
+        for n in ITEM_NAMES:
             np.testing.assert_allclose(got[r][n], getattr(states[0], n), rtol=1e-6, atol=1e-7, err_msg=n)
+            np.testing.assert_allclose(got[r][n], getattr(states[1], n), rtol=1e-6, atol=1e-7, err_msg=n)
+        for n in USER_NAMES:
+            for q in range(world):
+                b0, b1 = int(bounds[q]), int(bounds[q + 1])
+                np.testing.assert_allclose(got[r][n][b0:b1], getattr(states[q], n)[b0:b1], rtol=1e-6, atol=1e-7,
+                                           err_msg=n)
     # every user row was trained by exactly one rank: the union changed rows of both shards
-    b = got[0]["bounds"]
-    moved = np.any(got[0]["user_embeddings"] != oracle.State(ni, nu, d, np.random.RandomState(3)).user_embeddings, axis=1)
-    assert moved[: b[1]].any() and moved[b[1]:].any()
+    fresh = oracle.State(ni, nu, d, np.random.RandomState(3)).user_embeddings
+    moved = np.any(got[0]["user_embeddings"] != fresh, axis=1)
+    assert moved[: bounds[1]].any() and moved[bounds[1]:].any()
