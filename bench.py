@@ -413,8 +413,8 @@ def main():
             m.fit(q_train, item_features=feats, epochs=q_epochs)
             quality = {"epochs": q_epochs, "precision_at_10": precision_at_10(m, q_train, q_test, feats),
                        "eval_users": 4000, "data": q_note,
-                       "metric": "precision_at_k(k=10) of lightfm/evaluation.py:14-87 on a held-out 5% of the "
-                                 "same synthetic process; both backends fit %d epochs from the same seed" % q_epochs}
+                       "metric": "precision_at_k(k=10) of lightfm/evaluation.py:14-87 on a held-out 5 percent of "
+                                 "the same synthetic process; both backends fit %d epochs from the same seed" % q_epochs}
         if not args.no_cpu_baseline:
             try:
                 if cfg["shape"] == "ml-20m":

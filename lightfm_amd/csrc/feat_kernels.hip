@@ -34,9 +34,14 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
         const char *w = getenv("LIGHTFM_AMD_FEAT_WAVES_PER_BLOCK");
         wpb_env = w ? atoi(w) : 0;
     }
-    // default budget per wavefront: 13 wavefronts per CU for the wide models, 16 otherwise
-    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024 : (d > 64 ? 12 * 1024 : 6 * 1024);
-    g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : (d > 64 ? 1 : 2);
+    // default budget per wavefront (8 wavefronts run per CU, session.hip): the representation tile
+    // of the loss plus a staging area of >= 16 rows (C3 sweep: 20 staged rows at 8 wavefronts per CU
+    // beat 38 rows at 7), at most 19 KiB
+    const size_t tile_bytes = (size_t)(g.cand_base + cb) * g.ts * 4 + 3 * (size_t)g.pair_cap * 4;
+    const size_t floor_b = d > 64 ? 12 * 1024 : 6 * 1024;
+    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024
+                                        : std::min<size_t>(19 * 1024, std::max(floor_b, tile_bytes + (size_t)16 * d * 4 + 256));
+    g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : 1;
     const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list
     for (;; --cb) {
         g.rr = g.cand_base + cb;

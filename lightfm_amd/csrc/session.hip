@@ -368,13 +368,14 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     s->lr = model->lr;
     s->rho = model->rho;
     s->eps = model->eps;
-    // Tables that fit the L2s stay cached (small models, the parity tests' serial mode); beyond
-    // the 32 MiB of aggregate L2 they are allocated uncached (see table_alloc_flags).
+    // Tables that fit ONE XCD's 4 MiB L2 stay cached (small models, the parity tests); beyond that
+    // they are allocated uncached (see table_alloc_flags): measured on a 1/8 row shard of the
+    // ML-20M shape (23 MB of tables) 880 vs 726 M interactions/s.
     size_t table_bytes = 0;
     for (int side = 0; side < 2; ++side)
         for (int k = 0; k < 6; ++k)
             if (kind_used(s, k)) table_bytes += tab_count(s, side, k) * sizeof(float);
-    const bool big_tables = table_bytes > (32u << 20) || getenv("LIGHTFM_AMD_TABLE_ALLOC") != nullptr;
+    const bool big_tables = table_bytes > (4u << 20) || getenv("LIGHTFM_AMD_TABLE_ALLOC") != nullptr;
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
             s->tab[side][k].flags = (big_tables && ((table_alloc_mask() >> k) & 1)) ? table_alloc_flags() : 0;
@@ -985,7 +986,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 a.tile_stride = t.stride;
                 a.first_batch = t.first_batch;
             }
-            const size_t cu_blocks = use_feat ? (size_t)(16 / wpb) : 8;  // at most 16 wavefronts per CU
+            // row-stream kernels: 8 wavefronts per CU publish fastest (C3: 43 M/s at 2 048 interactions
+            // in flight against 35 M/s at 3 072 -- the float atomics queue up in the fabric)
+            const size_t cu_blocks = use_feat ? (size_t)(8 / wpb) : 8;
             const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
             const bool below_residency = allowed / (wpb * per_wave) < max_grid;
@@ -995,14 +998,18 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
             if (reg) {
-                // The reference folds the lazy-regularisation scale into the weights as soon as it
-                // passes MAX_REG_SCALE (locked_regularize, PYX:678-691, tested after EVERY
-                // interaction).  Here that test runs at launch boundaries, so a launch must not let
-                // the scale grow by more than that: every interaction multiplies it by at most
-                // (1 + alpha * lr) (adagrad: lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
+                // Lazy regularisation in parallel mode.  The reference multiplies a global scale by
+                // (1 + alpha * avg_lr) per interaction and folds it into the weights once it passes
+                // MAX_REG_SCALE (PYX:640-691); between two folds every representation is multiplied
+                // by the current scale.  Thousands of concurrent interactions cannot follow a scale
+                // that moves by orders of magnitude inside one launch, so here the scale is folded
+                // into the weights at EVERY launch boundary (the fold is exact algebra: W / s with
+                // s reset to 1) and a launch is cut short enough for the scale to at most double
+                // inside it: every interaction multiplies it by at most 1 + alpha * lr (adagrad:
+                // lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
                 const double lr_max = s->adadelta ? 1.0 : (double)s->lr;
                 const double step = std::max(item_alpha, user_alpha) * std::max(lr_max, 1e-12);
-                const double max_len = log(MAX_REG_SCALE) / log1p(step);
+                const double max_len = log(2.0) / log1p(step);
                 if (max_len < (double)len) len = std::max<int64_t>(1, (int64_t)max_len);
             }
             a.begin = begin;
@@ -1034,7 +1041,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
-                HIP_TRY(launch_regularize(a.m, 0, s->stream));  // PYX:901-904
+                HIP_TRY(launch_regularize(a.m, 1, s->stream));  // fold now (see above); PYX:652-675
             }
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp

@@ -92,7 +92,6 @@ __device__ __forceinline__ int row_bcast(int v, int k)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(4))) float cfloat_t;  // constant address space: uniform loads are s_load
 
 // Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
 __device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi)
@@ -272,15 +271,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                 p4 = ldp<VEC>(gl ? Wi + (size_t)c_pos * d + VEC * p : Wi);
             }
             float bu = 0.0f;
-            const bool scalar_bias = (a.debug & 16) != 0 && LPR < 64;  // experiment: biases through the scalar cache
-            if (scalar_bias) {
-                const cfloat_t *cu = (const cfloat_t *)bu_tab;
-#pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    const float v = cu[__builtin_amdgcn_readlane(c_user, gg * LPR)];
-                    bu = (g == gg) ? v : bu;
-                }
-            } else if (act) bu = bu_tab[c_user];
+            if (act) bu = bu_tab[c_user];
             uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
             if constexpr (!DMA) {
                 if (gl) {
@@ -340,21 +331,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                 const int myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);  // PYX:860-861
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
-                if (scalar_bias && nb <= 10) {
-                    // the bias tables read here are per-launch snapshots (session.hip): constant for
-                    // the kernel, so the 4-byte lookups can go through the scalar cache (s_load_dword)
-                    // instead of occupying the vector memory pipeline
-                    const cfloat_t *ci = (const cfloat_t *)bi_tab;
-#pragma unroll
-                    for (int gg = 0; gg < NG; ++gg) {
-#pragma unroll
-                        for (int k = 0; k <= 10; ++k) {
-                            const int src = gg * LPR + min(k, nb);
-                            const float v = ci[__builtin_amdgcn_readlane(myitem, src)];
-                            bi = (lane == src) ? v : bi;
-                        }
-                    }
-                } else if (rowlane) bi = bi_tab[myitem];
+                if (rowlane) bi = bi_tab[myitem];
                 // up to 10 candidate rows per round, ALL requested before the first is staged
                 const bool gln = need && pc;
                 if constexpr (DMA) {
