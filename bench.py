@@ -385,7 +385,12 @@ def main():
                 "draws_per_interaction": counters[1] / max(1.0, counters[0]),
                 "updates_per_interaction": counters[2] / max(1.0, counters[0])}
 
-    if options.warp_kernel == 2:  # profiling build: per-phase shader cycles per wavefront pass
+    if options.feat_kernel == 2 and used == 2:  # profiling build of the row-stream kernel
+        ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
+        roofline["phase_cycles_per_interaction"] = dict(zip(
+            ("sampling", "entry_lists", "rep_gather", "rep_reduce", "score", "update_gather", "update_math_publish",
+             "tail"), [round(float(x) / max(1.0, counters[0]), 1) for x in ph]))
+    if options.warp_kernel == 2 and used == 1:  # profiling build: per-phase shader cycles per wavefront pass
         ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
         passes = counters[0] / float(max(1, ng))
         roofline["phase_cycles_per_pass"] = dict(zip(

@@ -88,7 +88,8 @@ typedef struct lfm_opts {
     int32_t feat_kernel;        /* parallel mode, models the lane-group tile kernel does not cover
                                    (feature CSRs, BPR, k-OS, logistic): 0 = auto (the pipelined
                                    row-stream kernels, csrc/feat_kernel.hpp, when d <= 128 and
-                                   alpha == 0), 1 = force the generic kernels                   */
+                                   alpha == 0), 1 = force the generic kernels, 2 = row-stream kernels
+                                   instrumented with per-phase cycle counters (BPR / k-OS, d > 64) */
     int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
                                    regularisation: 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
@@ -96,7 +97,7 @@ typedef struct lfm_opts {
                                    2 = tile kernel instrumented with per-phase cycle counters */
     int32_t debug;              /* kernel experiments; bits 0-2: force the tile kernel's
                                    interactions per wavefront pass (1, 2 or 4); 0 = auto */
-    int64_t phase_cycles[8];    /* out, warp_kernel = 2 (profiling build of the tile kernel): shader
+    int64_t phase_cycles[8];    /* out, warp_kernel = 2 / feat_kernel = 2 (profiling builds): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator
                                    loads, 5 cell arithmetic + atomics, 6 tail */

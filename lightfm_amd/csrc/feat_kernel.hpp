@@ -53,9 +53,24 @@ struct Entries {
 }  // namespace
 
 // LOSS: LFM_LOSS_* (0 logistic, 1 WARP, 2 BPR, 3 k-OS WARP).  NC = ceil(d / 64).
-template <int LOSS, int NC>
+// TIMED (profiling builds, lfm_opts.feat_kernel = 2): every wavefront accumulates shader-clock
+// deltas per phase of an interaction into a.counters[4..11] -- 0 record / sampling loads and
+// in_positives, 1 CSR extents + entry lists, 2 representation row gathers, 3 reduction into the
+// tile, 4 scoring and loss, 5 update row gathers (W and G), 6 cell arithmetic + publication,
+// 7 everything else (loop tail, logs).
+template <int LOSS, int NC, bool TIMED = false>
 __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
 {
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TIMED) {
+            if (a.debug & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain: pure phases
+            unsigned long long t = __builtin_readcyclecounter();
+            ph[k] += t - tprev;
+            tprev = t;
+        }
+    };
+    if constexpr (TIMED) tprev = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id(), wib = uni((int)(threadIdx.x >> 6));
     const int d = a.m.d, TS = a.tile_stride, RR = a.tile_rows, SR = a.stage_rows;
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             if (lane == 0) rp[d] = 0.0f;
         }
         int start, len, off, T;
+        stamp(0);
         job_extent(row, side, J, start, len, off, T);
         if (keep) keep->n = -1;
         int cur = -1;
@@ -170,11 +186,14 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             if (keep && T <= WAVE) *keep = e;
             float bx = 0.0f;
             if (lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
+            if constexpr (TIMED) asm volatile("" : "+v"(e.feat), "+v"(e.w));
+            stamp(1);
             for (int ce = 0; ce < e.n; ce += SR) {
                 const int nc = min(SR, e.n - ce);
                 dma_rows(e.feat, e.eside, ce, nc, stage, false);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
+                stamp(2);
                 for (int t = ce; t < ce + nc; ++t) {
                     const int jt = read_lane(e.job, t);
                     if (jt != cur) {
@@ -195,10 +214,12 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     accb = __fadd_rn(accb, __fmul_rn(wt, bt));
                 }
                 wave_sync();  // the stage is rewritten by the next chunk
+                stamp(3);
             }
         }
         if (cur >= 0) flush();
         wave_sync();
+        stamp(3);
     };
 
     // ---- update of the feature rows of one round of a flat list (update / warp_update,
@@ -216,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         float *stW = stage, *stG = stage + (size_t)SRh * d;
         const bool on = lane < e.n;
         int gen = 0;
+        stamp(4);
         for (int t = 0; t + 1 < e.n; ++t) {
             const int ft = read_lane(e.feat, t), st_ = read_lane(e.eside, t);
             if (on && lane > t && e.feat == ft && e.eside == st_) ++gen;
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 dma_rows(e.feat, e.eside, ce, nc, stG, true);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 wave_sync();
+                stamp(5);
                 for (int t = ce; t < ce + nc; ++t) {
                     if (!((live >> t) & 1ull)) continue;
                     const int jt = read_lane(e.job, t), st_ = read_lane(e.eside, t), fe = read_lane(e.feat, t);
@@ -268,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     }
                 }
                 wave_sync();
+                stamp(6);
             }
             {
                 float nW, nG, nM;
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     publish(bgp, nG, obG, um);
                 }
             }
+            stamp(6);
         }
     };
     // the same for a list of jobs given as rows (fetches the flat list round by round)
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         int row2 = 0;
         if (i + 2 * nw < a.end) row2 = a.shuffle[i + 2 * nw];
         if (i + nw < a.end) nxt = fetch(row1);
+        stamp(7);
         const int user = uni(cur.x), item = uni(cur.y);
         const float y = unif(__int_as_float(cur.z)), wgt = unif(__int_as_float(cur.w));
         cur = nxt;
@@ -529,6 +555,11 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 log_pos(i, chosen, sampled);
             }
         }
+    }
+    if constexpr (TIMED) {
+        stamp(7);
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(a.counters + 4 + k, ph[k]);
     }
     if (lane == 0) {
         if (c0) atomicAdd(a.counters + 0, c0);

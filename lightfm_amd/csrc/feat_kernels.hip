@@ -65,10 +65,14 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
 
 template <int NC>
 static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
-                                 int *grid_used)
+                                 int *grid_used, bool timed)
 {
     void (*kernel)(FitArgs) = nullptr;
-    switch (loss) {
+    if (timed) {  // profiling builds (per-phase shader clocks), the two BASELINE losses only
+        if (loss == LFM_LOSS_BPR_ID) kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, true>;
+        else if (loss == LFM_LOSS_WARP_KOS_ID) kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, true>;
+    }
+    if (!kernel) switch (loss) {
     case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC>; break;
     case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC>; break;
     case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC>; break;
@@ -86,10 +90,10 @@ static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block
 }
 
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
-                           int *grid_used)
+                           int *grid_used, bool timed)
 {
-    if (a.m.d <= 64) return launch_feat_nc<1>(loss, a, grid, block, smem, st, cus, grid_used);
-    if (a.m.d <= 128) return launch_feat_nc<2>(loss, a, grid, block, smem, st, cus, grid_used);
+    if (a.m.d <= 64) return launch_feat_nc<1>(loss, a, grid, block, smem, st, cus, grid_used, false);
+    if (a.m.d <= 128) return launch_feat_nc<2>(loss, a, grid, block, smem, st, cus, grid_used, timed);
     return hipErrorInvalidValue;
 }
 

@@ -41,7 +41,7 @@ struct FeatPlan {
 // rows_hint: rows of a typical update list (f_user + 2 f_item), so that one chunk covers it
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
-                           int *grid_used = nullptr);
+                           int *grid_used = nullptr, bool timed = false);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
 hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);

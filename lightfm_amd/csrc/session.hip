@@ -1037,7 +1037,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2,
                                              &grid_used));
             }
-            else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used));
+            else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used,
+                                                       opts->feat_kernel == 2));
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
