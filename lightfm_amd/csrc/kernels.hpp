@@ -22,6 +22,9 @@ struct RanksArgs {
     float *ranks;           // aligned with test.data
     const int32_t *ulist;   // ranks_mfma_kernel: users that have test interactions
     int32_t n_ulist;
+    float *item_eps;        // ranks_mfma2_kernel: [2][n_items] item-side terms of the pre-filter's error bound
+    float *test_scores;     // ranks_mfma2_kernel: [test_nnz] exact scores of the test interactions
+    int64_t test_nnz;
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)
@@ -29,9 +32,10 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
                       int cus = 0, int *grid_used = nullptr);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)
 // ng = interactions per wavefront pass (1, 2, 4); vec = floats of a row per lane
-size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec);
+// dma4: the LDS-DMA (global_load_lds_dwordx4) variant of ng = 4 with its candidate-major tile
+size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec, bool dma4 = false);
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
-                                int cus, bool timed = false, int *grid_used = nullptr);
+                                int cus, bool timed = false, int *grid_used = nullptr, bool dma4 = false);
 // feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...
@@ -62,6 +66,9 @@ hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
 // MFMA pre-filtered variant (d <= 128): false if the shape is outside what it supports
 bool ranks_mfma_supported(int d);
 hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus);
+// users as tile columns (a lane owns a user for the whole sweep); ulist ordered by test count, largest first
+hipError_t launch_ranks_mfma2(const RanksArgs &a, hipStream_t st, int cus);
+int ranks_mfma2_item_rows(int d);  // rows the component-major item table must have for it
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);
 

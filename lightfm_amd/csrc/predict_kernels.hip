@@ -270,6 +270,238 @@ __global__ __launch_bounds__(64) void ranks_mfma_kernel(RanksArgs a)
     }
 }
 
+// Per item: the two item-side terms of the pre-filter's error bound, kappa |b_j| and kappa |v_j|
+// (out[j], out[n_items + j]), from the component-major table.
+__global__ void item_eps_kernel(const float *vT, int n_items, int d, float kappa, float *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_items) return;
+    float n2 = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const float v = vT[(size_t)k * n_items + j];
+        n2 += v * v;
+    }
+    out[j] = kappa * fabsf(vT[(size_t)d * n_items + j]);
+    out[(size_t)n_items + j] = kappa * (sqrtf(n2) * 1.0000005f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict_ranks, second MFMA formulation: USERS are the columns of the 32 x 32 output tile and
+// ITEMS its rows, so a lane owns ONE user for the whole sweep over the item table:
+//   * its user's representation (the B operand of every v_mfma_f32_32x32x2_f32 of the sweep), the
+//     exact scores of its test items (thresholds) and their counters live in registers;
+//   * per 32-item tile: 32 coalesced loads of the component-major item table (the A operand,
+//     requested for the NEXT tile while this tile's scores are compared), d/2 MFMAs, and per
+//     score four VALU instructions per threshold -- `count += (score - eps > threshold)`
+//     (v_cmp + v_addc) and the distance to the nearest threshold (v_sub + v_min);
+//   * a score within eps of a threshold is re-decided with the reference's sequential dot
+//     (rare: eps ~ 1e-5 of the score scale), so the ranks are the reference's integers;
+//   * train positives: the lane walks its user's sorted train row alongside the sweep (one
+//     32-bit mask per tile), the next entry always requested one step ahead.
+// One wavefront = 32 users; users are ordered by their number of test items (host side) so the
+// 32 users of a wavefront need the same number of passes of 16 thresholds.
+// Scores within eps of a threshold, re-decided with the reference's sequential dot (PYX:1317-1319).
+// Kept out of line: it runs for a few scores per thousand and must not cost the sweep registers.
+__device__ __forceinline__ void band_recheck(unsigned bandmask, int lane, int j0, int m, float nu, float eu,
+                                          const float *urow, const float *vT, int I, int d, const float *sc_s,
+                                          const float *ej_s, const float *nj_s, const float *thr_s,
+                                          const int *tid_s, int *xcnt_s)
+{
+    constexpr int MT = 16;
+    const int half = lane >> 5;
+    // rare path: keep its address arithmetic here (opaque copies, so that nothing of it is hoisted
+    // into the sweep and kept in registers there)
+    asm volatile("" : "+s"(I), "+s"(d), "+s"(vT));
+    while (bandmask) {
+        const int r = __ffs((int)bandmask) - 1;
+        bandmask &= bandmask - 1u;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half, item = j0 + i;
+        const float sc = sc_s[r * WAVE + lane];
+        const float eps = __fmaf_rn(nu, nj_s[i], eu + ej_s[i]);
+        bool need = false;
+        for (int t = 0; t < m; ++t)
+            need = need || (fabsf(sc - thr_s[lane * MT + t]) <= eps && item != tid_s[lane * MT + t]);
+        if (need) {
+            // the reference's sequential dot (PYX:320-334), one component at a time: few registers
+            float ex = __fadd_rn(urow[d], vT[(size_t)d * I + item]);
+#pragma unroll 1
+            for (int c = 0; c < d; ++c) ex = __fadd_rn(ex, __fmul_rn(urow[c], vT[(size_t)c * I + item]));
+            for (int t = 0; t < m; ++t) {
+                const float tht = thr_s[lane * MT + t];
+                if (fabsf(sc - tht) <= eps && item != tid_s[lane * MT + t] && ex >= tht) xcnt_s[lane * MT + t] += 1;
+            }
+        }
+    }
+}
+
+// Exact (sequential-dot) score of every test interaction: the thresholds of the sweep.
+__global__ void test_scores_kernel(RanksArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.test_nnz) return;
+    // the row of entry t: binary search of indptr
+    int lo = 0, hi = a.test.rows;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)a.test.indptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    a.test_scores[t] = dense_dot(a.user_rep + (size_t)lo * a.rs, a.item_rep, (size_t)a.test.cols, a.test.indices[t], a.d);
+}
+
+template <int KSTEPS>
+__global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(RanksArgs a)
+{
+    constexpr int MT = 16;
+    __shared__ float thr_s[WAVE * MT];  // thresholds, ids and exact in-band hits, by lane
+    __shared__ int tid_s[WAVE * MT];
+    __shared__ int xcnt_s[WAVE * MT];
+    __shared__ float sc_s[16 * WAVE];   // slow path: the tile's scores [r][lane]
+    __shared__ float ej_s[32], nj_s[32];  // slow path: eps terms of the tile's items
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    const int d = a.d, I = a.test.cols;
+    const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
+    const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
+    const float INF = __int_as_float(0x7f800000);
+    for (int tile = blockIdx.x; tile * 32 < a.n_ulist; tile += gridDim.x) {
+        const int ui = tile * 32 + col;
+        const bool uok = ui < a.n_ulist;
+        const int user = uok ? a.ulist[ui] : 0;
+        const float *urow = a.user_rep + (size_t)user * a.rs;
+        float ub[KSTEPS];
+        float n2 = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int k = 2 * kk + half;
+            ub[kk] = (uok && k < d) ? urow[k] : 0.0f;
+            n2 += ub[kk] * ub[kk];
+        }
+        n2 += __shfl_xor(n2, 32, WAVE);
+        const float bu = uok ? urow[d] : 0.0f;
+        const float nu = sqrtf(n2) * 1.0000005f, eu = kappa * fabsf(bu);
+        const int t_lo = uok ? a.test.indptr[user] : 0, t_hi = uok ? a.test.indptr[user + 1] : 0;
+        int m_max = t_hi - t_lo;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m_max = max(m_max, __shfl_xor(m_max, off, WAVE));
+        for (int p0 = 0; p0 < m_max; p0 += MT) {
+            // ---- this pass's test items: ids and exact scores (PYX:1278-1293)
+            const int m = max(0, min(MT, (t_hi - t_lo) - p0));
+#pragma unroll 1
+            for (int t = 0; t < MT; ++t) {
+                // exact scores of the test items (PYX:1278-1293) come from test_scores_kernel
+                const bool on = t < m;
+                thr_s[lane * MT + t] = on ? a.test_scores[t_lo + p0 + t] : INF;
+                tid_s[lane * MT + t] = on ? a.test.indices[t_lo + p0 + t] : -1;
+                xcnt_s[lane * MT + t] = 0;
+            }
+            float th[MT];
+            int cl[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                th[t] = thr_s[lane * MT + t];
+                cl[t] = 0;
+            }
+            // train row cursor of the user, one entry ahead
+            int tp = 0, tend = 0, next = 0x7fffffff, next2 = 0x7fffffff;
+            if (uok) {
+                tp = a.train.indptr[user];
+                tend = a.train.indptr[user + 1];
+                if (tp < tend) next = a.train.indices[tp];
+                if (tp + 1 < tend) next2 = a.train.indices[tp + 1];
+            }
+            // A operand of a tile: V[item j0 + col][2 kk + half], walked down the component-major table
+            // (the table has >= 2 KSTEPS rows, zero beyond d); items past the end re-read the last one
+            float av[KSTEPS], bj = 0.0f, ej = 0.0f, njk = 0.0f;
+            auto load_tile = [&](int j0) {
+                // scalar row pointer + one 32-bit lane offset for all rows (global_load saddr form)
+                const unsigned jc = (unsigned)min(j0 + col, I - 1);
+                const unsigned voff = jc + (unsigned)half * (unsigned)I;
+                const float *rowp = vT;
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    av[kk] = rowp[voff];
+                    rowp += 2 * (size_t)I;
+                }
+                bj = (vT + (size_t)d * I)[jc];
+                ej = a.item_eps[jc];
+                njk = (a.item_eps + (size_t)I)[jc];
+            };
+            int first = 0;
+            asm volatile("" : "+s"(first));  // opaque: the first tile's addresses are not worth keeping in registers
+            load_tile(first);
+            for (int j0 = 0; j0 < I; j0 += 32) {
+                const float bjt = bj;
+                const float ejt = ej, njt = njk;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int iA = (r & 3) + 8 * (r >> 2);
+                    const float b_lo = read_lanef(bjt, iA), b_hi = read_lanef(bjt, iA + 4);
+                    acc[r] = __fadd_rn(bu, half ? b_hi : b_lo);
+                }
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], ub[kk], acc, 0, 0, 0);
+                // the MFMAs have read this tile's operands: request the next tile's now, they
+                // travel while the scores are compared
+                if (j0 + 32 < I) load_tile(j0 + 32);
+                // train positives inside [j0, j0 + 32) (PYX:1303-1304)
+                unsigned tmask = 0u;
+                while (next < j0 + 32) {
+                    tmask |= 1u << (next - j0);
+                    ++tp;
+                    next = next2;
+                    next2 = tp + 1 < tend ? a.train.indices[tp + 1] : 0x7fffffff;
+                }
+                unsigned bandmask = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int iA = (r & 3) + 8 * (r >> 2), i = iA + 4 * half;
+                    // one score at a time: nothing of score r starts before the counts of score r - 1
+                    // are done (otherwise all 16 x 16 differences are computed up front and spill)
+                    float ejr = ejt, njr = njt, scr = acc[r];
+                    asm volatile("" : "+v"(ejr), "+v"(njr), "+v"(scr)
+                                 : "v"(cl[0]), "v"(cl[1]), "v"(cl[2]), "v"(cl[3]), "v"(cl[4]), "v"(cl[5]), "v"(cl[6]), "v"(cl[7]),
+                                   "v"(cl[8]), "v"(cl[9]), "v"(cl[10]), "v"(cl[11]), "v"(cl[12]), "v"(cl[13]), "v"(cl[14]),
+                                   "v"(cl[15]), "v"(bandmask));
+                    const float e_lo = read_lanef(ejr, iA), e_hi = read_lanef(ejr, iA + 4);
+                    const float n_lo = read_lanef(njr, iA), n_hi = read_lanef(njr, iA + 4);
+                    const float eps = __fmaf_rn(nu, half ? n_hi : n_lo, eu + (half ? e_hi : e_lo));
+                    const bool valid = (j0 + i < I) && !((tmask >> i) & 1u);
+                    // an item that does not count scores -inf: above no threshold, near none
+                    const float sc = valid ? scr : -INF;
+                    sc_s[r * WAVE + lane] = sc;  // for the rare exact re-check below (same lane reads it)
+                    float dmin = INF;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const float df = sc - th[t];  // ONE rounded difference decides "above" and "near"
+                        cl[t] += (df > eps) ? 1 : 0;
+                        dmin = fminf(dmin, fabsf(df));
+                    }
+                    bandmask |= (dmin <= eps) ? (1u << r) : 0u;
+                }
+                if (__ballot(bandmask != 0u) != 0ull) {
+                    // some score lies within eps of a threshold: re-decide those pairs with the
+                    // reference's sequential dot (PYX:1317-1319).  Rolled loops over LDS copies.
+                    if (half == 0) {
+                        ej_s[col] = ejt;
+                        nj_s[col] = njt;
+                    }
+                    wave_sync();
+                    band_recheck(bandmask, lane, j0, m, nu, eu, urow, vT, I, d, sc_s, ej_s, nj_s, thr_s, tid_s, xcnt_s);
+                    wave_sync();
+                }
+            }
+            // both halves of a user's column counted different items
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                int c = cl[t] + xcnt_s[lane * MT + t];
+                c += __shfl_xor(c, 32, WAVE);
+                if (half == 0 && t < m) a.ranks[t_lo + p0 + t] += (float)c;
+            }
+        }
+    }
+}
+
 bool ranks_mfma_supported(int d) { return d >= 1 && d <= 128; }
 
 hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus)
@@ -284,6 +516,33 @@ hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus)
         grid = std::min(tiles, per_cu * std::max(cus, 1));
     ranks_mfma_kernel<MT><<<grid, 64, smem, st>>>(a);
     return hipGetLastError();
+}
+
+template <int KSTEPS>
+static hipError_t launch_ranks_mfma2_k(const RanksArgs &a, hipStream_t st, int cus)
+{
+    const int tiles = (a.n_ulist + 31) / 32;
+    int per_cu = 0, grid = tiles;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma2_kernel<KSTEPS>, 64, 0) == hipSuccess && per_cu > 0)
+        grid = std::min(tiles, per_cu * std::max(cus, 1));
+    ranks_mfma2_kernel<KSTEPS><<<grid, 64, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+int ranks_mfma2_item_rows(int d) { return std::max(d + 1, d <= 32 ? 32 : (d <= 64 ? 64 : 128)); }
+
+// a.ulist must be ordered by the users' number of test interactions, largest first; a.item_rep has
+// ranks_mfma2_item_rows(d) rows (zero beyond the bias row d), a.item_eps room for 2 * n_items floats
+hipError_t launch_ranks_mfma2(const RanksArgs &a, hipStream_t st, int cus)
+{
+    if (a.n_ulist <= 0) return hipSuccess;
+    const float kappa = 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
+    item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
+    test_scores_kernel<<<(int)((a.test_nnz + 255) / 256), 256, 0, st>>>(a);
+    if (a.d <= 32) return launch_ranks_mfma2_k<16>(a, st, cus);
+    if (a.d <= 64) return launch_ranks_mfma2_k<32>(a, st, cus);
+    if (a.d <= 128) return launch_ranks_mfma2_k<64>(a, st, cus);
+    return hipErrorInvalidValue;
 }
 
 __device__ void heap_sift(float *x, int start, int end)

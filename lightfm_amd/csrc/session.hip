@@ -875,7 +875,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
     // NG = 4 is the most instruction-efficient mapping; when a launch may keep only few
     // interactions in flight, fewer per wavefront buy more wavefronts (latency hiding).
-    struct TilePlan { bool ok = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
+    struct TilePlan { bool ok = false, dma4 = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
     TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
@@ -884,7 +884,14 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         for (int ng : {4, 2, 1}) {
             if (forced && ng != forced) continue;
             TilePlan &t = tile[ng];
-            t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec);
+            // four interactions per pass: rows go memory -> LDS by LDS-DMA (debug bit 6: the
+            // register-staged variant instead)
+            t.dma4 = ng == 4 && !(opts->debug & 64);
+            t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec, t.dma4);
+            if (t.smem == 0 && t.dma4) {
+                t.dma4 = false;
+                t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec, false);
+            }
             if (t.smem == 0) continue;
             t.ok = true;
             t.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
@@ -1009,7 +1016,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 // lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
                 const double lr_max = s->adadelta ? 1.0 : (double)s->lr;
                 const double step = std::max(item_alpha, user_alpha) * std::max(lr_max, 1e-12);
-                const double max_len = log(2.0) / log1p(step);
+                static const double growth = [] {  // experiments: largest growth of the scale inside one launch
+                    const char *e = getenv("LIGHTFM_AMD_REG_GROWTH");
+                    const double g = e ? atof(e) : 0.0;
+                    return g > 1.0 ? g : 2.0;
+                }();
+                const double max_len = log(growth) / log1p(step);
                 if (max_len < (double)len) len = std::max<int64_t>(1, (int64_t)max_len);
             }
             a.begin = begin;
@@ -1035,7 +1047,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                     }
                 }
                 HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2,
-                                             &grid_used));
+                                             &grid_used, tile[ng].dma4));
             }
             else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));
@@ -1043,6 +1055,13 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (reg) {
                 HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
                 HIP_TRY(launch_regularize(a.m, 1, s->stream));  // fold now (see above); PYX:652-675
+                // very large alpha means thousands of tiny launches: keep the queue of pending
+                // commands bounded
+                static const int sync_every = [] {
+                    const char *e = getenv("LIGHTFM_AMD_REG_SYNC");
+                    return e ? atoi(e) : 256;
+                }();
+                if (sync_every > 0 && (n_launches + 1) % sync_every == 0) HIP_TRY(hipStreamSynchronize(s->stream));
             }
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp
@@ -1232,7 +1251,14 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     usf.rows = test->rows;  // only users/items of the interaction matrix (PYX:1264, 1301)
     itf.rows = test->cols;
     LFM_TRY(urep.alloc((size_t)usf.rows * rs));
-    LFM_TRY(irep.alloc((size_t)itf.rows * rs));
+    // component-major item table: the MFMA sweep walks 2 * ceil-pow2(d / 2) rows, zero beyond the bias row
+    const int irows = std::max(rs, ranks_mfma_supported(s->d) ? ranks_mfma2_item_rows(s->d) : rs);
+    DBuf<float> ieps;
+    LFM_TRY(irep.alloc((size_t)itf.rows * irows));
+    LFM_TRY(ieps.alloc((size_t)itf.rows * 2));
+    DBuf<float> tscores;
+    LFM_TRY(tscores.alloc((size_t)test->nnz));
+    HIP_TRY(hipMemsetAsync(irep.p, 0, (size_t)itf.rows * irows * sizeof(float), s->stream));
     LFM_TRY(dranks.upload(ranks, (size_t)test->nnz));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     HIP_TRY(launch_rep_rows(usf, s->tab[1][0].p, s->tab[1][3].p, s->d, rs, urep.p, s->stream));
@@ -1247,18 +1273,30 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.ranks = dranks.p;
     a.ulist = nullptr;
     a.n_ulist = 0;
-    const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");  // 0: the scalar kernel (tests compare the two)
-    const bool mfma_ok = mfma_env == nullptr || atoi(mfma_env) != 0;
+    a.item_eps = ieps.p;
+    a.test_scores = tscores.p;
+    a.test_nnz = test->nnz;
+    // LIGHTFM_AMD_RANKS_MFMA: 0 the scalar kernel, 1 the first MFMA formulation (users as tile rows),
+    // unset / 2 the second (a lane owns a user); the tests compare all three
+    const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
+    const int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
     DBuf<int32_t> ulist;
-    if (mfma_ok && ranks_mfma_supported(s->d)) {
-        // users with test interactions, in tiles of 32 per wavefront
+    if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
+        // users with test interactions, in tiles of 32 per wavefront, most test items first: the
+        // users of a wavefront then need the same number of threshold passes and the heavy
+        // wavefronts are dispatched first
         std::vector<int32_t> ul;
         for (int32_t u = 0; u < test->rows; ++u)
             if (test->indptr[u + 1] > test->indptr[u]) ul.push_back(u);
+        if (mfma_mode != 1)
+            std::stable_sort(ul.begin(), ul.end(), [&](int32_t x, int32_t y) {
+                return test->indptr[x + 1] - test->indptr[x] > test->indptr[y + 1] - test->indptr[y];
+            });
         LFM_TRY(ulist.upload(ul.data(), ul.size()));
         a.ulist = ulist.p;
         a.n_ulist = (int32_t)ul.size();
-        HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
+        if (mfma_mode == 1) HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
+        else HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
     } else {
         HIP_TRY(launch_ranks(a, s->stream));
     }

@@ -27,7 +27,9 @@ hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids,
 // Tile geometry for `ng` interactions per wavefront pass (1, 2 or 4): lanes per row = 64 / ng,
 // a lane carries vec = 1, 2 or 4 consecutive floats of a row.  Returns the LDS bytes per
 // 256-thread workgroup, or 0 if (d, max_sampled, ng) is outside what the kernel supports.
-size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec)
+// dma4 (ng = 4, vec = 4 only): the candidate-major LDS-DMA layout of warp_tile_kernel.hpp -- rg rows of
+// (4 * 64 + 4) floats plus four user rows of 64 + 4.
+size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec, bool dma4)
 {
     if (d < 4 || (d & 3) != 0 || max_sampled < 1 || (ng != 1 && ng != 2 && ng != 4)) return 0;
     const int lpr = WAVE / ng;
@@ -37,6 +39,13 @@ size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride
     if (!v) return 0;  // d too wide for this many interactions per pass
     const int ts = d + 4;  // 16-byte aligned rows, consecutive rows 4 dwords apart in bank phase
     int rg = std::min(max_sampled, lpr - 1) + 1;
+    if (dma4) {
+        if (ng != 4 || v != 4) return 0;
+        *rows = rg;
+        *stride = ts;
+        *vec = v;
+        return (size_t)WAVES_PER_BLOCK * ((size_t)rg * (4 * WAVE + 4) + 4 * (WAVE + 4)) * sizeof(float);
+    }
     // at least two workgroups per CU (160 KiB LDS)
     while (rg > 2 && (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float) > 78 * 1024) --rg;
     *rows = rg;
@@ -45,15 +54,15 @@ size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride
     return (size_t)WAVES_PER_BLOCK * (ng * rg + ng) * ts * sizeof(float);
 }
 
-hipError_t launch_tile_lpr16(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
+hipError_t launch_tile_lpr16(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *, bool);
 hipError_t launch_tile_lpr32(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
 hipError_t launch_tile_lpr64(const FitArgs &, int, int, size_t, hipStream_t, int, bool, int *);
 
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
-                                int cus, bool timed, int *grid_used)
+                                int cus, bool timed, int *grid_used, bool dma4)
 {
     switch (ng) {
-    case 4: return launch_tile_lpr16(a, vec, grid, smem, st, cus, timed, grid_used);
+    case 4: return launch_tile_lpr16(a, vec, grid, smem, st, cus, timed, grid_used, dma4);
     case 2: return launch_tile_lpr32(a, vec, grid, smem, st, cus, timed, grid_used);
     case 1: return launch_tile_lpr64(a, vec, grid, smem, st, cus, timed, grid_used);
     default: return hipErrorInvalidValue;

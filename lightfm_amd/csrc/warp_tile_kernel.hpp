@@ -69,6 +69,12 @@ __device__ __forceinline__ void dma_lane_dword(const float *g, float *lds_row)
 {
     __builtin_amdgcn_global_load_lds(g, (lds_float_t *)lds_row, 4, 0, 0);
 }
+// The same with 16 bytes per lane (global_load_lds_dwordx4): lane l deposits its 16 bytes at
+// lds_base + 16 l -- one instruction lays 1 KiB of LDS.
+__device__ __forceinline__ void dma_lane_x4(const float *g, float *lds_base)
+{
+    __builtin_amdgcn_global_load_lds(g, (lds_float_t *)lds_base, 16, 0, 0);
+}
 
 // x % n for x < 2^31, 2 <= n < 2^31, with magic = floor(2^32 / n) + 1:
 // floor(x*magic / 2^32) is floor(x/n) or one more (x*magic/2^32 lies in (x/n, x/n + 1/2)).
@@ -165,9 +171,20 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 
 // TIMED (profiling builds of the same kernel, lfm_opts.warp_kernel = 2): every wave
 // accumulates s_memtime deltas per phase of a pass into a.counters[4..11].
-template <int LPR, int VEC, bool TIMED, bool ADADELTA>
-__global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
+//
+// DMA4 (LPR = 16, VEC = 4: four interactions per pass, the steady-state variant): rows go memory ->
+// LDS by LDS-DMA, 16 bytes per lane, with no staging registers and no ds_write.  One instruction
+// deposits the k-th row of ALL four groups as one contiguous KiB (lane (g, p) -> bytes
+// 256 g + 16 p), so the tile is laid out candidate-major: row k of group g at k * (4 * 64 + 4) +
+// 64 g floats.  The 4-float skew per candidate keeps the scoring pass free of bank conflicts: the
+// sixteen lanes one ds_read_b128 phase serves hold candidates 0-3 of one group and 4-11 of
+// another (MI355X_MICROARCH.md, LDS), i.e. twelve different bank quadruples.  The four user rows
+// are fetched by one instruction per group whose LDS base is skewed by 16 bytes per group.
+// Without the staging registers the kernel fits three workgroups per CU (12 wavefronts).
+template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false>
+__global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fit_warp_tile_kernel(FitArgs a)
 {
+    static_assert(!DMA4 || (LPR == 16 && VEC == 4), "the LDS-DMA tile layout is the four-group one");
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMED) {
@@ -189,10 +206,16 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
     // wave-uniform -- say so, and the compiler keeps them in SGPRs / branches instead of masks
     const int g = LPR == 64 ? 0 : lane / LPR, p = LPR == 64 ? lane : lane % LPR, gbase = g * LPR;
     const int d = a.m.d, TS = a.tile_stride, RG = a.tile_rows;
-    // wave-private tile: NG*RG item rows (row 0 of a group = the positive) + NG user rows
-    float *tile = smem + (size_t)wib * (NG * RG + NG) * TS;
-    float *vrows = tile + (size_t)g * RG * TS;
-    float *urow = tile + (size_t)(NG * RG + g) * TS;
+    // wave-private tile: NG*RG item rows (row 0 of a group = the positive) + NG user rows.
+    // KS = floats between consecutive rows of a group, GS = between the groups' first rows,
+    // UB = first user row, US = between user rows.
+    const int KS = DMA4 ? (NG * LPR * VEC + 4) : TS;
+    const int GS = DMA4 ? (LPR * VEC) : RG * TS;
+    const int UB = DMA4 ? RG * KS : NG * RG * TS;
+    const int US = DMA4 ? (LPR * VEC + 4) : TS;
+    float *tile = smem + (size_t)wib * (UB + NG * US);
+    float *vrows = tile + (size_t)g * GS;
+    float *urow = tile + UB + (size_t)g * US;
     const bool pc = VEC * p < d;  // this lane carries a piece (VEC floats) of every gathered row
     const float *Wi = a.m.W[0], *Wu = a.m.W[1];
     const float *bi_tab = a.b_read[0], *bu_tab = a.b_read[1];
@@ -265,6 +288,17 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                     dma_lane_dword(Wu + (size_t)c_user * d + p, urow);
                     dma_lane_dword(Wi + (size_t)c_pos * d + p, vrows);
                 }
+            } else if constexpr (DMA4) {
+                if (gl) {
+                    // lane (gg, p) -> tile[UB + gg * US + 4 p]; a scalar loop: the LDS base of an
+                    // instruction is M0, i.e. wave-uniform, and must not be merged into a per-lane select
+#pragma nounroll
+                    for (int gg = 0; gg < NG; ++gg) {
+                        float *ub = tile + UB + __builtin_amdgcn_readfirstlane(gg) * (US - LPR * VEC);
+                        if (g == gg) dma_lane_x4(Wu + (size_t)c_user * d + VEC * p, ub);
+                    }
+                    dma_lane_x4(Wi + (size_t)c_pos * d + VEC * p, tile);  // row 0 of every group
+                }
             } else {
                 // lanes without a piece read the table's first 16 bytes instead of branching
                 u4 = ldp<VEC>(gl ? Wu + (size_t)c_user * d + VEC * p : Wu);
@@ -273,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
             float bu = 0.0f;
             if (act) bu = bu_tab[c_user];
             uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
-            if constexpr (!DMA) {
+            if constexpr (!DMA && !DMA4) {
                 if (gl) {
                     stp<VEC>(urow + VEC * p, u4);
                     stp<VEC>(vrows + VEC * p, p4);
@@ -342,6 +376,17 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
+                } else if constexpr (DMA4) {
+                    // one instruction per candidate: the k-th row of every group that is still looking
+                    // (a finished group's lanes stay masked, its chosen row survives)
+#pragma unroll
+                    for (int k = 1; k < LPR; ++k) {
+                        if (k <= nb) {  // wave-uniform
+                            const int neg = row_bcast(myitem, k);
+                            if (gln) dma_lane_x4(Wi + (size_t)neg * d + VEC * p, tile + (size_t)k * KS);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // user, positive and candidate rows have landed
                 } else if constexpr (LPR == 16) {
                     // a lane group is a DPP row: row_newbcast:k hands lane k's item to its 16
                     // lanes in one VALU instruction (no LDS round trip per candidate)
@@ -403,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                 wave_sync();
                 stamp(1);  // gathers landed and staged
                 float score = 0.0f;
-                if (rowlane) score = row_dot(urow, vrows + (size_t)p * TS, d, bu, bi);
+                if (rowlane) score = row_dot(urow, vrows + (size_t)p * KS, d, bu, bi);
                 // (one interaction per wavefront: lane reads instead of shuffles keep the whole
                 // sampling control flow below in SGPRs and scalar branches)
                 if (done == 0) pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
@@ -510,9 +555,9 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
                         const int cr = __builtin_amdgcn_readlane(chosen_r, gg * LPR);
                         const double loss = read_laned(lossd, gg * LPR);
                         const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
-                        const float *tu = tile + (size_t)(NG * RG + gg) * TS;
-                        const float *tp = tile + (size_t)(gg * RG) * TS;
-                        const float *tn = tile + (size_t)(gg * RG + cr) * TS;
+                        const float *tu = tile + UB + (size_t)gg * US;
+                        const float *tp = tile + (size_t)gg * GS;
+                        const float *tn = tp + (size_t)cr * KS;
                         // All cell arithmetic of the group first, as ONE straight-line block (the
                         // 3*NC row cells and the bias cell are independent float64 dependency
                         // chains the scheduler interleaves), then every publication.
@@ -620,14 +665,14 @@ __global__ __launch_bounds__(256, 2) void fit_warp_tile_kernel(FitArgs a)
 }
 
 // Launch helper shared by the per-LPR translation units (warp_tile_lpr*.hip).
-template <int LPR, int VEC>
+template <int LPR, int VEC, bool DMA4 = false>
 hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus, bool timed,
                                int *grid_used)
 {
     void (*kernel)(FitArgs);
-    if (a.m.adadelta) kernel = fit_warp_tile_kernel<LPR, VEC, false, true>;
-    else if (timed) kernel = fit_warp_tile_kernel<LPR, VEC, true, false>;
-    else kernel = fit_warp_tile_kernel<LPR, VEC, false, false>;
+    if (a.m.adadelta) kernel = fit_warp_tile_kernel<LPR, VEC, false, true, DMA4>;
+    else if (timed) kernel = fit_warp_tile_kernel<LPR, VEC, true, false, DMA4>;
+    else kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4>;
     if (cus > 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) == hipSuccess &&

@@ -5,10 +5,12 @@
 namespace lfm {
 
 hipError_t launch_tile_lpr16(const FitArgs &a, int vec, int grid, size_t smem, hipStream_t st, int cus,
-                             bool timed, int *grid_used)
+                             bool timed, int *grid_used, bool dma4)
 {
     switch (vec) {
-    case 4: return launch_tile_variant<16, 4>(a, grid, smem, st, cus, timed, grid_used);
+    case 4:
+        if (dma4) return launch_tile_variant<16, 4, true>(a, grid, smem, st, cus, timed, grid_used);
+        return launch_tile_variant<16, 4>(a, grid, smem, st, cus, timed, grid_used);
     default: return hipErrorInvalidValue;
     }
 }

@@ -98,34 +98,62 @@ def test_intersecting_train_and_test_is_rejected(fitted):
     precision_at_k(model, train, train_interactions=train, check_intersections=False)
 
 
-def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
-    """predict_ranks through the MFMA pre-filter (csrc/predict_kernels.hip: ranks_mfma_kernel) and
-    through the scalar sequential-dot kernel on a TRAINED model at the ML-20M item count: every rank
-    identical (the MFMA score only decides comparisons outside its rounding band)."""
+_RANK_KERNELS = (("lane-per-user", "2"), ("users-as-rows", "1"), ("scalar", "0"))
+
+
+def _ranks_by_kernel(model, test, train=None, **kw):
     import os
+    out = {}
+    try:
+        for name, env in _RANK_KERNELS:
+            os.environ["LIGHTFM_AMD_RANKS_MFMA"] = env
+            out[name] = model.predict_rank(test, train_interactions=train, check_intersections=False, **kw).data
+    finally:
+        os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
+    return out
+
+
+def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
+    """predict_ranks through both MFMA pre-filters (csrc/predict_kernels.hip: ranks_mfma2_kernel -- the
+    default, a lane owns a user -- and ranks_mfma_kernel) and through the scalar sequential-dot kernel
+    on a TRAINED model at the ML-20M item count: every rank identical (an MFMA score only decides
+    comparisons outside its rounding band, the rest is re-decided with the sequential dot)."""
     import scipy.sparse as sp
     from lightfm_amd import LightFM, synthetic
     data = synthetic.make_interactions(6000, 26744, 900000, seed=5)
     train, test = synthetic.train_test_split(data, 0.1, seed=1)
     m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=3)
-    ranks = {}
-    try:
-        for name, env in (("mfma", "1"), ("scalar", "0")):
-            os.environ["LIGHTFM_AMD_RANKS_MFMA"] = env
-            ranks[name] = m.predict_rank(test, train_interactions=train, check_intersections=False)
-    finally:
-        os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
-    assert ranks["mfma"].nnz == test.nnz and ranks["mfma"].data.max() > 100
-    assert np.array_equal(ranks["mfma"].data, ranks["scalar"].data)
-    # heavy users (more test items than one pass of the kernel holds) and an odd no_components
+    ranks = _ranks_by_kernel(m, test, train)
+    assert len(ranks["scalar"]) == test.nnz and ranks["scalar"].max() > 100
+    assert np.array_equal(ranks["lane-per-user"], ranks["scalar"])
+    assert np.array_equal(ranks["users-as-rows"], ranks["scalar"])
+    # heavy users (more test items than one pass of the kernels holds) and an odd no_components
     m2 = LightFM(no_components=33, loss="bpr", random_state=2).fit(train, epochs=1)
     heavy = sp.coo_matrix((np.ones(300, np.float32), (np.repeat([3, 4000], 150), np.tile(np.arange(150) * 7, 2))),
                           shape=test.shape, dtype=np.float32)
-    out = {}
-    try:
-        for name, env in (("mfma", "1"), ("scalar", "0")):
-            os.environ["LIGHTFM_AMD_RANKS_MFMA"] = env
-            out[name] = m2.predict_rank(heavy, check_intersections=False)
-    finally:
-        os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
-    assert np.array_equal(out["mfma"].data, out["scalar"].data)
+    out = _ranks_by_kernel(m2, heavy)
+    assert np.array_equal(out["lane-per-user"], out["scalar"])
+    assert np.array_equal(out["users-as-rows"], out["scalar"])
+
+
+@pytest.mark.parametrize("d,n_items", [(8, 37), (32, 1000), (100, 513), (128, 2048)])
+def test_mfma_ranks_shapes_and_ties(d, n_items):
+    """Every width class of the MFMA sweep (d <= 32, 64, 128), item counts that are not multiples of
+    the 32-item tile, items that tie EXACTLY with a test item (duplicated embedding rows: the
+    reference counts them, `>=`) and a fresh model whose scores are all within the rounding band."""
+    from lightfm_amd import LightFM, synthetic
+    data = synthetic.make_interactions(300, n_items, 12 * 300, seed=d)
+    train, test = synthetic.train_test_split(data, 0.2, seed=3)
+    m = LightFM(no_components=d, loss="warp", random_state=4).fit(train, epochs=2)
+    # exact ties: the second half of the items repeats the first half's rows and biases
+    h = n_items // 2
+    m.item_embeddings[h:2 * h] = m.item_embeddings[:h]
+    m.item_biases[h:2 * h] = m.item_biases[:h]
+    out = _ranks_by_kernel(m, test, train)
+    assert np.array_equal(out["lane-per-user"], out["scalar"])
+    assert np.array_equal(out["users-as-rows"], out["scalar"])
+    fresh = LightFM(no_components=d, loss="warp", random_state=5)
+    fresh._initialize(d, n_items, 300)
+    fresh.item_embeddings *= 1e-3
+    out = _ranks_by_kernel(fresh, test, train)
+    assert np.array_equal(out["lane-per-user"], out["scalar"])

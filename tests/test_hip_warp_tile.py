@@ -36,8 +36,10 @@ _DEFAULTS = dict(mode="parallel", launches_per_epoch=0, first_batch=0, max_waves
                  log_samples=False, warp_kernel=0, update_mode=0, debug=0)
 
 # options.debug bits 0-2 force the tile kernel's interactions per wavefront pass (NG = 4, 2, 1:
-# 16, 32, 64 lanes per row); 0 = the session's automatic choice
+# 16, 32, 64 lanes per row); 0 = the session's automatic choice.  Bit 6 (64) selects the
+# register-staged NG = 4 variant instead of the LDS-DMA one (global_load_lds_dwordx4).
 NGS = [0, 4, 2, 1]
+REGS = 64
 
 
 @pytest.fixture(autouse=True)
@@ -93,12 +95,12 @@ FROZEN = [
 
 
 @pytest.mark.parametrize("case", FROZEN, ids=[c[0] for c in FROZEN])
-@pytest.mark.parametrize("kernel", ["generic", "tile-auto", "tile-ng4", "tile-ng2", "tile-ng1"])
+@pytest.mark.parametrize("kernel", ["generic", "tile-auto", "tile-ng4", "tile-ng4-regs", "tile-ng2", "tile-ng1"])
 def test_frozen_weights_samples_exact(fast, case, kernel):
     from lightfm_amd.options import options
     _, nu, ni, nnz, d, ms, fb, ratings = case
-    ng = {"generic": 0, "tile-auto": 0, "tile-ng4": 4, "tile-ng2": 2, "tile-ng1": 1}[kernel]
-    if (ng == 4 and d > 64) or (ng == 2 and d > 128):
+    ng = {"generic": 0, "tile-auto": 0, "tile-ng4": 4, "tile-ng4-regs": 4 | REGS, "tile-ng2": 2, "tile-ng1": 1}[kernel]
+    if ((ng & 7) == 4 and d > 64) or (ng == 2 and d > 128):
         pytest.skip("row wider than the lane group covers: the session falls back to fewer per wave")
     coo = H.make_interactions(nu, ni, nnz, seed=17, ratings=ratings, zipf=0.6)
     rng = np.random.RandomState(9)
@@ -128,7 +130,7 @@ SEQ = [("d64-adagrad", 64, "adagrad", 10), ("d32-adadelta", 32, "adadelta", 6),
 
 @pytest.mark.parametrize("case", SEQ, ids=[c[0] for c in SEQ])
 @pytest.mark.parametrize("update_mode", [1, 3], ids=["store", "atomic"])
-@pytest.mark.parametrize("ng", [4, 2, 1])
+@pytest.mark.parametrize("ng", [4, 4 | REGS, 2, 1], ids=["4", "4-regs", "2", "1"])
 def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode, ng):
     """launches_per_epoch = n makes the Hogwild kernel sequential: the sample logs must then
     equal the oracle's (same per-position streams) exactly and, two epochs later, every
@@ -138,7 +140,7 @@ def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode, ng):
     one float32 ulp of the largest weight."""
     from lightfm_amd.options import options
     _, d, sched, ms = case
-    if (ng == 4 and d > 64) or (ng == 2 and d > 128):
+    if ((ng & 7) == 4 and d > 64) or (ng == 2 and d > 128):
         pytest.skip("row wider than the lane group covers")
     coo = H.make_interactions(40, 30, 260, seed=3, ratings=True)
     rng = np.random.RandomState(4)
@@ -171,8 +173,8 @@ def _candidates(base_seed, positions, max_sampled, n_items):
     return out
 
 
-@pytest.mark.parametrize("d,group", [(64, 4), (128, 2)])
-def test_concurrent_disjoint_groups_bit_exact(fast, d, group):
+@pytest.mark.parametrize("d,group,variant", [(64, 4, 0), (64, 4, REGS), (128, 2, 0)], ids=["d64-4", "d64-4-regs", "d128-2"])
+def test_concurrent_disjoint_groups_bit_exact(fast, d, group, variant):
     """`group` interactions per launch = one per lane group of ONE wavefront.  When no
     interaction of a launch reads or writes a row another one writes, the concurrent
     result equals the sequential one bit for bit."""
@@ -200,7 +202,7 @@ def test_concurrent_disjoint_groups_bit_exact(fast, d, group):
     st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
     _spread(st)
     a, b = st.copy(), st.copy()
-    options.set(log_samples=True, launches_per_epoch=n // group, update_mode=1, debug=group)
+    options.set(log_samples=True, launches_per_epoch=n // group, update_mode=1, debug=group | variant)
     _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
     o = _orc_warp(coo, b, shuffle, seeds, coo.data)
     neg, sampled = options.last_logs
