@@ -53,6 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+ATOMIC_PEAK_GOPS = 320.0  # global_atomic_add_f32 lanes per second, measured (tools/membench.hip)
 MAX_SAMPLED = 10
 
 CONFIGS = {
@@ -385,6 +386,17 @@ def main():
                 "draws_per_interaction": counters[1] / max(1.0, counters[0]),
                 "updates_per_interaction": counters[2] / max(1.0, counters[0])}
 
+    # Second ceiling of the update-heavy configurations: every updated cell is published with one
+    # global_atomic_add_f32 per table (W, G), and the chip executes a fixed ~320 G of them per second
+    # whatever the table size or allocation (tools/membench.hip, profiles/r02_membench.txt: 10 G
+    # 128-B line-ops/s = 1.28 TB/s of atomic payload).  Reported next to the HBM roofline.
+    n_upd = counters[2] if loss != "logistic" else n_examples
+    rows_upd = (1.0 + 2.0 * f_i) if loss != "logistic" else (1.0 + f_i)
+    atomics = float(n_upd) * rows_upd * (d + 1) * 2.0
+    roofline["atomic_unit"] = {"achieved": atomics / kernel_s / 1e9, "peak": ATOMIC_PEAK_GOPS, "unit": "G float atomics/s",
+                               "frac": atomics / kernel_s / 1e9 / ATOMIC_PEAK_GOPS,
+                               "atomics_per_interaction": atomics / max(1.0, counters[0]),
+                               "peak_source": "measured on this chip by tools/membench.hip (profiles/r02_membench.txt)"}
     if options.feat_kernel == 2 and used == 2:  # profiling build of the row-stream kernel
         ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
         roofline["phase_cycles_per_interaction"] = dict(zip(

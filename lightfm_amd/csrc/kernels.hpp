@@ -25,6 +25,8 @@ struct RanksArgs {
     float *item_eps;        // ranks_mfma2_kernel: [2][n_items] item-side terms of the pre-filter's error bound
     float *test_scores;     // ranks_mfma2_kernel: [test_nnz] exact scores of the test interactions
     int64_t test_nnz;
+    const int32_t *work;    // ranks_mfma2_kernel: [n_work][2] (32-user tile of ulist, first test item of the pass)
+    int32_t n_work;
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)

@@ -362,7 +362,10 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
     const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
     const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
     const float INF = __int_as_float(0x7f800000);
-    for (int tile = blockIdx.x; tile * 32 < a.n_ulist; tile += gridDim.x) {
+    // a work item = (32-user tile, pass of 16 test items): a heavy user's many passes run on different
+    // wavefronts instead of one after the other
+    for (int w = blockIdx.x; w < a.n_work; w += gridDim.x) {
+        const int tile = a.work[2 * w], p0 = a.work[2 * w + 1];
         const int ui = tile * 32 + col;
         const bool uok = ui < a.n_ulist;
         const int user = uok ? a.ulist[ui] : 0;
@@ -379,10 +382,7 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
         const float bu = uok ? urow[d] : 0.0f;
         const float nu = sqrtf(n2) * 1.0000005f, eu = kappa * fabsf(bu);
         const int t_lo = uok ? a.test.indptr[user] : 0, t_hi = uok ? a.test.indptr[user + 1] : 0;
-        int m_max = t_hi - t_lo;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m_max = max(m_max, __shfl_xor(m_max, off, WAVE));
-        for (int p0 = 0; p0 < m_max; p0 += MT) {
+        {
             // ---- this pass's test items: ids and exact scores (PYX:1278-1293)
             const int m = max(0, min(MT, (t_hi - t_lo) - p0));
 #pragma unroll 1
@@ -521,10 +521,9 @@ hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus)
 template <int KSTEPS>
 static hipError_t launch_ranks_mfma2_k(const RanksArgs &a, hipStream_t st, int cus)
 {
-    const int tiles = (a.n_ulist + 31) / 32;
-    int per_cu = 0, grid = tiles;
+    int per_cu = 0, grid = a.n_work;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma2_kernel<KSTEPS>, 64, 0) == hipSuccess && per_cu > 0)
-        grid = std::min(tiles, per_cu * std::max(cus, 1));
+        grid = std::min(a.n_work, per_cu * std::max(cus, 1));
     ranks_mfma2_kernel<KSTEPS><<<grid, 64, 0, st>>>(a);
     return hipGetLastError();
 }
@@ -535,7 +534,7 @@ int ranks_mfma2_item_rows(int d) { return std::max(d + 1, d <= 32 ? 32 : (d <= 6
 // ranks_mfma2_item_rows(d) rows (zero beyond the bias row d), a.item_eps room for 2 * n_items floats
 hipError_t launch_ranks_mfma2(const RanksArgs &a, hipStream_t st, int cus)
 {
-    if (a.n_ulist <= 0) return hipSuccess;
+    if (a.n_ulist <= 0 || a.n_work <= 0) return hipSuccess;
     const float kappa = 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
     item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
     test_scores_kernel<<<(int)((a.test_nnz + 255) / 256), 256, 0, st>>>(a);

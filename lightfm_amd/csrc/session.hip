@@ -1280,7 +1280,9 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     // unset / 2 the second (a lane owns a user); the tests compare all three
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
     const int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
-    DBuf<int32_t> ulist;
+    DBuf<int32_t> ulist, work;
+    a.work = nullptr;
+    a.n_work = 0;
     if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
         // users with test interactions, in tiles of 32 per wavefront, most test items first: the
         // users of a wavefront then need the same number of threshold passes and the heavy
@@ -1295,8 +1297,24 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
         LFM_TRY(ulist.upload(ul.data(), ul.size()));
         a.ulist = ulist.p;
         a.n_ulist = (int32_t)ul.size();
-        if (mfma_mode == 1) HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
-        else HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
+        if (mfma_mode == 1) {
+            HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
+        } else {
+            // work items: every 32-user tile x every pass of 16 test items its heaviest (first) user needs
+            std::vector<int32_t> wl;
+            for (size_t t0 = 0; t0 < ul.size(); t0 += 32) {
+                const int32_t u0 = ul[t0];
+                const int32_t cnt = test->indptr[u0 + 1] - test->indptr[u0];
+                for (int32_t p0 = 0; p0 < cnt; p0 += 16) {
+                    wl.push_back((int32_t)(t0 / 32));
+                    wl.push_back(p0);
+                }
+            }
+            LFM_TRY(work.upload(wl.data(), wl.size()));
+            a.work = work.p;
+            a.n_work = (int32_t)(wl.size() / 2);
+            HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
+        }
     } else {
         HIP_TRY(launch_ranks(a, s->stream));
     }

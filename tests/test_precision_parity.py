@@ -42,6 +42,7 @@ def _p10(model, train_csr, test_csr, feats):
 
 
 def _gap(loss, d, train, test, feats, epochs, **model_kw):
+    from concurrent.futures import ThreadPoolExecutor
     from lightfm_amd import LightFM, options
     from oracle import oracle
     from oracle.ref_model import RefLightFM
@@ -50,14 +51,24 @@ def _gap(loss, d, train, test, feats, epochs, **model_kw):
     options.set(mode="parallel")
     train_csr, test_csr = train.tocsr(), test.tocsr()
     hip, ref = [], []
+
+    def fit_ref(seed):
+        # the reference's native epoch loop releases the GIL: the seeds of a round train side by side
+        # (16 OpenMP threads each) while the main thread drives the GPU
+        r = RefLightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
+        r.fit(train, item_features=feats, epochs=epochs, num_threads=_ref_threads())
+        return r
+
     for rnd in range(MAX_ROUNDS):
-        for seed in range(1 + rnd * SEEDS_PER_ROUND, 1 + (rnd + 1) * SEEDS_PER_ROUND):
-            m = LightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
-            m.fit(train, item_features=feats, epochs=epochs)
-            hip.append(_p10(m, train_csr, test_csr, feats))
-            r = RefLightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
-            r.fit(train, item_features=feats, epochs=epochs, num_threads=_ref_threads())
-            ref.append(_p10(r, train_csr, test_csr, feats))
+        seeds = range(1 + rnd * SEEDS_PER_ROUND, 1 + (rnd + 1) * SEEDS_PER_ROUND)
+        with ThreadPoolExecutor(max_workers=SEEDS_PER_ROUND) as pool:
+            pending = [pool.submit(fit_ref, seed) for seed in seeds]
+            for seed in seeds:
+                m = LightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
+                m.fit(train, item_features=feats, epochs=epochs)
+                hip.append(_p10(m, train_csr, test_csr, feats))
+            for f in pending:  # ranks of the reference-trained weights: the same (exact) device kernel
+                ref.append(_p10(f.result(), train_csr, test_csr, feats))
         delta = float(np.mean(hip) - np.mean(ref))
         print("%s d=%d: hip %.4f +- %.4f  ref %.4f +- %.4f  delta %+.4f  (n=%d per side)"
               % (loss, d, np.mean(hip), np.std(hip), np.mean(ref), np.std(ref), delta, len(hip)))
