@@ -1011,15 +1011,16 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 // by the current scale.  Thousands of concurrent interactions cannot follow a scale
                 // that moves by orders of magnitude inside one launch, so here the scale is folded
                 // into the weights at EVERY launch boundary (the fold is exact algebra: W / s with
-                // s reset to 1) and a launch is cut short enough for the scale to at most double
-                // inside it: every interaction multiplies it by at most 1 + alpha * lr (adagrad:
+                // s reset to 1) and a launch is cut short enough for the scale to grow 16-fold at most
+                // inside it (the forward estimate of apply_scale_step follows it inside the launch):
+                // every interaction multiplies it by at most 1 + alpha * lr (adagrad:
                 // lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
                 const double lr_max = s->adadelta ? 1.0 : (double)s->lr;
                 const double step = std::max(item_alpha, user_alpha) * std::max(lr_max, 1e-12);
                 static const double growth = [] {  // experiments: largest growth of the scale inside one launch
                     const char *e = getenv("LIGHTFM_AMD_REG_GROWTH");
                     const double g = e ? atof(e) : 0.0;
-                    return g > 1.0 ? g : 2.0;
+                    return g > 1.0 ? g : 16.0;
                 }();
                 const double max_len = log(growth) / log1p(step);
                 if (max_len < (double)len) len = std::max<int64_t>(1, (int64_t)max_len);

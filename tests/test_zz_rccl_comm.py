@@ -1,6 +1,10 @@
 """RCCL plumbing on one GPU: a communicator of ONE rank exercises librccl loading,
 ncclCommInitRank, the grouped all-reduces of the three merge modes, the flag reduction and the barrier (the N > 1
-arithmetic itself is covered on CPU by tests/test_multi_gpu_semantics.py)."""
+arithmetic itself is covered on CPU by tests/test_multi_gpu_semantics.py).
+
+The file is named to be collected LAST: librccl stays loaded (with its runtime threads) for the life of the
+process that initialised it; a rank process of a real multi-GPU job carries it from the start, the single-GPU
+suite should not run under it."""
 import ctypes as C
 
 import numpy as np
