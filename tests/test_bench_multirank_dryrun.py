@@ -1,0 +1,219 @@
+"""Dry run of bench.py's N > 1 control flow on CPU (world size 2 over gloo): the row sharding, the
+rendezvous of the RCCL unique id, the segment / merge schedule every rank must walk in lockstep,
+the barriers, the max-over-ranks timing and the contract line -- with the device session replaced
+by a stand-in that counts calls (no kernel runs here; the arithmetic of the merges is covered by
+tests/test_multi_gpu_semantics.py and, on the GPU, tests/test_hip_round2.py).  A rank that made a
+different number of collective calls than the other would hang this test."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _FakeLib(object):
+    def lfm_comm_unique_id(self, buf):
+        buf.raw = bytes(range(128))
+        return 0
+
+
+def _worker(rank, world, port, out, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import lightfm_amd._native as N
+    import lightfm_amd.lightfm as L
+
+    calls = {"epoch": 0, "merge": 0, "positions": 0, "ids": []}
+
+    class FakeSession(object):
+        def __init__(self, struct, item_f, user_f, device=0):
+            self.n = 0
+            self.users = struct.user_features.shape[0]
+
+        def set_interactions(self, positives, rows, cols, data, weight):
+            assert rows.dtype == np.int32 and cols.dtype == np.int32 and data.dtype == np.float32
+            assert rows.max() < self.users, "user ids must be relative to the rank's row range"
+            self.n = len(rows)
+
+        def build_positives(self, n_users, n_items):
+            assert n_users == self.users
+
+        def comm_init(self, uid, rank_, nranks):
+            calls["ids"].append(bytes(uid.raw))
+            assert (rank_, nranks) == (rank, world)
+
+        def device_shuffle(self, k0, k1, slot=0):
+            pass
+
+        def epoch(self, loss, ia, ua, k, n, seeds, opts, slot=0):
+            b, e = int(opts.pos_begin), int(opts.pos_end)
+            assert 0 <= b < e <= self.n
+            calls["epoch"] += 1
+            calls["positions"] += e - b
+            opts.counters[0] = e - b
+            opts.counters[1] = 7 * (e - b)
+            opts.counters[2] = (e - b) // 2
+            opts.counters[3] = (e - b) // 2
+            opts.kernel_ms = 1e-3 * (e - b)
+            opts.launches, opts.tile_ng, opts.kernel_used, opts.in_flight = 1, 4, 1, 12288
+
+        def comm_merge(self, sides, mode):
+            calls["merge"] += 1
+            dist.barrier()  # a collective: all ranks must call it the same number of times
+
+        def check_finite(self):
+            return True
+
+        def comm_any(self, flag):
+            import torch
+            t = torch.tensor([int(bool(flag))])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(t[0])
+
+        def comm_barrier(self):
+            dist.barrier()
+
+        def close(self):
+            pass
+
+    L._Session = FakeSession
+    N.device_count = lambda: 8
+    N.device_info = lambda i: ("fake-gfx950", 256, 288 << 30)
+    N.lib = lambda: _FakeLib()
+    N.check = lambda rc: rc
+    sys.argv = ["bench.py"] + argv
+    import io
+    import contextlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_dryrun", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(out % rank, "w") as f:
+        json.dump({"stdout": buf.getvalue(), "calls": {k: v for k, v in calls.items() if k != "ids"},
+                   "same_id": len(set(calls["ids"])) == 1, "id0": calls["ids"][0][:8].hex()}, f)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = str(tmp_path / "rank%d.json")
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "1", "--config", "c2",
+            "--scale", "0.004", "--scaling", scaling]
+    mp.spawn(_worker, args=(world, port, out, argv), nprocs=world, join=True)
+    got = [json.load(open(out % r)) for r in range(world)]
+    assert got[0]["calls"]["merge"] == got[1]["calls"]["merge"] > 0
+    assert got[0]["id0"] == got[1]["id0"], "both ranks must hold rank 0's unique id"
+    assert got[1]["stdout"].strip() == ""  # only rank 0 prints
+    line = json.loads(got[0]["stdout"].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["steps"] == 2
+    assert line["unit"] == "interactions/s" and line["higher_is_better"] is True
+    # value = positives visited by ALL ranks in the timed steps / max-over-ranks time
+    timed = sum(g["calls"]["positions"] for g in got)  # warm-up + timed positions of both ranks
+    assert 0 < line["value"] * line["ms_per_step"] * 1e-3 * line["steps"] <= timed
+    assert "roofline" in line and line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
+    assert "GPUs" in line["config"]["parallelism"]
+
+
+def _fit_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import lightfm_amd._native as N
+        import lightfm_amd.lightfm as L
+        from lightfm_amd import LightFM, synthetic
+        from lightfm_amd.distributed import DistributedFit
+        log = {"epoch": 0, "merge": 0, "positions": 0}
+
+        class FakeSession(object):
+            def __init__(self, struct, item_f, user_f, device=0):
+                self.users = struct.user_features.shape[0]
+                self.struct = struct
+
+            def set_interactions(self, positives, rows, cols, data, weight):
+                assert rows.dtype == np.int32 and data.dtype == np.float32 and rows.max() < self.users
+                self.n = len(rows)
+
+            def build_positives(self, n_users, n_items):
+                pass
+
+            def comm_init(self, uid, r, n):
+                pass
+
+            def device_shuffle(self, k0, k1, slot=0):
+                pass
+
+            def epoch(self, loss, ia, ua, k, n, seeds, opts, slot=0):
+                log["epoch"] += 1
+                log["positions"] += int(opts.pos_end - opts.pos_begin)
+                self.struct.user_features[:] += 1.0  # "training": every own user row moves
+
+            def comm_merge(self, sides, mode):
+                log["merge"] += 1
+                dist.barrier()
+
+            def check_finite(self):
+                return True
+
+            def comm_any(self, flag):
+                return bool(flag)
+
+            def sync_to_host(self, struct):
+                pass
+
+            def close(self):
+                pass
+
+        L._Session = FakeSession
+        N.lib = lambda: _FakeLib()
+        N.check = lambda rc: rc
+        data = synthetic.make_interactions(400, 300, 20000, seed=3).astype(np.float64)  # wrong dtype on purpose
+        model = LightFM(no_components=8, loss="warp", random_state=5)
+        fit = DistributedFit(model, data, rank, world, device=rank, dist=dist)
+        before = model.user_embeddings.copy()
+        fit.run(epochs=2)
+        fit.gather_users()
+        fit.close()
+        b0, b1 = fit.user_range
+        json.dump({"log": log, "n_local": int(fit.shard.nnz), "range": [b0, b1], "global_n": int(fit.global_n),
+                   "moved_all": bool(np.all(model.user_embeddings != before))}, open(out % rank, "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_distributed_fit_control_flow_two_ranks(tmp_path):
+    """DistributedFit (the class a multi-GPU user drives) with a stand-in session: dtype coercion of the
+    interactions, disjoint contiguous user ranges covering every user, every local position trained once per
+    epoch, the same number of merges on both ranks, and gather_users() delivering the other rank's rows."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = str(tmp_path / "fit%d.json")
+    mp.spawn(_fit_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [json.load(open(out % r)) for r in range(world)]
+    assert got[0]["log"]["merge"] == got[1]["log"]["merge"] > 2
+    assert got[0]["range"][0] == 0 and got[0]["range"][1] == got[1]["range"][0] and got[1]["range"][1] == 400
+    for g in got:
+        assert g["log"]["positions"] == 2 * g["n_local"]
+        assert g["moved_all"], "after gather_users every rank holds the trained rows of every user"
+    assert got[0]["n_local"] + got[1]["n_local"] == got[0]["global_n"] == got[1]["global_n"] > 15000
