@@ -248,6 +248,12 @@ def main():
     want_quality = world == 1 and not args.no_quality and cfg["shape"] == "ml-20m"
     train, feats, test, global_n, n_users, n_items = build_workload(args.config, rank, world, scaling, args.scale,
                                                                      want_quality)
+    if world > 1 and scaling == "weak":
+        # every rank generated its own shard: the merge schedule must be derived from ONE global count
+        import torch
+        t = torch.tensor([train.nnz], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        global_n = int(t[0])
     if args.emulate_shard > 1 and world == 1:
         from lightfm_amd.distributed import local_shard
         train, _ = local_shard(train, 0, args.emulate_shard, rebase=True)
