@@ -97,6 +97,40 @@ __global__ __launch_bounds__(256) void rmw_kernel(float *tab, uint32_t rows, int
     }
 }
 
+// Other read-modify-write flavours on random 256-B rows (64 lanes, one element per lane), to learn what the
+// atomic rate depends on -- operations or dwords:
+//   0 atomicAdd(float) whose OLD value is used (returning atomic)      1 atomicAdd(unsigned)
+//   2 atomicAdd(double): 64 lanes x 8 B = a 512-B row                   3 atomicCAS(64 bit), one attempt
+//   4 atomicMax(unsigned)
+template <int BURST>
+__global__ __launch_bounds__(256) void atomic_flavour_kernel(float *tab, uint32_t rows, int iters, int flavour, float *out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t s = mix(wave * 977u + 13u);
+    float acc = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int b = 0; b < BURST; ++b) {
+            s = lcg(s);
+            const uint32_t r = mix(s) % rows;
+            if (flavour == 0) {
+                acc += atomicAdd(tab + (size_t)r * 64 + lane, 1e-9f);
+            } else if (flavour == 1) {
+                atomicAdd(reinterpret_cast<unsigned *>(tab) + (size_t)r * 64 + lane, 1u);
+            } else if (flavour == 2) {
+                atomicAdd(reinterpret_cast<double *>(tab) + (size_t)(r / 2) * 64 + lane, 1e-9);
+            } else if (flavour == 3) {
+                unsigned long long *q = reinterpret_cast<unsigned long long *>(tab) + (size_t)(r / 2) * 64 + lane;
+                atomicCAS(q, 0ull, (unsigned long long)it);
+            } else {
+                atomicMax(reinterpret_cast<unsigned *>(tab) + (size_t)r * 64 + lane, (unsigned)it);
+            }
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 static float *alloc(size_t bytes, bool uncached)
 {
     void *p = nullptr;
@@ -167,6 +201,16 @@ int main()
                 double rows_n = (double)grid * 4 * iters * 6;
                 printf("rmw    %-34s %s %2d waves/CU burst  6: %7.1f GB/s read + the same atomically added (%.2f G "
                        "rows/s)\n", t.name, unc ? "uncached" : "cached  ", wpc, rows_n * 256 / ms / 1e6, rows_n / ms / 1e6);
+                if (wpc == 8) {
+                    const char *fl[5] = {"f32 add, returning", "u32 add", "f64 add (512-B rows)", "u64 CAS (512-B rows)", "u32 max"};
+                    for (int f = 0; f < 5; ++f) {
+                        ms = time_ms([&] { atomic_flavour_kernel<6><<<grid, 256>>>(tab, t.rows, iters, f, out); });
+                        const double bytes = (f == 2 || f == 3) ? 512.0 : 256.0;
+                        printf("atomic %-34s %s %2d waves/CU %-22s: %7.1f GB/s payload (%.2f G row-ops/s = %.1f G lane-ops/s)\n",
+                               t.name, unc ? "uncached" : "cached  ", wpc, fl[f], rows_n * bytes / ms / 1e6, rows_n / ms / 1e6,
+                               64 * rows_n / ms / 1e6);
+                    }
+                }
             }
             CHECK(hipFree(tab));
         }
