@@ -96,7 +96,11 @@ typedef struct lfm_opts {
                                    1 = do not use the tile kernel (the row-stream or generic kernels run),
                                    2 = tile kernel instrumented with per-phase cycle counters */
     int32_t debug;              /* kernel experiments; bits 0-2: force the tile kernel's
-                                   interactions per wavefront pass (1, 2 or 4); 0 = auto */
+                                   interactions per wavefront pass (1, 2 or 4), 0 = auto; bit 6 (64):
+                                   the register-staged variant of the 4-per-pass tile kernel instead of
+                                   the LDS-DMA one (global_load_lds_dwordx4); bit 0 with the profiling
+                                   builds: drain the memory counters at every phase stamp; bit 5 (32):
+                                   no bias snapshots */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 / feat_kernel = 2 (profiling builds): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator
@@ -174,7 +178,10 @@ int lfm_predict(const lfm_csr *item_features, const lfm_csr *user_features,
                 const int32_t *user_ids, const int32_t *item_ids, float *predictions, int64_t n,
                 const lfm_model *model);
 
-/* predict_ranks, PYX:1232-1323 (LFM:979-987): ranks[] += count, in place */
+/* predict_ranks, PYX:1232-1323 (LFM:979-987): ranks[] += count, in place.  The dense all-items pass runs
+ * on the matrix cores (v_mfma_f32_32x32x2_f32 pre-filter + sequential-dot re-check inside the rounding
+ * band): the ranks are the reference's integers.  LIGHTFM_AMD_RANKS_MFMA = 0 | 1 select the scalar / the
+ * first MFMA kernel (cross-checks). */
 int lfm_predict_ranks(const lfm_csr *item_features, const lfm_csr *user_features,
                       const lfm_csr *test_interactions, const lfm_csr *train_interactions,
                       float *ranks, const lfm_model *model);
