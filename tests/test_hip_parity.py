@@ -158,9 +158,13 @@ def _conflict_free(n_users, n_items, seed):
 
 
 @pytest.mark.parametrize("d", [8, 64, 100])
-def test_parallel_conflict_free_is_bit_exact(fast, d):
-    """With no two interactions sharing a row, Hogwild has no races: the atomic
-    read-modify-write path must reproduce the sequential result bit for bit."""
+def test_parallel_conflict_free_matches_sequential(fast, d):
+    """With no two interactions sharing a row, Hogwild has no races: the atomic read-modify-write
+    path must reproduce the sequential result.  The bar is 1e-6 relative, not bit equality: the
+    logistic loss evaluates exp() in the device libm (the oracle uses the host's) and an update
+    published as old + fl32(new - old) differs from `new` where the subtraction is inexact; the
+    bit-exact statements of this suite are the serial-mode tests above and the WARP kernels'
+    one-interaction-per-launch / disjoint-group tests (tests/test_hip_warp_tile.py)."""
     coo = _conflict_free(300, 280, 5)
     item_f, user_f = H.identity_features(280), H.identity_features(300)
     rng = np.random.RandomState(1)
