@@ -31,6 +31,8 @@ extern "C" {
 #define LFM_ENOMEM (-3)   /* device or host allocation failed */
 #define LFM_ECOMM (-4)    /* RCCL failure */
 #define LFM_EUNSUPPORTED (-5)
+#define LFM_ECORRUPT (-6) /* LIGHTFM_AMD_VALIDATE=1 (debugging): a read-only device input of the session
+                             changed, or the shuffle slot is not a permutation (csrc/session.hip) */
 
 /* CSRMatrix (PYX:145-182): int32 indices/indptr, float32 data, C-contiguous. */
 typedef struct lfm_csr {

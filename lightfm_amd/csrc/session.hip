@@ -274,6 +274,13 @@ struct lfm_session {
     int snap_sides = 0;         // bit 0 item, bit 1 user: which sides have a valid snapshot
     DBuf<float> scratch[2];     // merge temporaries (ADAGRAD mode: this rank's dG; local reduce: sums)
 
+    // LIGHTFM_AMD_VALIDATE=1 (debugging): checksums of the read-only device inputs at the end of the
+    // previous epoch, by (address, bytes): see validate_inputs()
+    struct GuardSum { const void *p; size_t bytes; unsigned long long sum; };
+    std::vector<GuardSum> guard_sums;
+    DBuf<unsigned long long> guard_dev;
+    int64_t epochs_run = 0;
+
     ~lfm_session()
     {
         for (auto *s : shuffles) delete s;
@@ -415,6 +422,7 @@ extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *posit
     HIP_TRY(hipSetDevice(s->device));
     s->n = n;
     s->recs_valid = false;
+    s->guard_sums.clear();  // new contents: nothing to compare against
     // an argument that is NULL leaves nothing of an earlier upload behind
     if (positives) {
         LFM_TRY(validate_csr(positives, "interactions"));
@@ -755,6 +763,111 @@ extern "C" int lfm_session_comm_barrier(lfm_session *s)
     return LFM_OK;
 }
 
+// ------------------------------------------------ input integrity (debug) ---
+// LIGHTFM_AMD_VALIDATE=1: every lfm_session_epoch checksums the READ-ONLY device inputs (COO arrays,
+// packed records, positives lookup, feature CSRs, loss table) before its first launch and after its
+// last one, and range-checks the shuffle slot.  A buffer whose checksum changed inside the epoch was
+// written by one of the epoch's kernels; one that changed since the previous epoch of this session
+// was overwritten in between (another session, an upload to a stale address, the allocator).  The
+// call then fails with LFM_ECORRUPT naming the buffer instead of running kernels on garbage.
+__global__ void checksum_kernel(const uint32_t *p, int64_t n_words, unsigned long long *out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0ull;
+    for (int64_t j = t; j < n_words; j += st) acc += (unsigned long long)p[j] * (2ull * (unsigned long long)j + 1ull);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && acc) atomicAdd(out, acc);
+}
+// out[0] = entries outside [0, n), out[1] = sum of the entries (a permutation sums to n (n - 1) / 2)
+__global__ void shuffle_check_kernel(const int32_t *p, int64_t n, unsigned long long *out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0ull, sum = 0ull;
+    for (int64_t j = t; j < n; j += st) {
+        const int32_t v = p[j];
+        if (v < 0 || (int64_t)v >= n) ++bad; else sum += (unsigned long long)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        bad += __shfl_xor(bad, off, WAVE);
+        sum += __shfl_xor(sum, off, WAVE);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        if (bad) atomicAdd(out, bad);
+        if (sum) atomicAdd(out + 1, sum);
+    }
+}
+
+static bool validate_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("LIGHTFM_AMD_VALIDATE");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
+// when: 0 = before the epoch's first launch, 1 = after its last one (stream synchronised by the caller)
+static int validate_inputs(lfm_session *s, int slot, int when, bool recs_in_use)
+{
+    struct Item { const char *name; const void *p; size_t bytes; };
+    std::vector<Item> items;
+    auto add = [&](const char *name, const void *p, size_t bytes) {
+        if (p && bytes >= 4) items.push_back(Item{name, p, bytes & ~(size_t)3});
+    };
+    add("user_ids", s->user_ids.p, s->user_ids.n * 4);
+    add("item_ids", s->item_ids.p, s->item_ids.n * 4);
+    add("Y", s->Y.p, s->Y.n * 4);
+    add("sample_weight", s->weight.p, s->weight.n * 4);
+    if (recs_in_use && s->recs_valid) add("records", s->recs.p, s->recs.n * sizeof(int4));
+    add("positives.indptr", s->pos.indptr.p, s->pos.indptr.p ? ((size_t)s->pos.rows + 1) * 4 : 0);
+    add("positives.indices", s->pos.indices.p, (size_t)s->pos.nnz * 4);
+    add("item_features.indptr", s->itf.indptr.p, s->itf.indptr.n * 4);
+    add("item_features.indices", s->itf.indices.p, s->itf.indices.n * 4);
+    add("item_features.data", s->itf.data.p, s->itf.data.n * 4);
+    add("user_features.indptr", s->usf.indptr.p, s->usf.indptr.n * 4);
+    add("user_features.indices", s->usf.indices.p, s->usf.indices.n * 4);
+    add("user_features.data", s->usf.data.p, s->usf.data.n * 4);
+    const size_t k = items.size();
+    LFM_TRY(s->guard_dev.alloc(k + 2));
+    HIP_TRY(hipMemsetAsync(s->guard_dev.p, 0, (k + 2) * sizeof(unsigned long long), s->stream));
+    for (size_t i = 0; i < k; ++i) {
+        const int64_t words = (int64_t)(items[i].bytes / 4);
+        checksum_kernel<<<grid_for(words), 256, 0, s->stream>>>((const uint32_t *)items[i].p, words, s->guard_dev.p + i);
+    }
+    if (s->n > 0)
+        shuffle_check_kernel<<<grid_for(s->n), 256, 0, s->stream>>>(s->shuffles[slot]->p, s->n, s->guard_dev.p + k);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> sums(k + 2);
+    HIP_TRY(hipMemcpyAsync(sums.data(), s->guard_dev.p, (k + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    char msg[256];
+    if (s->n > 0) {
+        const unsigned long long want = (unsigned long long)s->n * (unsigned long long)(s->n - 1) / 2ull;
+        if (sums[k] != 0ull || sums[k + 1] != want) {
+            snprintf(msg, sizeof(msg), "LIGHTFM_AMD_VALIDATE: shuffle slot %d is not a permutation of [0, %lld): %llu entries out of "
+                     "range, sum %llu instead of %llu (%s epoch %lld)", slot, (long long)s->n, sums[k], sums[k + 1], want,
+                     when ? "after" : "before", (long long)s->epochs_run);
+            return fail(LFM_ECORRUPT, msg);
+        }
+    }
+    for (size_t i = 0; i < k; ++i) {
+        for (const auto &g : s->guard_sums) {
+            if (g.p == items[i].p && g.bytes == items[i].bytes && g.sum != sums[i]) {
+                snprintf(msg, sizeof(msg), "LIGHTFM_AMD_VALIDATE: read-only device buffer '%s' (%zu bytes at %p) changed %s: checksum "
+                         "%016llx -> %016llx", items[i].name, items[i].bytes, items[i].p,
+                         when ? "INSIDE the epoch (written by one of its kernels)" : "BETWEEN two epochs of this session",
+                         g.sum, sums[i]);
+                return fail(LFM_ECORRUPT, msg);
+            }
+        }
+    }
+    s->guard_sums.clear();
+    for (size_t i = 0; i < k; ++i) s->guard_sums.push_back(lfm_session::GuardSum{items[i].p, items[i].bytes, sums[i]});
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------------ epoch ---
 
 static void tile_geometry(int d, int want_rows, int *rows, int *stride)
@@ -934,6 +1047,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (a.sampled_log) HIP_TRY(hipMemsetAsync(a.sampled_log, 0, (size_t)s->n * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, 12 * sizeof(unsigned long long), s->stream));
 
+    const bool recs_in_use = a.recs != nullptr;
+    if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 0, recs_in_use));
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -1088,6 +1203,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     opts->launches = n_launches;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
+    if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));
+    ++s->epochs_run;
     return LFM_OK;
 }
 
@@ -1147,6 +1264,7 @@ extern "C" int lfm_session_build_positives(lfm_session *s, int32_t n_users, int3
     if ((double)n_users * (double)n_items >= 1.8e19) return fail(LFM_EUNSUPPORTED, "shape beyond 64-bit keys");
     HIP_TRY(hipSetDevice(s->device));
     s->pos.clear();
+    s->guard_sums.clear();
     LFM_TRY(s->pos.indptr.alloc((size_t)n_users + 1));
     DBuf<int32_t> idx;
     LFM_TRY(idx.alloc((size_t)std::max<int64_t>(s->n, 1)));
