@@ -11,6 +11,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_lib", "liblfm_hip.so")
 
+# Kernel arguments in HOST memory (the HIP runtime's classic path) unless the user decided otherwise.
+# On this GPU generation the runtime otherwise writes them into device memory through the PCIe BAR
+# and flushes the host data path before the doorbell; long irregular processes (the GPU test-suite)
+# sporadically behaved as if a kernel had run with the arguments of an earlier launch (DESIGN.md
+# "Known issue").  Unproven, harmless (a few hundred bytes per launch travel the other way; the
+# epoch kernels run for ~1 ms), and it has to be in the environment before the HIP runtime loads.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "0")
+
 F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)
 U32P = C.POINTER(C.c_uint32)
