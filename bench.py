@@ -215,17 +215,20 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
     from lightfm_amd import _native as N
     from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
     from lightfm_amd.distributed import MergePolicy, merge_schedule, segment_positions
     from lightfm_amd.lightfm import LightFM, _Session
     from lightfm_amd.options import options
+    # liblfm_hip.so (and with it /opt/rocm's HIP runtime, the one its kernels and librccl were built
+    # for) is loaded BEFORE torch brings its own copy of the runtime into the process
+    n_devices = N.device_count()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     tuned = {k: getattr(args, k) for k in ("update_mode", "first_batch", "launches_per_epoch", "max_waves",
                                            "warp_kernel", "feat_kernel", "debug", "ramp_k", "shared_cap")
@@ -238,7 +241,7 @@ def main():
         policy.merge_k = args.merge_k
     if args.merge_max:
         policy.merge_max = args.merge_max
-    if N.device_count() <= local_rank:
+    if n_devices <= local_rank:
         raise SystemExit("no HIP device for local rank %d" % local_rank)
     dev_name, cus, hbm = N.device_info(local_rank)
 
