@@ -1,0 +1,117 @@
+"""Register / scratch budgets the design relies on, checked at COMPILE time (hipcc cross-compiles for
+gfx950 without a GPU; `-Rpass-analysis=kernel-resource-usage`):
+
+  * no production kernel spills to scratch (a spill in the MFMA sweep of predict_ranks or in the
+    tile kernel's gather would put memory round trips into their inner loops);
+  * the LDS-DMA tile kernel fits three workgroups per CU (<= 168 VGPRs: 12 wavefronts per CU is
+    where its throughput comes from), the register-staged variant two;
+  * the MFMA ranks kernel runs two wavefronts per SIMD for d <= 64.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lightfm_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+         "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c"]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def _usage(source, tmp_path):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    out = subprocess.run([hipcc] + FLAGS + [os.path.join(CSRC, source), "-o", str(tmp_path / "x.o")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    kernels, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"remark: +Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark: +(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    assert kernels, "no resource remarks in the compiler output"
+    return kernels
+
+
+def _one(kernels, fragment):
+    hits = [v for k, v in kernels.items() if fragment in k]
+    assert len(hits) == 1, (fragment, sorted(kernels))
+    return hits[0]
+
+
+@pytest.mark.timeout(1200)
+def test_tile_kernel_budgets(tmp_path):
+    k = _usage("warp_tile_lpr16.hip", tmp_path)
+    for name, u in k.items():
+        assert u["ScratchSize"] == 0, (name, u)
+    # fit_warp_tile_kernel<16, 4, TIMED = false, ADADELTA = false, DMA4 = true / false>
+    dma = _one(k, "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb1EEE")
+    regs = _one(k, "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb0EEE")
+    assert dma["VGPRs"] + dma["AGPRs"] <= 168 and dma["Occupancy"] == 3, dma
+    assert regs["Occupancy"] == 2 and dma["VGPRs"] < regs["VGPRs"], (dma, regs)
+
+
+@pytest.mark.timeout(1200)
+def test_scoring_kernel_budgets(tmp_path):
+    k = _usage("predict_kernels.hip", tmp_path)
+    for name, u in k.items():
+        assert u["ScratchSize"] == 0, (name, u)
+    for ks in (16, 32):  # d <= 32, d <= 64: two wavefronts per SIMD (MFMA of one overlaps the compares of the other)
+        u = _one(k, "ranks_mfma2_kernelILi%dEEE" % ks)
+        assert u["Occupancy"] >= 2 and u["VGPRs"] + u["AGPRs"] <= 256, (ks, u)
+    assert _one(k, "ranks_mfma2_kernelILi64EEE")["Occupancy"] >= 1
+
+
+@pytest.mark.timeout(1200)
+def test_row_stream_kernel_budgets(tmp_path):
+    k = _usage("feat_kernels.hip", tmp_path)
+    for name, u in k.items():
+        assert u["ScratchSize"] == 0, (name, u)
+        assert u["Occupancy"] >= 2, (name, u)  # 8 wavefronts per CU are launched (csrc/session.hip)
+
+
+def _asm(source, tmp_path):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    flags = [f for f in FLAGS if f not in ("-c", "-Rpass-analysis=kernel-resource-usage")]
+    out = subprocess.run([hipcc] + flags + ["-S", os.path.join(CSRC, source), "-o", str(tmp_path / "x.s")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    text = open(str(tmp_path / "x.s")).read()
+    bodies = {}
+    for m in re.finditer(r"^(_ZN3lfm\w+):.*?s_endpgm", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(0)
+    return bodies
+
+
+@pytest.mark.timeout(1200)
+def test_instruction_selection_of_the_hot_kernels(tmp_path):
+    """What the kernels are DESIGNED around is what the compiler emitted: LDS-DMA gathers with no
+    ds_write staging and hardware float atomics in the tile kernel; the matrix cores in predict_ranks."""
+    tile = _asm("warp_tile_lpr16.hip", tmp_path)
+    dma = [b for n, b in tile.items() if "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb1EEE" in n][0]
+    regs = [b for n, b in tile.items() if "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb0EEE" in n][0]
+    assert dma.count("global_load_lds_dwordx4") >= 12  # user rows (loop), positive row, up to 15 candidates
+    assert "ds_write_b128" not in dma and regs.count("ds_write_b128") > 10
+    assert dma.count("global_atomic_add_f32") >= 8 and "scratch_" not in dma
+    assert "row_newbcast" in dma  # candidate ids reach the loading lanes by DPP
+    ranks = _asm("predict_kernels.hip", tmp_path)
+    sweep = [b for n, b in ranks.items() if "ranks_mfma2_kernelILi32EEE" in n][0]
+    assert sweep.count("v_mfma_f32_32x32x2_f32") == 32  # d = 64: 32 steps of k = 2
+    assert "scratch_" not in sweep and "v_pk_add_f32" in sweep
