@@ -46,9 +46,6 @@ import os
 import sys
 import time
 
-# before anything loads the HIP runtime (torch does, for N > 1): see lightfm_amd/_native.py
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "0")
-
 import numpy as np
 import scipy.sparse as sp
 

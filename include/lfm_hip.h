@@ -31,7 +31,8 @@ extern "C" {
 #define LFM_ENOMEM (-3)   /* device or host allocation failed */
 #define LFM_ECOMM (-4)    /* RCCL failure */
 #define LFM_EUNSUPPORTED (-5)
-#define LFM_ECORRUPT (-6) /* LIGHTFM_AMD_VALIDATE=1 (debugging): a read-only device input of the session
+#define LFM_ECORRUPT (-6) /* an epoch kernel read a shuffle entry outside [0, n) (invalid shuffle input or
+                              corrupted device memory); LIGHTFM_AMD_VALIDATE=1 (debugging): a read-only device input of the session
                              changed, or the shuffle slot is not a permutation (csrc/session.hip) */
 
 /* CSRMatrix (PYX:145-182): int32 indices/indptr, float32 data, C-contiguous. */
@@ -139,6 +140,14 @@ float lfm_last_kernel_ms(void);
 int lfm_device_count(void);
 /* name (<=255 chars) and CU count of a device; used by bench.py */
 int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hbm_bytes);
+
+/* Device memory of the library comes from a process-wide pool (csrc/pool.hpp): buffers of destroyed
+ * sessions are kept and reused instead of going through hipFree / hipMalloc (see DESIGN.md "Root cause of
+ * the round-2 process abort").  lfm_device_trim hands the unused part back to the HIP runtime (bytes via
+ * *released, may be NULL); lfm_device_pool_stats reports the bytes held / currently unused.  No
+ * counterpart in the reference (host memory is numpy's). */
+int lfm_device_trim(int64_t *released);
+int lfm_device_pool_stats(int64_t *reserved, int64_t *cached);
 
 /* ------------------------------------------------------------------------
  * One-shot epoch drivers: upload, run ONE epoch on device 0, download.

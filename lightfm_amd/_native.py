@@ -11,14 +11,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_lib", "liblfm_hip.so")
 
-# Kernel arguments in HOST memory (the HIP runtime's classic path) unless the user decided otherwise.
-# On this GPU generation the runtime otherwise writes them into device memory through the PCIe BAR
-# and flushes the host data path before the doorbell; long irregular processes (the GPU test-suite)
-# sporadically behaved as if a kernel had run with the arguments of an earlier launch (DESIGN.md
-# "Known issue").  Unproven, harmless (a few hundred bytes per launch travel the other way; the
-# epoch kernels run for ~1 ms), and it has to be in the environment before the HIP runtime loads.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "0")
-
 F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)
 U32P = C.POINTER(C.c_uint32)
@@ -72,6 +64,7 @@ EXPORTS = (
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
+    "lfm_device_trim", "lfm_device_pool_stats",
     "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_merge_begin",
     "lfm_session_comm_any", "lfm_session_comm_barrier", "lfm_sessions_merge_local",
 )
@@ -138,6 +131,20 @@ def require(a, dtype, ndim, name):
     if not a.flags.c_contiguous:
         raise ValueError("ndarray is not C-contiguous (%s)" % name)
     return a
+
+
+def device_trim():
+    """Hands the library's cached device memory back to the HIP runtime; returns the bytes released."""
+    released = C.c_int64()
+    check(lib().lfm_device_trim(C.byref(released)))
+    return released.value
+
+
+def device_pool_stats():
+    """(bytes held from the HIP runtime, bytes of them currently unused)."""
+    reserved, cached = C.c_int64(), C.c_int64()
+    check(lib().lfm_device_pool_stats(C.byref(reserved), C.byref(cached)))
+    return reserved.value, cached.value
 
 
 def device_count():

@@ -21,6 +21,8 @@ HEADERS = ["device.hpp", "kernels.hpp", "warp_tile_kernel.hpp", "feat_kernel.hpp
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+if os.environ.get("LFM_BUILD_DEBUG"):  # line tables + symbols for rocgdb (same code generation)
+    FLAGS.append("-g")
 
 
 def _stale(target, deps):

@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.hpp"
+#include "pool.hpp"
 
 namespace lfm {
 
@@ -63,16 +65,18 @@ hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids,
     uint64_t *k0 = nullptr, *k1 = nullptr;
     int *d_count = nullptr;
     void *tmp = nullptr;
+    // the temporaries come from the library's pool (pool.hpp) and go back there once the stream has drained
     auto cleanup = [&]() {
-        if (k0) (void)hipFree(k0);
-        if (k1) (void)hipFree(k1);
-        if (d_count) (void)hipFree(d_count);
-        if (tmp) (void)hipFree(tmp);
+        (void)hipStreamSynchronize(st);
+        pool_free(k0);
+        pool_free(k1);
+        pool_free(d_count);
+        pool_free(tmp);
     };
 #define CSR_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
-    CSR_TRY(hipMalloc((void **)&k0, (size_t)n * sizeof(uint64_t)));
-    CSR_TRY(hipMalloc((void **)&k1, (size_t)n * sizeof(uint64_t)));
-    CSR_TRY(hipMalloc((void **)&d_count, sizeof(int)));
+    CSR_TRY(pool_alloc((void **)&k0, (size_t)n * sizeof(uint64_t)));
+    CSR_TRY(pool_alloc((void **)&k1, (size_t)n * sizeof(uint64_t)));
+    CSR_TRY(pool_alloc((void **)&d_count, sizeof(int)));
     const int grid = (int)std::min<int64_t>(8192, (n + 255) / 256);
     make_keys_kernel<<<grid, 256, 0, st>>>(user_ids, item_ids, n, (uint64_t)n_items, k0);
     const int end_bit = std::min(64, bits_for((uint64_t)n_users * (uint64_t)n_items));
@@ -80,7 +84,7 @@ hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids,
     size_t sort_bytes = 0, uniq_bytes = 0;
     CSR_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys, (int)n, 0, end_bit, st));
     CSR_TRY(hipcub::DeviceSelect::Unique(nullptr, uniq_bytes, k0, k1, d_count, (int)n, st));
-    CSR_TRY(hipMalloc(&tmp, std::max(sort_bytes, uniq_bytes)));
+    CSR_TRY(pool_alloc(&tmp, std::max(sort_bytes, uniq_bytes)));
     CSR_TRY(hipcub::DeviceRadixSort::SortKeys(tmp, sort_bytes, keys, (int)n, 0, end_bit, st));
     uint64_t *sorted = keys.Current(), *uniq = keys.Alternate();
     CSR_TRY(hipcub::DeviceSelect::Unique(tmp, uniq_bytes, sorted, uniq, d_count, (int)n, st));

@@ -70,9 +70,22 @@ struct FitArgs {
     int32_t stage_rows;    // feat_kernel.hpp: rows of the wave's LDS-DMA staging area
     int32_t cand_base;     // feat_kernel.hpp: first candidate-negative row of the representation tile
     int32_t *neg_log, *sampled_log;
-    unsigned long long *counters;  // [4]
+    unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
     double *scale_prod;            // [2] parallel mode: product of (1+alpha*avg_lr) of this launch
 };
+
+// counters[12]: set when a shuffle entry outside [0, n) was read.  A shuffle slot is a permutation of
+// [0, n), so this never fires on intact inputs; on corrupted device memory the epoch then ends with
+// LFM_ECORRUPT instead of a wild COO index faulting the GPU (which aborts the host process).
+constexpr int FAULT_SLOT = 12;
+__device__ __forceinline__ int guard_row(const FitArgs &a, int r)
+{
+    if ((uint32_t)r >= (uint32_t)a.n) {
+        a.counters[FAULT_SLOT] = 1ull;
+        r = 0;
+    }
+    return r;
+}
 
 // ------------------------------------------------------------------ lanes ---
 

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const int64_t nw = (int64_t)gridDim.x * wpb;
     const uint32_t base_seed = LOSS != LFM_LOSS_LOGISTIC_ID ? a.seeds[0] : 0u;
     auto fetch = [&](int row) -> int4 {
+        row = guard_row(a, row);
         if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) return make_int4(a.user_ids[row], 0, 0, 0);
         else return a.recs[row];
     };

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, OCC) void fit_warp_kernel(FitArgs a)
     int row1 = 0, c_user = 0, c_pos = 0;
     float c_y = 0.0f, c_w = 0.0f;
     if (i < a.end) {
-        int row0 = a.shuffle[i];
+        int row0 = guard_row(a, a.shuffle[i]);
         c_user = a.user_ids[row0];
         c_pos = a.item_ids[row0];
         c_y = a.Y[row0];
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, OCC) void fit_warp_kernel(FitArgs a)
         float n_y = 0.0f, n_w = 0.0f;
         if (i + 2 * nw < a.end) row2 = a.shuffle[i + 2 * nw];
         if (i + nw < a.end) {
+            row1 = guard_row(a, row1);
             n_user = a.user_ids[row1];
             n_pos = a.item_ids[row1];
             n_y = a.Y[row1];
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void fit_bpr_kernel(FitArgs a)
     const uint32_t base_seed = a.seeds[0];
     const uint32_t n_examples = (uint32_t)a.n;
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {
-        int row = uni(a.shuffle[i]);
+        int row = guard_row(a, uni(a.shuffle[i]));
         if (!(a.Y[row] > 0.0f)) {  // PYX:1116-1117
             log_pos(a, i, -1, 0, lane);
             continue;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void fit_logistic_kernel(FitArgs a)
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {
-        int row = uni(a.shuffle[i]);
+        int row = guard_row(a, uni(a.shuffle[i]));
         int user = uni(a.user_ids[row]), item = uni(a.item_ids[row]);
         float weight = unif(a.weight[row]);
         Rep<NC> U, I;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
     uint32_t state = a.serial ? a.seeds[a.seed_idx] : 0u;
     const uint32_t base_seed = a.seeds[0];
     for (int64_t i = a.begin + gw; i < a.end; i += nw) {
-        int row = uni(a.shuffle[i]);
+        int row = guard_row(a, uni(a.shuffle[i]));
         int user = uni(a.user_ids[row]);
         if (!a.serial) state = position_seed(base_seed, (uint64_t)i);
         int start = uni(a.pos.indptr[user]), stop = uni(a.pos.indptr[user + 1]);

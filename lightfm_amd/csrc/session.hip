@@ -18,6 +18,7 @@
 #include "../../include/lfm_hip.h"
 #include "device.hpp"
 #include "kernels.hpp"
+#include "pool.hpp"
 
 using namespace lfm;
 
@@ -70,6 +71,26 @@ extern "C" int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hb
     return LFM_OK;
 }
 
+// Releases the library's cached (unused) device memory to the HIP runtime (csrc/pool.hpp); returns
+// the number of bytes released through *released.  Sessions in use are not affected.
+extern "C" int lfm_device_trim(int64_t *released)
+{
+    (void)hipDeviceSynchronize();
+    const size_t b = DevPool::instance().trim();
+    if (released) *released = (int64_t)b;
+    return LFM_OK;
+}
+
+// bytes the pool holds from the runtime / the part of them not handed out at the moment
+extern "C" int lfm_device_pool_stats(int64_t *reserved, int64_t *cached)
+{
+    size_t r = 0, c = 0;
+    DevPool::instance().stats(&r, &c);
+    if (reserved) *reserved = (int64_t)r;
+    if (cached) *cached = (int64_t)c;
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------ device memory ---
 
 // Allocation flavour of the weight tables: 0 = hipMalloc (coarse-grained: an XCD's L2 may serve
@@ -99,34 +120,94 @@ static int table_alloc_mask()
     return m;
 }
 
+// LIGHTFM_AMD_TRACE=1 (debugging): every device allocation / release and every epoch launch is
+// written to stderr, so that a faulting address reported by the runtime can be attributed.
+static bool trace_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("LIGHTFM_AMD_TRACE");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
+// LIGHTFM_AMD_VALIDATE (debugging): 1 = checksums of the read-only device inputs around every epoch
+// (validate_inputs); 2 = additionally every uploaded buffer keeps a host-side shadow copy and is read
+// back and compared with it before every epoch (DBuf::verify): a mismatch names the buffer, the first
+// differing word and what the device holds instead.
+static int validate_level()
+{
+    static const int lvl = [] {
+        const char *e = getenv("LIGHTFM_AMD_VALIDATE");
+        return e ? atoi(e) : 0;
+    }();
+    return lvl;
+}
+
 template <typename T>
 struct DBuf {
     T *p = nullptr;
     size_t n = 0;
     int flags = 0;  // hipExtMallocWithFlags flags (0 = plain hipMalloc)
+    std::vector<unsigned char> shadow;  // LIGHTFM_AMD_VALIDATE=2: what was uploaded last
     ~DBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (trace_enabled()) fprintf(stderr, "LFM_FREE  %p %zu\n", (void *)p, n * sizeof(T));
+            pool_free(p);  // pool.hpp: no synchronisation -- the owner has waited for the work that used it
+        }
         p = nullptr;
         n = 0;
+        shadow.clear();
     }
     int alloc(size_t count)
     {
         if (count == n && p) return LFM_OK;
+        // a buffer that changes size goes back to the pool: nothing in flight may still use it
+        if (p) (void)hipDeviceSynchronize();
         release();
         if (count == 0) return LFM_OK;
-        hipError_t e = flags ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), (unsigned)flags)
-                             : hipMalloc((void **)&p, count * sizeof(T));
+        hipError_t e = pool_alloc((void **)&p, count * sizeof(T), flags);
         if (e != hipSuccess) return fail(LFM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
         n = count;
+        if (trace_enabled()) fprintf(stderr, "LFM_ALLOC %p %zu flags %d\n", (void *)p, n * sizeof(T), flags);
         return LFM_OK;
     }
     int upload(const T *src, size_t count)
     {
         LFM_TRY(alloc(count));
         if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        if (validate_level() >= 2) {
+            shadow.assign((const unsigned char *)src, (const unsigned char *)src + count * sizeof(T));
+            LFM_TRY(verify("right after its upload"));
+        }
         return LFM_OK;
+    }
+    // LIGHTFM_AMD_VALIDATE=2: the device contents against the shadow copy of the last upload
+    int verify(const char *when) const
+    {
+        if (shadow.empty() || !p || shadow.size() != n * sizeof(T)) return LFM_OK;
+        std::vector<unsigned char> back(shadow.size());
+        HIP_TRY(hipMemcpy(back.data(), p, back.size(), hipMemcpyDeviceToHost));
+        if (memcmp(back.data(), shadow.data(), back.size()) == 0) return LFM_OK;
+        const uint32_t *b = (const uint32_t *)back.data(), *e = (const uint32_t *)shadow.data();
+        const size_t words = back.size() / 4;
+        size_t first = words, last = 0, bad = 0;
+        for (size_t i = 0; i < words; ++i)
+            if (b[i] != e[i]) {
+                if (first == words) first = i;
+                last = i;
+                ++bad;
+            }
+        char msg[512];
+        snprintf(msg, sizeof(msg), "LIGHTFM_AMD_VALIDATE: device buffer %p (%zu bytes) differs from what was uploaded, %s: %zu of %zu "
+                 "words, first at word %zu (expected %08x %08x %08x %08x, device holds %08x %08x %08x %08x), last at word %zu",
+                 (void *)p, back.size(), when, bad, words, first, first < words ? e[first] : 0u, first + 1 < words ? e[first + 1] : 0u,
+                 first + 2 < words ? e[first + 2] : 0u, first + 3 < words ? e[first + 3] : 0u, first < words ? b[first] : 0u,
+                 first + 1 < words ? b[first + 1] : 0u, first + 2 < words ? b[first + 2] : 0u, first + 3 < words ? b[first + 3] : 0u, last);
+        fprintf(stderr, "%s\n", msg);
+        return fail(LFM_ECORRUPT, msg);
     }
     int download(T *dst) const
     {
@@ -176,6 +257,20 @@ struct DevCsr {
         identity = false;
     }
     DCsr view() const { return DCsr{indices.p, indptr.p, data.p, rows, cols, identity ? 1 : 0}; }
+};
+
+// Per-call device buffers go back to the pool when their DBuf leaves scope -- on every path, error
+// returns included -- and the pool does not synchronise: declare one of these AFTER the buffers (it
+// is then destroyed BEFORE them) so the stream has drained by the time they are released.
+struct DrainOnExit {
+    hipStream_t st;
+    bool device_wide;
+    explicit DrainOnExit(hipStream_t s, bool all = false) : st(s), device_wide(all) {}
+    ~DrainOnExit()
+    {
+        if (device_wide) (void)hipDeviceSynchronize();
+        else (void)hipStreamSynchronize(st);
+    }
 };
 
 static int validate_csr(const lfm_csr *m, const char *what)
@@ -283,6 +378,8 @@ struct lfm_session {
 
     ~lfm_session()
     {
+        // the buffers go back to the pool without any implicit synchronisation (hipFree had one)
+        if (stream) (void)hipStreamSynchronize(stream);
         for (auto *s : shuffles) delete s;
         if (comm && rccl()) rccl()->CommDestroy(comm);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -341,6 +438,50 @@ static int validate_model(const lfm_model *m)
     return LFM_OK;
 }
 
+// ids that index device tables are range-checked on the device at upload: an out-of-range id would
+// otherwise fault the GPU inside an epoch kernel, and a GPU memory fault aborts the host process
+// (the reference reads out of bounds in the same situation, PYX:828-829).
+__global__ void id_range_kernel(const int32_t *p, int64_t n, int32_t *lohi)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
+    for (int64_t j = t; j < n; j += st) {
+        const int32_t v = p[j];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, WAVE));
+        hi = max(hi, __shfl_xor(hi, off, WAVE));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && lo <= hi) {
+        atomicMin(lohi, lo);
+        atomicMax(lohi + 1, hi);
+    }
+}
+
+static int check_id_range(lfm_session *s, const int32_t *dev, int64_t n, int64_t limit, const char *what)
+{
+    if (n <= 0 || !dev) return LFM_OK;
+    DBuf<int32_t> lohi;
+    DrainOnExit drain(s->stream);
+    const int32_t init[2] = {0x7fffffff, (int32_t)0x80000000};
+    LFM_TRY(lohi.alloc(2));
+    HIP_TRY(hipMemcpyAsync(lohi.p, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    id_range_kernel<<<(int)std::min<int64_t>(2048, (n + 255) / 256), 256, 0, s->stream>>>(dev, n, lohi.p);
+    HIP_TRY(hipGetLastError());
+    int32_t got[2];
+    HIP_TRY(hipMemcpyAsync(got, lohi.p, sizeof(got), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (got[0] < 0 || (int64_t)got[1] >= limit) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "%s out of range: values span [%d, %d], valid is [0, %lld)", what, got[0], got[1], (long long)limit);
+        return fail(LFM_EINVAL, msg);
+    }
+    return LFM_OK;
+}
+
 extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
                                   const lfm_csr *item_features, const lfm_csr *user_features)
 {
@@ -392,10 +533,15 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     double sc[2] = {model->item_scale, model->user_scale}, one[2] = {1.0, 1.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
     if (rc == LFM_OK) guard(s->scale_prod.upload(one, 2));
-    if (rc == LFM_OK) guard(s->counters.alloc(12));
+    if (rc == LFM_OK) guard(s->counters.alloc(13));
     if (rc == LFM_OK) guard(s->flag.alloc(1));
     if (rc == LFM_OK) guard(s->itf.upload(item_features, true, true));
     if (rc == LFM_OK) guard(s->usf.upload(user_features, true, true));
+    // feature ids index the embedding tables
+    if (rc == LFM_OK && !s->itf.identity)
+        guard(check_id_range(s, s->itf.indices.p, s->itf.nnz, s->n_feat[0], "item_features.indices"));
+    if (rc == LFM_OK && !s->usf.identity)
+        guard(check_id_range(s, s->usf.indices.p, s->usf.nnz, s->n_feat[1], "user_features.indices"));
     if (rc != LFM_OK) {
         delete s;
         return rc;
@@ -436,6 +582,13 @@ extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *posit
     s->weight_aliases_Y = (Y != nullptr && sample_weight == Y);
     if (sample_weight && !s->weight_aliases_Y) LFM_TRY(s->weight.upload(sample_weight, (size_t)n));
     else s->weight.release();
+    LFM_TRY(check_id_range(s, s->user_ids.p, n, s->usf.rows, "user_ids (rows of user_features)"));
+    LFM_TRY(check_id_range(s, s->item_ids.p, s->item_ids.p ? n : 0, s->itf.rows, "item_ids (rows of item_features)"));
+    if (positives) {
+        if (positives->rows < 0 || positives->cols > s->itf.rows)
+            return fail(LFM_EINVAL, "interactions matrix has more columns than item_features has rows");
+        LFM_TRY(check_id_range(s, s->pos.indices.p, s->pos.nnz, std::max<int64_t>(positives->cols, 1), "interactions.indices"));
+    }
     return LFM_OK;
 }
 
@@ -799,36 +952,41 @@ __global__ void shuffle_check_kernel(const int32_t *p, int64_t n, unsigned long 
     }
 }
 
-static bool validate_enabled()
-{
-    static const bool on = [] {
-        const char *e = getenv("LIGHTFM_AMD_VALIDATE");
-        return e && atoi(e) != 0;
-    }();
-    return on;
-}
+static bool validate_enabled() { return validate_level() >= 1; }
 
 // when: 0 = before the epoch's first launch, 1 = after its last one (stream synchronised by the caller)
 static int validate_inputs(lfm_session *s, int slot, int when, bool recs_in_use)
 {
-    struct Item { const char *name; const void *p; size_t bytes; };
+    struct Item { const char *name; const void *p; size_t bytes; const std::vector<unsigned char> *shadow; };
     std::vector<Item> items;
-    auto add = [&](const char *name, const void *p, size_t bytes) {
-        if (p && bytes >= 4) items.push_back(Item{name, p, bytes & ~(size_t)3});
+    auto add = [&](const char *name, const void *p, size_t bytes, const std::vector<unsigned char> *shadow = nullptr) {
+        if (p && bytes >= 4) items.push_back(Item{name, p, bytes & ~(size_t)3, shadow});
     };
-    add("user_ids", s->user_ids.p, s->user_ids.n * 4);
-    add("item_ids", s->item_ids.p, s->item_ids.n * 4);
-    add("Y", s->Y.p, s->Y.n * 4);
-    add("sample_weight", s->weight.p, s->weight.n * 4);
+    add("user_ids", s->user_ids.p, s->user_ids.n * 4, &s->user_ids.shadow);
+    add("item_ids", s->item_ids.p, s->item_ids.n * 4, &s->item_ids.shadow);
+    add("Y", s->Y.p, s->Y.n * 4, &s->Y.shadow);
+    add("sample_weight", s->weight.p, s->weight.n * 4, &s->weight.shadow);
     if (recs_in_use && s->recs_valid) add("records", s->recs.p, s->recs.n * sizeof(int4));
-    add("positives.indptr", s->pos.indptr.p, s->pos.indptr.p ? ((size_t)s->pos.rows + 1) * 4 : 0);
-    add("positives.indices", s->pos.indices.p, (size_t)s->pos.nnz * 4);
-    add("item_features.indptr", s->itf.indptr.p, s->itf.indptr.n * 4);
-    add("item_features.indices", s->itf.indices.p, s->itf.indices.n * 4);
-    add("item_features.data", s->itf.data.p, s->itf.data.n * 4);
-    add("user_features.indptr", s->usf.indptr.p, s->usf.indptr.n * 4);
-    add("user_features.indices", s->usf.indices.p, s->usf.indices.n * 4);
-    add("user_features.data", s->usf.data.p, s->usf.data.n * 4);
+    add("positives.indptr", s->pos.indptr.p, s->pos.indptr.p ? ((size_t)s->pos.rows + 1) * 4 : 0, &s->pos.indptr.shadow);
+    add("positives.indices", s->pos.indices.p, (size_t)s->pos.nnz * 4, &s->pos.indices.shadow);
+    add("item_features.indptr", s->itf.indptr.p, s->itf.indptr.n * 4, &s->itf.indptr.shadow);
+    add("item_features.indices", s->itf.indices.p, s->itf.indices.n * 4, &s->itf.indices.shadow);
+    add("item_features.data", s->itf.data.p, s->itf.data.n * 4, &s->itf.data.shadow);
+    add("user_features.indptr", s->usf.indptr.p, s->usf.indptr.n * 4, &s->usf.indptr.shadow);
+    add("user_features.indices", s->usf.indices.p, s->usf.indices.n * 4, &s->usf.indices.shadow);
+    add("user_features.data", s->usf.data.p, s->usf.data.n * 4, &s->usf.data.shadow);
+    if (validate_level() >= 2) {
+        const char *w = when ? "after the epoch" : "before the epoch";
+        LFM_TRY(s->user_ids.verify(w));
+        LFM_TRY(s->item_ids.verify(w));
+        LFM_TRY(s->Y.verify(w));
+        LFM_TRY(s->weight.verify(w));
+        for (const DevCsr *f : {&s->pos, &s->itf, &s->usf}) {
+            LFM_TRY(f->indptr.verify(w));
+            LFM_TRY(f->indices.verify(w));
+            LFM_TRY(f->data.verify(w));
+        }
+    }
     const size_t k = items.size();
     LFM_TRY(s->guard_dev.alloc(k + 2));
     HIP_TRY(hipMemsetAsync(s->guard_dev.p, 0, (k + 2) * sizeof(unsigned long long), s->stream));
@@ -849,6 +1007,20 @@ static int validate_inputs(lfm_session *s, int slot, int when, bool recs_in_use)
             snprintf(msg, sizeof(msg), "LIGHTFM_AMD_VALIDATE: shuffle slot %d is not a permutation of [0, %lld): %llu entries out of "
                      "range, sum %llu instead of %llu (%s epoch %lld)", slot, (long long)s->n, sums[k], sums[k + 1], want,
                      when ? "after" : "before", (long long)s->epochs_run);
+            return fail(LFM_ECORRUPT, msg);
+        }
+    }
+    // level 2: what a KERNEL reads (through the caches) against the uploaded bytes (the shadow copy)
+    for (size_t i = 0; i < k && validate_level() >= 2; ++i) {
+        if (!items[i].shadow || items[i].shadow->size() < items[i].bytes) continue;
+        const uint32_t *w = (const uint32_t *)items[i].shadow->data();
+        unsigned long long want = 0ull;
+        for (size_t j = 0; j < items[i].bytes / 4; ++j) want += (unsigned long long)w[j] * (2ull * (unsigned long long)j + 1ull);
+        if (want != sums[i]) {
+            snprintf(msg, sizeof(msg), "LIGHTFM_AMD_VALIDATE: a kernel reads device buffer '%s' (%zu bytes at %p) differently from what was "
+                     "uploaded (checksum %016llx, uploaded %016llx) %s epoch %lld although a read-back copy matches",
+                     items[i].name, items[i].bytes, items[i].p, sums[i], want, when ? "after" : "before", (long long)s->epochs_run);
+            fprintf(stderr, "%s\n", msg);
             return fail(LFM_ECORRUPT, msg);
         }
     }
@@ -1045,7 +1217,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
     if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
     if (a.sampled_log) HIP_TRY(hipMemsetAsync(a.sampled_log, 0, (size_t)s->n * 4, s->stream));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 12 * sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 13 * sizeof(unsigned long long), s->stream));
 
     const bool recs_in_use = a.recs != nullptr;
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 0, recs_in_use));
@@ -1144,6 +1316,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
             const int grid = (int)std::min<int64_t>(max_grid, (waves + wpb - 1) / wpb);
+            if (trace_enabled())
+                fprintf(stderr, "LFM_LAUNCH s=%p loss %d [%lld, %lld) grid %d ng %d feat %d shuffle %p ids %p %p Y %p w %p pos %p %p W %p %p\n",
+                        (void *)s, loss, (long long)a.begin, (long long)a.end, grid, ng, (int)use_feat, (const void *)a.shuffle,
+                        (const void *)a.user_ids, (const void *)a.item_ids, (const void *)a.Y, (const void *)a.weight,
+                        (const void *)a.pos.indptr, (const void *)a.pos.indices, (void *)a.m.W[0], (void *)a.m.W[1]);
             int grid_used = grid;
             if (ng) {
                 // Scoring reads twelve 4-byte biases per interaction.  With uncached tables each
@@ -1193,7 +1370,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     opts->kernel_ms = ms;
-    unsigned long long c[12];
+    unsigned long long c[13];
     LFM_TRY(s->counters.download(c));
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
@@ -1205,6 +1382,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));
     ++s->epochs_run;
+    if (c[FAULT_SLOT])  // device.hpp: guard_row
+        return fail(LFM_ECORRUPT, "a shuffle entry outside [0, n) was read on the device: the shuffle slot is not a permutation "
+                                  "(lfm_session_upload_shuffle input) or device memory is corrupted; the epoch's updates are unreliable");
     return LFM_OK;
 }
 
@@ -1267,6 +1447,7 @@ extern "C" int lfm_session_build_positives(lfm_session *s, int32_t n_users, int3
     s->guard_sums.clear();
     LFM_TRY(s->pos.indptr.alloc((size_t)n_users + 1));
     DBuf<int32_t> idx;
+    DrainOnExit drain(s->stream);
     LFM_TRY(idx.alloc((size_t)std::max<int64_t>(s->n, 1)));
     int64_t nnz = 0;
     hipError_t e = build_positives_csr(s->user_ids.p, s->item_ids.p, s->n, n_users, n_items, idx.p,
@@ -1306,8 +1487,9 @@ extern "C" int lfm_session_representations(lfm_session *s, int32_t side, const l
     if (features->rows == 0) return LFM_OK;
     HIP_TRY(hipSetDevice(s->device));
     DevCsr f;
-    LFM_TRY(f.upload(features, true, true));
     DBuf<float> demb, dbias;
+    DrainOnExit drain(s->stream);
+    LFM_TRY(f.upload(features, true, true));
     LFM_TRY(demb.alloc((size_t)features->rows * s->d));
     LFM_TRY(dbias.alloc((size_t)features->rows));
     HIP_TRY(launch_rep_rows(f.view(), s->tab[side][0].p, s->tab[side][3].p, s->d, s->d, demb.p, s->stream, 0, dbias.p));
@@ -1328,6 +1510,7 @@ extern "C" int lfm_session_predict(lfm_session *s, const int32_t *user_ids, cons
     HIP_TRY(hipSetDevice(s->device));
     DBuf<int32_t> du, di;
     DBuf<float> dout;
+    DrainOnExit drain(s->stream);
     LFM_TRY(du.upload(user_ids, (size_t)n));
     LFM_TRY(di.upload(item_ids, (size_t)n));
     LFM_TRY(dout.alloc((size_t)n));
@@ -1362,20 +1545,20 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     if (test->nnz == 0) return LFM_OK;
     HIP_TRY(hipSetDevice(s->device));
     DevCsr dtest, dtrain;
+    DBuf<float> urep, irep, dranks, ieps, tscores;
+    DBuf<int32_t> ulist, work;
+    DrainOnExit drain(s->stream);
     LFM_TRY(dtest.upload(test, false, false));
     LFM_TRY(dtrain.upload(train, false, false));
     int rs = ((s->d + 1 + 3) / 4) * 4;
-    DBuf<float> urep, irep, dranks;
     DCsr usf = s->usf.view(), itf = s->itf.view();
     usf.rows = test->rows;  // only users/items of the interaction matrix (PYX:1264, 1301)
     itf.rows = test->cols;
     LFM_TRY(urep.alloc((size_t)usf.rows * rs));
     // component-major item table: the MFMA sweep walks 2 * ceil-pow2(d / 2) rows, zero beyond the bias row
     const int irows = std::max(rs, ranks_mfma_supported(s->d) ? ranks_mfma2_item_rows(s->d) : rs);
-    DBuf<float> ieps;
     LFM_TRY(irep.alloc((size_t)itf.rows * irows));
     LFM_TRY(ieps.alloc((size_t)itf.rows * 2));
-    DBuf<float> tscores;
     LFM_TRY(tscores.alloc((size_t)test->nnz));
     HIP_TRY(hipMemsetAsync(irep.p, 0, (size_t)itf.rows * irows * sizeof(float), s->stream));
     LFM_TRY(dranks.upload(ranks, (size_t)test->nnz));
@@ -1399,7 +1582,6 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     // unset / 2 the second (a lane owns a user); the tests compare all three
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
     const int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
-    DBuf<int32_t> ulist, work;
     a.work = nullptr;
     a.n_work = 0;
     if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
@@ -1532,9 +1714,10 @@ extern "C" int lfm_auc_from_rank(const lfm_csr *ranks, const int32_t *num_train_
         return fail(LFM_ENODEV, "no HIP device available (the HIP backend has no CPU fallback)");
     HIP_TRY(hipSetDevice(0));
     DevCsr dr;
-    LFM_TRY(dr.upload(ranks, false, true));
     DBuf<int32_t> dntp;
     DBuf<float> drd, dauc;
+    DrainOnExit drain(nullptr, true);
+    LFM_TRY(dr.upload(ranks, false, true));
     LFM_TRY(dntp.upload(num_train_positives, (size_t)ranks->rows));
     LFM_TRY(dauc.upload(auc, (size_t)ranks->rows));
     DCsr v = dr.view();
@@ -1564,8 +1747,9 @@ extern "C" int lfm_in_positives(int32_t row, int32_t col, const lfm_csr *mat)
         return fail(LFM_ENODEV, "no HIP device available (the HIP backend has no CPU fallback)");
     HIP_TRY(hipSetDevice(0));
     DevCsr dm;
-    LFM_TRY(dm.upload(mat, false, false));
     DBuf<int> out;
+    DrainOnExit drain(nullptr, true);
+    LFM_TRY(dm.upload(mat, false, false));
     LFM_TRY(out.alloc(1));
     in_positives_kernel<<<1, WAVE>>>(dm.view(), row, col, out.p);
     HIP_TRY(hipGetLastError());

@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
     int c_lo = 0, c_hi = 0, row2 = 0;
     if (ib + g < a.end) {
-        cur = a.recs[a.shuffle[ib + g]];
+        cur = a.recs[guard_row(a, a.shuffle[ib + g])];
         c_lo = indptr[cur.x];
         c_hi = indptr[cur.x + 1];
     }
-    if (ib + stride + g < a.end) nxt = a.recs[a.shuffle[ib + stride + g]];
+    if (ib + stride + g < a.end) nxt = a.recs[guard_row(a, a.shuffle[ib + stride + g])];
     if (ib + 2 * stride + g < a.end) row2 = a.shuffle[ib + 2 * stride + g];
 
     for (; ib < a.end; ib += stride) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
             n_lo = indptr[nxt.x];
             n_hi = indptr[nxt.x + 1];
         }
-        if (i + 2 * stride < a.end) rec2 = a.recs[row2];
+        if (i + 2 * stride < a.end) rec2 = a.recs[guard_row(a, row2)];
         if (i + 3 * stride < a.end) row3 = a.shuffle[i + 3 * stride];
         // with one interaction per wavefront the ids are wave-uniform: keep them in SGPRs so row
         // addresses are scalar arithmetic (global_load with an SGPR base)

@@ -1,27 +1,42 @@
-/* abort_trace.c -- LD_PRELOAD shim for debugging: prints the NATIVE backtrace of whoever calls abort()
- * (and of any SIGABRT), so that a silent abort inside a runtime library can be attributed.
+/* abort_trace.c -- LD_PRELOAD shim for debugging: records the NATIVE backtrace of whoever calls abort()
+ * (and of any SIGABRT) so that an abort inside a runtime library can be attributed.  The trace goes to a
+ * FILE opened in the constructor (ABORT_TRACE_FILE, default /tmp/abort_trace.<pid>.log) and to the
+ * process's ORIGINAL stderr (duplicated in the constructor): pytest's fd capture replaces fd 2 during a
+ * test, and whatever is written there is lost when the process dies.
  *   gcc -shared -fPIC -O1 -o tools/_bin/libaborttrace.so tools/abort_trace.c -ldl
- *   LD_PRELOAD=tools/_bin/libaborttrace.so python -m pytest ...
+ *   ABORT_TRACE_FILE=gpurun_out/abort.log LD_PRELOAD=tools/_bin/libaborttrace.so python -m pytest ...
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
+static int g_fd = -1, g_err = -1;
+
+static void put(int fd, const char *s)
+{
+    if (fd >= 0 && write(fd, s, strlen(s)) < 0) { /* nothing to do */ }
+}
+
 static void dump(const char *why)
 {
     void *frames[64];
     int n = backtrace(frames, 64);
-    const char *hdr = "\n==== abort_trace: ";
-    write(2, hdr, strlen(hdr));
-    write(2, why, strlen(why));
-    write(2, " ====\n", 6);
-    backtrace_symbols_fd(frames, n, 2);
-    write(2, "==== end ====\n", 14);
+    const int fds[2] = {g_fd, g_err};
+    for (int i = 0; i < 2; ++i) {
+        if (fds[i] < 0) continue;
+        put(fds[i], "\n==== abort_trace: ");
+        put(fds[i], why);
+        put(fds[i], " ====\n");
+        backtrace_symbols_fd(frames, n, fds[i]);
+        put(fds[i], "==== end ====\n");
+        fsync(fds[i]);
+    }
 }
 
 void abort(void)
@@ -42,5 +57,11 @@ static void on_abrt(int sig)
 
 __attribute__((constructor)) static void init(void)
 {
+    char path[512];
+    const char *p = getenv("ABORT_TRACE_FILE");
+    if (p && *p) snprintf(path, sizeof(path), "%s.%d", p, (int)getpid());
+    else snprintf(path, sizeof(path), "/tmp/abort_trace.%d.log", (int)getpid());
+    g_fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    g_err = dup(2);
     signal(SIGABRT, on_abrt);
 }

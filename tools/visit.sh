@@ -1,0 +1,87 @@
+#!/bin/bash
+# tools/visit.sh <step> [args] -- everything this repo runs on the GPU box, one parametrised script
+# (gpurun --timeout N -- 'bash tools/visit.sh <step>').  Outputs land in gpurun_out/<step>/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+STEP=${1:-suite}; shift
+OUT=$R/gpurun_out/$STEP
+mkdir -p $OUT
+export PYTHONFAULTHANDLER=1
+PYT="python3 -m pytest -p no:cacheprovider"
+summ() { grep -aE "abort_trace|Memory access fault|callbackQueue|HSA_STATUS|hipError|VALIDATE|FAILED|ERROR|passed|failed|Fatal|Aborted|SIGSEGV|SIGABRT|received signal|malloc|free\(\)|corrupt" "$1" | cut -c1-400 | head -${2:-30}; }
+
+case $STEP in
+hunt)
+  # The process abort.  -s: no fd capture, so ROCr / ROCclr / glibc messages reach the log.
+  export LD_PRELOAD=$R/tools/_bin/libaborttrace.so ABORT_TRACE_FILE=$OUT/abort_trace
+  died=0
+  for i in 1 2 3; do
+    timeout -k 5 400 $PYT tests -m gpu -x -q -s --deselect tests/test_precision_parity.py > $OUT/plain_$i.log 2>&1
+    rc=$?; echo "plain run $i: exit $rc  $(grep -aE ' passed| failed' $OUT/plain_$i.log | tail -1)"
+    if [ $rc -ne 0 ]; then died=1; summ $OUT/plain_$i.log; tail -c 1500 $OUT/plain_$i.log; break; fi
+  done
+  dmesg 2>/dev/null | tail -30 > $OUT/dmesg.txt
+  unset LD_PRELOAD
+  # the same under rocgdb: a GPU memory fault stops at the faulting wave (kernel name + pc), a host abort at its frame
+  for i in 1 2; do
+    timeout -k 5 600 rocgdb -batch -ex "set pagination off" -ex "set confirm off" -ex "handle SIGUSR1 nostop noprint pass" \
+      -ex run -ex "echo \n==== STOPPED ====\n" -ex "info threads" -ex "bt 40" -ex "x/16i \$pc-32" -ex "info agents" -ex "info dispatches" \
+      -ex "thread apply all bt 12" \
+      --args python3 -m pytest -p no:cacheprovider tests -m gpu -x -q -s --deselect tests/test_precision_parity.py > $OUT/rocgdb_$i.log 2>&1
+    echo "rocgdb run $i: exit $?  $(grep -aE ' passed| failed' $OUT/rocgdb_$i.log | tail -1)"
+    if grep -aq "==== STOPPED" $OUT/rocgdb_$i.log && grep -aqE "received signal|Memory access" $OUT/rocgdb_$i.log; then
+      sed -n '/received signal/,$p' $OUT/rocgdb_$i.log | cut -c1-300 | head -120; break
+    fi
+  done
+  ls -la $OUT | head -30
+  for f in $OUT/abort_trace.*; do [ -s "$f" ] && { echo "--- $f"; head -60 "$f"; }; done
+  ;;
+hunt2)
+  # precise fault location: debug-symbol build (LFM_BUILD_DEBUG=1), allocation / launch trace, rocgdb precise memory
+  export LIGHTFM_AMD_TRACE=1
+  for i in 1 2 3; do
+    timeout -k 5 900 rocgdb -batch -ex "set pagination off" -ex "set confirm off" -ex "set amdgpu precise-memory on" \
+      -ex "handle SIGUSR1 nostop noprint pass" -ex run -ex "echo \n==== STOPPED ====\n" -ex "bt 12" -ex "x/10i \$pc-32" \
+      -ex "info dispatches" -ex "p a" -ex "p/x a.m" -ex "p \$exec" \
+      -ex "p/x \$s0" -ex "p/x \$s1" -ex "p/x \$s8" -ex "p/x \$s9" -ex "p/x \$s10" -ex "p/x \$s11" -ex "p/x \$s22" -ex "p/x \$s34" -ex "p/x \$s35" \
+      -ex "p/x \$s72" -ex "p/x \$s73" -ex "p/x \$s74" -ex "p/x \$s75" \
+      -ex "p/x \$v10" -ex "p/x \$v11" -ex "p/x \$v18" -ex "p/x \$v19" -ex "p/x \$v20" -ex "p/x \$v21" -ex "p/x \$v76" -ex "p/x \$v77" -ex "p/x \$v78" -ex "p/x \$v79" -ex "p/x \$v96" -ex "p/x \$v164" \
+      -ex "info registers" \
+      --args python3 -m pytest -p no:cacheprovider tests -m gpu -x -q -s --deselect tests/test_precision_parity.py > $OUT/rocgdb_full_$i.log 2>&1
+    echo "rocgdb precise run $i: exit $?  $(grep -aE ' passed| failed' $OUT/rocgdb_full_$i.log | tail -1)"
+    grep -av "^LFM_LAUNCH\|^\[New Thread\|^\[Thread" $OUT/rocgdb_full_$i.log | head -c 3000000 > $OUT/rocgdb_$i.log
+    grep -a "^LFM_LAUNCH" $OUT/rocgdb_full_$i.log | tail -400 > $OUT/launches_$i.log
+    grep -a "^LFM_ALLOC\|^LFM_FREE" $OUT/rocgdb_full_$i.log | tail -3000 > $OUT/allocs_$i.log
+    rm -f $OUT/rocgdb_full_$i.log
+    if grep -aq "received signal" $OUT/rocgdb_$i.log; then sed -n '/received signal/,$p' $OUT/rocgdb_$i.log | cut -c1-400 | head -150; break; fi
+  done
+  unset LIGHTFM_AMD_TRACE
+  # discriminators: does the fault survive (a) serialised kernels, (b) blit copies instead of SDMA, (c) a sync after every launch
+  for cfg in "AMD_SERIALIZE_KERNEL=3" "HSA_ENABLE_SDMA=0" "LIGHTFM_AMD_REG_SYNC=1" "PLAIN=1"; do for i in 1 2; do
+    env $cfg timeout -k 5 400 $PYT tests -m gpu -x -q -s --deselect tests/test_precision_parity.py > $OUT/cfg_${cfg%%=*}_$i.log 2>&1
+    echo "$cfg run $i: exit $?  $(grep -aE ' passed| failed|Memory access fault' $OUT/cfg_${cfg%%=*}_$i.log | tail -2 | tr '\n' ' ')"
+  done; done
+  ;;
+rootcause)
+  # the pool OFF (hipMalloc / hipFree per buffer, the round-2 behaviour): with uncached tables (default) and without
+  for cfg in "LIGHTFM_AMD_POOL=0" "LIGHTFM_AMD_POOL=0 LIGHTFM_AMD_TABLE_ALLOC=0"; do for i in 1 2 3; do
+    tag=$(echo "$cfg" | tr ' =' '__')
+    env $cfg timeout -k 5 400 $PYT tests -m gpu -x -q -s --deselect tests/test_precision_parity.py > $OUT/${tag}_$i.log 2>&1
+    echo "$cfg run $i: exit $?  $(grep -aE ' passed| failed|Memory access fault' $OUT/${tag}_$i.log | tail -2 | tr '\n' ' ')"
+    grep -aE "^FAILED|^ERROR|LFM_ECORRUPT|shuffle entry" $OUT/${tag}_$i.log | cut -c1-300 | head -4
+  done; done
+  ;;
+membench)
+  tools/_bin/membench "$@" > $OUT/membench.txt 2>&1; echo "membench exit $?"; grep -a "atomic " $OUT/membench.txt | tail -40
+  ;;
+suite)
+  # the driver's round-end command, N times (default 3), uncaptured
+  N=${1:-3}
+  for i in $(seq 1 $N); do
+    timeout -k 5 1500 $PYT tests -m gpu -x -q -s > $OUT/suite_$i.log 2>&1
+    echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 12
+  done
+  ;;
+*)
+  echo "unknown step $STEP"; exit 2;;
+esac
