@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-fit", action="store_true")
+    ap.add_argument("--item-alpha", type=float, default=0.0, help="L2 penalty on item features (BASELINE: 0)")
+    ap.add_argument("--user-alpha", type=float, default=0.0, help="L2 penalty on user features (BASELINE: 0)")
     ap.add_argument("--merge-mode", default=None, help="sum | mean | adagrad (N > 1)")
     ap.add_argument("--merge-k", type=int, default=None)
     ap.add_argument("--merge-max", type=int, default=None)
@@ -297,7 +299,7 @@ def main():
         if world == 1:
             opts, _ = make_opts()
             opts.history = state["history"]
-            session.epoch(loss, 0.0, 0.0, 5, 10, seeds, opts)
+            session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
             all_stats.append(opts)
         else:
             pos = segment_positions(merge_schedule(state["history"], global_n, world, policy), n_local)
@@ -306,7 +308,7 @@ def main():
                 opts.history = (state["history"] + int(round(global_n * pos[j] / max(1, n_local)))) // world
                 opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
                 if pos[j + 1] > pos[j]:
-                    session.epoch(loss, 0.0, 0.0, 5, 10, seeds, opts)
+                    session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
                     all_stats.append(opts)
                 session.comm_merge(1, policy.mode_id())
                 state["merges"] += 1
@@ -492,6 +494,8 @@ def main():
         }
         if tuned:
             out["config"]["non_default_options"] = tuned
+        if args.item_alpha or args.user_alpha:
+            out["config"]["item_alpha"], out["config"]["user_alpha"] = args.item_alpha, args.user_alpha
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out), flush=True)

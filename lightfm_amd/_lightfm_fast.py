@@ -100,6 +100,8 @@ def make_opts(n=0, want_log=False):
 def _record(o, logs):
     options.last_counters = list(o.counters)
     options.last_kernel_ms = float(o.kernel_ms)
+    options.last_kernel_used = int(o.kernel_used)
+    options.last_launches = int(o.launches)
     options.last_phase_cycles = list(o.phase_cycles)
     options.last_logs = logs
 

@@ -71,7 +71,9 @@ struct FitArgs {
     int32_t cand_base;     // feat_kernel.hpp: first candidate-negative row of the representation tile
     int32_t *neg_log, *sampled_log;
     unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
-    double *scale_prod;            // [2] parallel mode: product of (1+alpha*avg_lr) of this launch
+    float *reg_live;               // [4] parallel mode, lazy L2 regularisation (see RegScale): the growth of
+                                   // log(item_scale), log(user_scale) since the last launch boundary (LIVE,
+                                   // float atomics) and min(item_scale, MAX), min(user_scale, MAX) at that boundary
 };
 
 // counters[12]: set when a shuffle entry outside [0, n) was read.  A shuffle slot is a permutation of
@@ -778,32 +780,86 @@ __device__ __forceinline__ int row_len(const DCsr &f, int row)
 }
 
 struct Scales {
-    double item, user;    // scales used when computing representations
-    double prod_i, prod_u;  // parallel mode: this wave's pending (1+alpha*avg) factors
-    double item0, user0;  // parallel mode: the global scales at the start of the launch
-    double nwaves;        // parallel mode: wavefronts sharing the launch
+    double item, user;  // scales used when computing representations (PYX:311)
 };
 
-// The reference's scale grows with EVERY interaction (PYX:648-649) and multiplies every
-// representation computed afterwards (PYX:311).  In parallel mode the exact factors are folded
-// into the global scale at the launch boundary (wave_end), but the representations inside the
-// launch must not keep using the launch-start value: at alpha = 1e-4 the scale grows ~20 % per
-// 100 k interactions.  Every wavefront sees a statistically identical stream, so after its own
-// factors have multiplied up to P, the factors of all nwaves wavefronts have multiplied up to
-// about P^nwaves: that estimate scales the representations (capped where the reference would have
-// folded the scale into the weights, PYX:678-691).
-__device__ __forceinline__ void apply_scale_step(Scales &sc, double avg, double ia, double ua,
-                                                 bool serial)
+// Lazy L2 regularisation in PARALLEL mode (PYX:640-691).  The reference keeps ONE global scale per side
+// that every interaction multiplies by (1 + alpha * avg_lr) and that multiplies every representation
+// computed afterwards; all OpenMP threads share it.  Here the scale of a side is
+//     S = S0 * exp(D)
+// with S0 = the scale at the last launch boundary (float32, constant while a launch runs) and D = the
+// LIVE growth of its logarithm since then: a.reg_live[4] = {D_item, D_user, S0_item, S0_user}, one 16-byte
+// line in uncached device memory.  An interaction reads the line when it starts and adds
+// log(1 + alpha * avg_lr) to D with one hardware float atomic per side when its update is done --
+// additions commute, so thousands of interactions in flight compose like the reference's product; a
+// reader misses only the factors of the interactions in flight at that moment (as the reference's
+// threads miss each other's).  D stays small (a launch's worth), so float32 holds it: an addition's
+// rounding is unbiased and a few per cent of one increment; the running total is kept in float64 by the
+// boundary kernels (fit_kernels.hip: regularize_kernel / reg_boundary_kernel), which also fold the
+// scale into the weights (W / scale, scale := 1: regularize, PYX:652-675) once it has passed
+// MAX_REG_SCALE, and at the end of the epoch.  A launch therefore covers its full slice of the epoch
+// whatever alpha is, and no kernel evaluates a float64 exp / log in its inner loop.
+struct RegScale {
+    struct Live { float d_item, d_user, s0_item, s0_user; };
+    __device__ static __forceinline__ Live load(const float *reg_live)
+    {
+        // two 8-byte agent-scope loads: the line is written by other XCDs' atomics
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(reg_live);
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Live l;
+        l.d_item = __uint_as_float((unsigned)lo);
+        l.d_user = __uint_as_float((unsigned)(lo >> 32));
+        l.s0_item = __uint_as_float((unsigned)hi);
+        l.s0_user = __uint_as_float((unsigned)(hi >> 32));
+        return l;
+    }
+    // exp(t), t >= 0 small (a launch's growth); the hardware exponential beyond
+    __device__ static __forceinline__ float exp_f32(float t)
+    {
+        if (t < 0.03125f) return 1.0f + t * (1.0f + t * 0.5f * (1.0f + t * (1.0f / 3) * (1.0f + t * 0.25f)));
+        return __expf(t);
+    }
+    // log(1 + x) for the x = alpha * avg_lr >= 0 of one interaction
+    __device__ static __forceinline__ float log1p_f32(float x)
+    {
+        if (x < 0.0625f)
+            return x * (1.0f - x * (0.5f - x * ((1.0f / 3) - x * (0.25f - x * (0.2f - x * (1.0f / 6))))));
+        return __logf(1.0f + x);
+    }
+    // (float)(1.0 * scale) of both sides, as compute_representation uses it (PYX:306)
+    __device__ static __forceinline__ void scales(const Live &l, float &w_item, float &w_user)
+    {
+        w_item = fminf(l.s0_item * exp_f32(fmaxf(l.d_item, 0.0f)), (float)MAX_REG_SCALE);
+        w_user = fminf(l.s0_user * exp_f32(fmaxf(l.d_user, 0.0f)), (float)MAX_REG_SCALE);
+    }
+    __device__ static __forceinline__ void add(float *reg_live, float add_item, float add_user)
+    {
+        if (add_item != 0.0f) atomicAdd(reg_live + 0, add_item);  // global_atomic_add_f32
+        if (add_user != 0.0f) atomicAdd(reg_live + 1, add_user);
+    }
+};
+
+// Start of an interaction in parallel mode: pick up the live scales.
+__device__ __forceinline__ void refresh_scales(const FitArgs &a, Scales &sc)
 {
+    if (a.serial || (a.item_alpha == 0.0 && a.user_alpha == 0.0)) return;
+    float wi, wu;
+    RegScale::scales(RegScale::load(a.reg_live), wi, wu);
+    sc.item = (double)wi;
+    sc.user = (double)wu;
+}
+
+// PYX:648-649 after an interaction's update; avg = its average learning rate.
+__device__ __forceinline__ void apply_scale_step(const FitArgs &a, Scales &sc, double avg, int lane)
+{
+    const double ia = a.item_alpha, ua = a.user_alpha;
     if (ia == 0.0 && ua == 0.0) return;  // exact no-op in the reference (scale *= 1.0)
-    if (serial) {
+    if (a.serial) {
         sc.item *= (1.0 + ia * avg);
         sc.user *= (1.0 + ua * avg);
-    } else {
-        sc.prod_i *= (1.0 + ia * avg);
-        sc.prod_u *= (1.0 + ua * avg);
-        sc.item = fmin(sc.item0 * pow(sc.prod_i, sc.nwaves), MAX_REG_SCALE);
-        sc.user = fmin(sc.user0 * pow(sc.prod_u, sc.nwaves), MAX_REG_SCALE);
+    } else if (lane == 0) {
+        RegScale::add(a.reg_live, RegScale::log1p_f32((float)(ia * avg)), RegScale::log1p_f32((float)(ua * avg)));
     }
 }
 
@@ -848,7 +904,7 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
         double avg = pre_summed ? lrb[0] : sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
         avg /= (double)cells;
-        apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
+        apply_scale_step(a, sc, avg, lane);
     }
 }
 
@@ -882,7 +938,7 @@ __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int u
         double avg = pre_summed ? lrb[0] : sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
         int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
         avg /= (double)cells;
-        apply_scale_step(sc, avg, a.item_alpha, a.user_alpha, a.serial != 0);
+        apply_scale_step(a, sc, avg, lane);
     }
 }
 

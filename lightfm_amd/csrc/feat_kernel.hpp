@@ -29,8 +29,9 @@
 //             float64 cell arithmetic (PYX:416-449) for its coordinate of every row and publishes
 //             new - old with global_atomic_add_f32; the rows' bias cells are handled one per lane.
 //
-// Scope: parallel mode, adagrad, no L2 regularisation, no_components a multiple of 4 up to 128.
-// Everything else (serial mode, adadelta, alpha != 0, wider models) runs the generic kernels.
+// Scope: parallel mode, adagrad, no_components a multiple of 4 up to 128; REG instantiations carry the
+// lazy L2 regularisation (item_alpha / user_alpha != 0, PYX:640-691; device.hpp: RegScale).
+// Everything else (serial mode, adadelta, wider models) runs the generic kernels.
 #pragma once
 #include "device.hpp"
 #include "kernels.hpp"
@@ -58,7 +59,7 @@ struct Entries {
 // in_positives, 1 CSR extents + entry lists, 2 representation row gathers, 3 reduction into the
 // tile, 4 scoring and loss, 5 update row gathers (W and G), 6 cell arithmetic + publication,
 // 7 everything else (loop tail, logs).
-template <int LOSS, int NC, bool TIMED = false>
+template <int LOSS, int NC, bool TIMED = false, bool REG = false>
 __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
 {
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -86,6 +87,24 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const int max_sampled = a.m.max_sampled;
     const int cand_base = a.cand_base, CB = RR - cand_base;  // candidate rows of the tile
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    // REG: (float)(1.0 * scale) of the two sides for the current interaction (PYX:306), wave-uniform
+    float wsc_i = 1.0f, wsc_u = 1.0f;
+    const double alpha_i = REG ? a.item_alpha : 0.0, alpha_u = REG ? a.user_alpha : 0.0;
+    auto refresh = [&]() {
+        if constexpr (REG) {
+            RegScale::scales(RegScale::load(a.reg_live), wsc_i, wsc_u);
+            wsc_i = unif(wsc_i);
+            wsc_u = unif(wsc_u);
+        }
+    };
+    // PYX:640-649 after an update: lr_sum = this lane's share of the cells' learning rates, T = entries updated
+    auto scale_step = [&](double lr_sum, int T) {
+        if constexpr (REG) {
+            const double avg = wave_sum(lr_sum) / ((double)(d + 1) * (double)max(T, 1));
+            if (lane == 0 && um != 2)
+                RegScale::add(a.reg_live, RegScale::log1p_f32((float)(alpha_i * avg)), RegScale::log1p_f32((float)(alpha_u * avg)));
+        }
+    };
 
     // ---- a list of jobs (lane j = job j): CSR extent of every job and the flat entry layout
     auto job_extent = [&](int row, int side, int J, int &start, int &len, int &off, int &T) {
@@ -203,7 +222,10 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
                         accb = 0.0f;
                     }
-                    const float wt = read_lanef(e.w, t), bt = read_lanef(bx, t);
+                    float wt = read_lanef(e.w, t);
+                    const float bt = read_lanef(bx, t);
+                    if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
+                        wt = (float)((double)wt * (double)(read_lane(e.eside, t) ? wsc_u : wsc_i));
                     const float *sr = stage + (size_t)(t - ce) * d;
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // the same row) and the generations are processed one after the other with a device-scope
     // fence in between -- rare, and exactly the sequential result.
     auto update_round = [&](const Entries &e, double g0, double g1, double g2, const float (&xI)[NC],
-                            const float (&xU)[NC]) {
+                            const float (&xU)[NC], double &lr_sum) {
         const int SRh = SR >> 1;
         float *stW = stage, *stG = stage + (size_t)SRh * d;
         const bool on = lane < e.n;
@@ -278,13 +300,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                             const float x = st_ ? xU[q] : xI[q];
                             float nW, nG, nM;
                             double lr;
-                            if (a.debug & 8) {  // experiment: float32 cell arithmetic (NOT the reference's)
-                                const float gg = (float)gc * x * (float)wt;
-                                nW = oW - h.lr * rsqrtf(oG) * gg;
-                                nG = oG + gg * gg;
-                            } else {
-                                cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, 0.0, nW, nG, nM, lr);
-                            }
+                            cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, st_ ? alpha_u : alpha_i, nW, nG, nM, lr);
+                            if constexpr (REG) lr_sum += lr;
                             publish(Wp + c, nW, oW, um);
                             publish(Gp + c, nG, oG, um);
                         }
@@ -296,8 +313,9 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             {
                 float nW, nG, nM;
                 double lr;
-                cell_math(obW, obG, 0.0f, (double)e.w, gb, h, 0.0, nW, nG, nM, lr);
+                cell_math(obW, obG, 0.0f, (double)e.w, gb, h, e.eside ? alpha_u : alpha_i, nW, nG, nM, lr);
                 if (mine) {
+                    if constexpr (REG) lr_sum += lr;
                     publish(bp, nW, obW, um);
                     publish(bgp, nG, obG, um);
                 }
@@ -310,13 +328,21 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                            const float (&xU)[NC]) {
         int start, len, off, T;
         job_extent(row, side, J, start, len, off, T);
+        double lr_sum = 0.0;
         for (int r = 0; r * WAVE < T; ++r) {
             Entries e;
             round_entries(r, J, start, len, off, side, T, e.feat, e.w, e.job, e.eside);
             e.n = min(WAVE, T - r * WAVE);
             if (r > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // rounds are sequential
-            update_round(e, g0, g1, g2, xI, xU);
+            update_round(e, g0, g1, g2, xI, xU, lr_sum);
         }
+        scale_step(lr_sum, T);
+    };
+    // a list that fitted one round and was kept from the representation phase
+    auto update_kept = [&](const Entries &e, double g0, double g1, double g2, const float (&xI)[NC], const float (&xU)[NC]) {
+        double lr_sum = 0.0;
+        update_round(e, g0, g1, g2, xI, xU, lr_sum);
+        scale_step(lr_sum, e.n);
     };
     auto rep_regs = [&](int r, float (&v)[NC]) {
         const float *rp = reps + (size_t)r * TS;
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         const float y = unif(__int_as_float(cur.z)), wgt = unif(__int_as_float(cur.w));
         cur = nxt;
         row1 = row2;
+        refresh();
 
         if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
             // fit_logistic, PYX:726-775
@@ -374,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             if (yb) c0++;
             const double loss = (double)wgt * (prediction - (double)yb);
             // jobs in the order of the representation list: user row (x = item), item row (x = user)
-            if (el.n >= 0) update_round(el, loss, loss, 0.0, Uv, Iv);
+            if (el.n >= 0) update_kept(el, loss, loss, 0.0, Uv, Iv);
             else update_rows(lane == 0 ? user : item, lane == 0 ? 1 : 0, 2, loss, loss, 0.0, Uv, Iv);
             c2++;
             continue;
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 const double loss = (double)wgt * (1.0 - (double)sigmoidf_ref((float)(pp - np_)));
                 // jobs in the order of the representation list: user (+loss, x = neg - pos), positive
                 // (-loss, x = user), negative (+loss, x = user)
-                if (el.n >= 0) update_round(el, loss, -loss, loss, Uv, diff);
+                if (el.n >= 0) update_kept(el, loss, -loss, loss, Uv, diff);
                 else update_rows(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, 3, loss, -loss, loss,
                                  Uv, diff);
                 c2++;

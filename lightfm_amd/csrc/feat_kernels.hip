@@ -68,9 +68,17 @@ static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block
                                  int *grid_used, bool timed)
 {
     void (*kernel)(FitArgs) = nullptr;
-    if (timed) {  // profiling builds (per-phase shader clocks), the two BASELINE losses only
+    if (timed && a.item_alpha == 0.0 && a.user_alpha == 0.0) {  // profiling builds (per-phase shader clocks), the two BASELINE losses only
         if (loss == LFM_LOSS_BPR_ID) kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, true>;
         else if (loss == LFM_LOSS_WARP_KOS_ID) kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, true>;
+    }
+    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
+    if (!kernel && reg) switch (loss) {  // lazy L2 regularisation (device.hpp: RegScale)
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, true>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, true>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, true>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, true>; break;
+    default: return hipErrorInvalidValue;
     }
     if (!kernel) switch (loss) {
     case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC>; break;
@@ -80,9 +88,8 @@ static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block
     default: return hipErrorInvalidValue;
     }
     if (cus > 0) {  // only resident workgroups: every wavefront runs its grid-stride loop from the start
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) == hipSuccess && per_cu > 0)
-            grid = std::min(grid, per_cu * cus);
+        const int per_cu = occupancy_cached(kernel, block, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
     }
     if (grid_used) *grid_used = grid;
     kernel<<<grid, block, smem, st>>>(a);

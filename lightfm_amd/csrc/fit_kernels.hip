@@ -54,19 +54,6 @@ __device__ __forceinline__ void after_example(const FitArgs &a, Scales &sc, int 
     }
 }
 
-__device__ __forceinline__ void atomic_mul_double(double *p, double f)
-{
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-    unsigned long long old = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (true) {
-        double nv = __longlong_as_double((long long)old) * f;
-        unsigned long long want = (unsigned long long)__double_as_longlong(nv);
-        unsigned long long prev = atomicCAS(q, old, want);
-        if (prev == old) break;
-        old = prev;
-    }
-}
-
 __device__ __forceinline__ void wave_begin(const FitArgs &a, WaveCtx &w, Scales &sc, float *smem)
 {
     w.lane = lane_id();
@@ -74,13 +61,8 @@ __device__ __forceinline__ void wave_begin(const FitArgs &a, WaveCtx &w, Scales 
     w.TS = a.tile_stride;
     w.tile = smem + (size_t)wib * a.tile_rows * a.tile_stride;
     w.c0 = w.c1 = w.c2 = w.c3 = 0;
-    sc.item = a.m.scales[0];
+    sc.item = a.m.scales[0];  // serial mode; parallel mode refreshes per interaction (device.hpp: RegScale)
     sc.user = a.m.scales[1];
-    sc.prod_i = 1.0;
-    sc.prod_u = 1.0;
-    sc.item0 = sc.item;
-    sc.user0 = sc.user;
-    sc.nwaves = (double)gridDim.x * (double)(blockDim.x >> 6);
 }
 
 __device__ __forceinline__ void wave_end(const FitArgs &a, WaveCtx &w, Scales &sc)
@@ -93,9 +75,6 @@ __device__ __forceinline__ void wave_end(const FitArgs &a, WaveCtx &w, Scales &s
         if (a.serial) {
             a.m.scales[0] = sc.item;
             a.m.scales[1] = sc.user;
-        } else {
-            if (sc.prod_i != 1.0) atomic_mul_double(a.scale_prod + 0, sc.prod_i);
-            if (sc.prod_u != 1.0) atomic_mul_double(a.scale_prod + 1, sc.prod_u);
         }
     }
 }
@@ -185,6 +164,7 @@ __device__ __forceinline__ void warp_example(const FitArgs &a, WaveCtx &w, Scale
         return;
     }
     if (FAST || !a.serial) state = position_seed(base_seed, (uint64_t)i);
+    if constexpr (!FAST) refresh_scales(a, sc);
     w.c0++;
     // issued together with the row gathers; consumed by in_positives after the dots
     int pos_lo = a.pos.indptr[user], pos_hi = a.pos.indptr[user + 1];
@@ -276,6 +256,7 @@ __global__ __launch_bounds__(256) void fit_bpr_kernel(FitArgs a)
         float weight = unif(a.weight[row]);
         int user = uni(a.user_ids[row]), pos = uni(a.item_ids[row]);
         if (!a.serial) state = position_seed(base_seed, (uint64_t)i);
+        refresh_scales(a, sc);
         w.c0++;
         int neg = 0, draws = 0;
         for (int64_t j = 0; j < a.n; ++j) {  // PYX:1123-1127
@@ -325,6 +306,7 @@ __global__ __launch_bounds__(256) void fit_logistic_kernel(FitArgs a)
         int row = guard_row(a, uni(a.shuffle[i]));
         int user = uni(a.user_ids[row]), item = uni(a.item_ids[row]);
         float weight = unif(a.weight[row]);
+        refresh_scales(a, sc);
         Rep<NC> U, I;
         load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
         load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, item, sc.item, lane, I);
@@ -376,6 +358,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
             continue;
         }
         w.c0++;
+        refresh_scales(a, sc);
         Rep<NC> U, P;
         load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
         rep_to_tile<NC>(w.tile, U, d, lane);
@@ -431,22 +414,26 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
 
 // ---------------------------------------------------- lazy regularisation ---
 
-// Parallel mode, after each launch: fold the launch's (1+alpha*avg_lr) products
-// into the global scales (PYX:648-649).
-__global__ void fold_scales_kernel(double *scales, double *scale_prod)
+// Parallel mode (device.hpp: RegScale): reg_log[2] = log(item_scale), log(user_scale) at the last launch
+// boundary (float64 running totals), reg_live[4] = {growth of the logs since then (live), the scales then}.
+// Serial mode and the host see m.scales[2].  Start of a parallel epoch: reg_log := log(scales).
+__global__ void reg_log_init_kernel(const double *scales, double *reg_log, float *reg_live)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        scales[0] *= scale_prod[0];
-        scales[1] *= scale_prod[1];
-        scale_prod[0] = 1.0;
-        scale_prod[1] = 1.0;
+        for (int k = 0; k < 2; ++k) {
+            reg_log[k] = log(scales[k]);
+            reg_live[k] = 0.0f;
+            reg_live[2 + k] = (float)fmin(scales[k], MAX_REG_SCALE);
+        }
     }
 }
 
-// regularize (PYX:652-675) when `force`, locked_regularize's test (PYX:678-691) otherwise.
-__global__ void regularize_kernel(DModel m, int force)
+// regularize (PYX:652-675) when `force`, locked_regularize's test (PYX:678-691) otherwise.  reg_log != nullptr:
+// the scales are exp(reg_log + reg_live) (parallel mode, between two launches), else m.scales (serial mode).
+__global__ void regularize_kernel(DModel m, const double *reg_log, const float *reg_live, int force)
 {
-    double si = m.scales[0], su = m.scales[1];
+    double si = reg_log ? exp(reg_log[0] + (double)reg_live[0]) : m.scales[0];
+    double su = reg_log ? exp(reg_log[1] + (double)reg_live[1]) : m.scales[1];
     if (!force && !(si > MAX_REG_SCALE || su > MAX_REG_SCALE)) return;
     if (si == 1.0 && su == 1.0) return;  // x / 1.0 == x bit for bit
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -460,13 +447,30 @@ __global__ void regularize_kernel(DModel m, int force)
     }
 }
 
-__global__ void reset_scales_kernel(double *scales, int force)
+// After regularize_kernel: the launch's growth moves into the running totals; a fold resets them.
+__global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_live, int force)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (force || scales[0] > MAX_REG_SCALE || scales[1] > MAX_REG_SCALE) {
+        if (!reg_log) {  // serial mode
+            if (force || scales[0] > MAX_REG_SCALE || scales[1] > MAX_REG_SCALE) {
+                scales[0] = 1.0;
+                scales[1] = 1.0;
+            }
+            return;
+        }
+        double l0 = reg_log[0] + (double)reg_live[0], l1 = reg_log[1] + (double)reg_live[1];
+        if (force || exp(l0) > MAX_REG_SCALE || exp(l1) > MAX_REG_SCALE) {
+            l0 = 0.0;
+            l1 = 0.0;
             scales[0] = 1.0;
             scales[1] = 1.0;
         }
+        reg_log[0] = l0;
+        reg_log[1] = l1;
+        reg_live[0] = 0.0f;
+        reg_live[1] = 0.0f;
+        reg_live[2] = (float)fmin(exp(l0), MAX_REG_SCALE);
+        reg_live[3] = (float)fmin(exp(l1), MAX_REG_SCALE);
     }
 }
 
@@ -490,10 +494,8 @@ static hipError_t launch_resident(K kernel, const FitArgs &a, int grid, int bloc
                                   hipStream_t st, int cus, int *grid_used)
 {
     if (cus > 0 && block == 256) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) == hipSuccess &&
-            per_cu > 0)
-            grid = std::min(grid, per_cu * cus);
+        const int per_cu = occupancy_cached(kernel, block, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
     }
     if (grid_used) *grid_used = grid;
     kernel<<<grid, block, smem, st>>>(a);
@@ -529,18 +531,21 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st)
+hipError_t launch_reg_log_init(const double *scales, double *reg_log, float *reg_live, hipStream_t st)
 {
-    fold_scales_kernel<<<1, 64, 0, st>>>(scales, scale_prod);
+    reg_log_init_kernel<<<1, 64, 0, st>>>(scales, reg_log, reg_live);
     return hipGetLastError();
 }
 
-hipError_t launch_regularize(const DModel &m, int force, hipStream_t st)
+hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st)
 {
-    regularize_kernel<<<1024, 256, 0, st>>>(m, force);
+    // one pass over W and b of both sides (it returns at once unless a fold is due)
+    const int64_t cells = (int64_t)m.d * std::max(m.n_feat[0], m.n_feat[1]);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (cells + 255) / 256));
+    regularize_kernel<<<grid, 256, 0, st>>>(m, reg_log, reg_live, force);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    reset_scales_kernel<<<1, 64, 0, st>>>(m.scales, force);
+    reg_boundary_kernel<<<1, 64, 0, st>>>(m.scales, reg_log, reg_live, force);
     return hipGetLastError();
 }
 

@@ -3,7 +3,28 @@
 #include <algorithm>
 #include "device.hpp"
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 namespace lfm {
+
+// Resident workgroups per CU of a kernel at (block, LDS bytes): the runtime's occupancy query, asked once
+// per (kernel, block, smem) and remembered (an epoch may consist of thousands of launches).
+template <typename K>
+inline int occupancy_cached(K kernel, int block, size_t smem)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<const void *, int, size_t>, int> memo;
+    const auto key = std::make_tuple((const void *)kernel, block, smem);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) != hipSuccess) per_cu = 0;
+    memo[key] = per_cu;
+    return per_cu;
+}
 
 struct PredictArgs {
     DCsr itf, usf;
@@ -50,8 +71,10 @@ hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size
                            int *grid_used = nullptr, bool timed = false);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
-hipError_t launch_fold_scales(double *scales, double *scale_prod, hipStream_t st);
-hipError_t launch_regularize(const DModel &m, int force, hipStream_t st);
+// lazy L2 regularisation in parallel mode (device.hpp: RegScale): reg_log[2] float64 totals at the last launch
+// boundary, reg_live[4] the live state; both nullptr in serial mode (m.scales)
+hipError_t launch_reg_log_init(const double *scales, double *reg_log, float *reg_live, hipStream_t st);
+hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st);
 hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);
 
 hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st);

@@ -345,7 +345,8 @@ struct lfm_session {
     int32_t d = 0, adadelta = 0, max_sampled = 0;
     float lr = 0, rho = 0, eps = 0;
     DBuf<double> scales;      // [2]
-    DBuf<double> scale_prod;  // [2]
+    DBuf<double> reg_log;     // [2] parallel mode: log of the regularisation scales at the last launch boundary
+    DBuf<float> reg_live;     // [4] ... and their live state (device.hpp: RegScale), uncached memory
     DBuf<unsigned long long> counters;
     DBuf<uint32_t> seeds;
     DBuf<double> logtab;
@@ -530,9 +531,12 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
             if (kind_used(s, k)) guard(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
-    double sc[2] = {model->item_scale, model->user_scale}, one[2] = {1.0, 1.0};
+    double sc[2] = {model->item_scale, model->user_scale}, zero[2] = {0.0, 0.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
-    if (rc == LFM_OK) guard(s->scale_prod.upload(one, 2));
+    if (rc == LFM_OK) guard(s->reg_log.upload(zero, 2));
+    const float live0[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+    s->reg_live.flags = (int)hipDeviceMallocUncached;  // read and added to by every XCD while a launch runs
+    if (rc == LFM_OK) guard(s->reg_live.upload(live0, 4));
     if (rc == LFM_OK) guard(s->counters.alloc(13));
     if (rc == LFM_OK) guard(s->flag.alloc(1));
     if (rc == LFM_OK) guard(s->itf.upload(item_features, true, true));
@@ -1097,7 +1101,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     a.k = k;
     a.n_pos = n_positives;
     a.counters = s->counters.p;
-    a.scale_prod = s->scale_prod.p;
+    a.reg_live = s->reg_live.p;
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
     // never calls log(): PYX:881 / C_OMP:7446 (WARP), PYX:1039 / C_OMP:8452 (k-OS).
@@ -1156,7 +1160,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         return std::min<int64_t>(shared_cap, std::max<int64_t>(8, (history0 + done_this_epoch) / ramp_k));
     };
 
-    // Parallel WARP over identity features without regularisation (BASELINE configs C2/C4):
+    // Parallel WARP over identity features, with or without L2 regularisation (BASELINE configs C2/C4):
     // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
     // NG = 4 is the most instruction-efficient mapping; when a launch may keep only few
     // interactions in flight, fewer per wavefront buy more wavefronts (latency hiding).
@@ -1164,7 +1168,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
-        s->usf.identity && item_alpha == 0.0 && user_alpha == 0.0 && s->itf.rows >= 2) {
+        s->usf.identity && s->itf.rows >= 2 && !(s->adadelta && (item_alpha != 0.0 || user_alpha != 0.0))) {
         const int forced = opts->debug & 7;  // experiment override: 1, 2 or 4
         for (int ng : {4, 2, 1}) {
             if (forced && ng != forced) continue;
@@ -1194,12 +1198,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         }
     }
 
-    // Every other parallel-mode model without regularisation: the pipelined row-stream kernels
+    // Every other parallel-mode adagrad model (with or without L2 regularisation): the pipelined row-stream kernels
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
     FeatPlan fplan;
     bool use_feat = false;
-    if (!serial && !use_tile && opts->feat_kernel != 1 && item_alpha == 0.0 && user_alpha == 0.0 && !s->adadelta &&
-        s->itf.rows >= 1 && s->n > 0) {
+    if (!serial && !use_tile && opts->feat_kernel != 1 && !s->adadelta && s->itf.rows >= 1 && s->n > 0) {
         auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
         const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
         use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan);
@@ -1222,6 +1225,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const bool recs_in_use = a.recs != nullptr;
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 0, recs_in_use));
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
+    if (reg && !serial) HIP_TRY(launch_reg_log_init(s->scales.p, s->reg_log.p, s->reg_live.p, s->stream));
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
@@ -1291,27 +1295,6 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const int64_t flight = (int64_t)max_grid * wpb * per_wave;
             int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
-            if (reg) {
-                // Lazy regularisation in parallel mode.  The reference multiplies a global scale by
-                // (1 + alpha * avg_lr) per interaction and folds it into the weights once it passes
-                // MAX_REG_SCALE (PYX:640-691); between two folds every representation is multiplied
-                // by the current scale.  Thousands of concurrent interactions cannot follow a scale
-                // that moves by orders of magnitude inside one launch, so here the scale is folded
-                // into the weights at EVERY launch boundary (the fold is exact algebra: W / s with
-                // s reset to 1) and a launch is cut short enough for the scale to grow 16-fold at most
-                // inside it (the forward estimate of apply_scale_step follows it inside the launch):
-                // every interaction multiplies it by at most 1 + alpha * lr (adagrad:
-                // lr / sqrt(G >= 1) <= lr; adadelta: bounded by 1 here).
-                const double lr_max = s->adadelta ? 1.0 : (double)s->lr;
-                const double step = std::max(item_alpha, user_alpha) * std::max(lr_max, 1e-12);
-                static const double growth = [] {  // experiments: largest growth of the scale inside one launch
-                    const char *e = getenv("LIGHTFM_AMD_REG_GROWTH");
-                    const double g = e ? atof(e) : 0.0;
-                    return g > 1.0 ? g : 16.0;
-                }();
-                const double max_len = log(growth) / log1p(step);
-                if (max_len < (double)len) len = std::max<int64_t>(1, (int64_t)max_len);
-            }
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
@@ -1345,17 +1328,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
-            if (reg) {
-                HIP_TRY(launch_fold_scales(s->scales.p, s->scale_prod.p, s->stream));
-                HIP_TRY(launch_regularize(a.m, 1, s->stream));  // fold now (see above); PYX:652-675
-                // very large alpha means thousands of tiny launches: keep the queue of pending
-                // commands bounded
-                static const int sync_every = [] {
-                    const char *e = getenv("LIGHTFM_AMD_REG_SYNC");
-                    return e ? atoi(e) : 256;
-                }();
-                if (sync_every > 0 && (n_launches + 1) % sync_every == 0) HIP_TRY(hipStreamSynchronize(s->stream));
-            }
+            // Lazy L2 regularisation (device.hpp: RegScale): the scales live in s->reg_log while the
+            // launch runs; between launches they are folded into the weights when one has passed
+            // MAX_REG_SCALE (locked_regularize, PYX:678-691) -- decided on the device, no host round trip.
+            if (reg) HIP_TRY(launch_regularize(a.m, s->reg_log.p, s->reg_live.p, 0, s->stream));
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp
             in_flight = (int)std::min<int64_t>((int64_t)grid_used * wpb * per_wave, INT32_MAX);
@@ -1364,7 +1340,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         }
         tile_ng_used = ng_used;
     }
-    if (reg) HIP_TRY(launch_regularize(a.m, 1, s->stream));  // PYX:910-912 (no-op when scales are 1)
+    if (reg) HIP_TRY(launch_regularize(a.m, serial ? nullptr : s->reg_log.p, serial ? nullptr : s->reg_live.p, 1, s->stream));  // PYX:910-912
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     float ms = 0.0f;

@@ -100,8 +100,16 @@ __device__ __forceinline__ int row_bcast(int v, int k)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Sequential float32 dot of PYX:320-334 over two LDS rows, biases passed in registers.
-__device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi)
+// REG (lazy L2 regularisation active): the tile holds the RAW embedding rows and every element of a
+// representation is fl(w * x) with w = (float)(1.0 * scale) of its side (compute_representation over an
+// identity row, PYX:306-313) -- formed here, on the fly.
+template <bool REG>
+__device__ __forceinline__ float row_dot(const float *u, const float *v, int d, float bu, float bi, float wu, float wi)
 {
+    if constexpr (REG) {
+        bu = __fmul_rn(wu, bu);
+        bi = __fmul_rn(wi, bi);
+    }
     float acc = __fadd_rn(bu, bi);
     int c = 0;
     // 8 ds_read_b128 in flight per 16 coordinates: the LDS latency is paid once per block
@@ -111,6 +119,10 @@ __device__ __forceinline__ float row_dot(const float *u, const float *v, int d, 
         for (int j = 0; j < 4; ++j) {
             a[j] = ld4(u + c + 4 * j);
             x[j] = ld4(v + c + 4 * j);
+            if constexpr (REG) {
+                a[j] = make_float4(__fmul_rn(wu, a[j].x), __fmul_rn(wu, a[j].y), __fmul_rn(wu, a[j].z), __fmul_rn(wu, a[j].w));
+                x[j] = make_float4(__fmul_rn(wi, x[j].x), __fmul_rn(wi, x[j].y), __fmul_rn(wi, x[j].z), __fmul_rn(wi, x[j].w));
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -127,6 +139,10 @@ __device__ __forceinline__ float row_dot(const float *u, const float *v, int d, 
     for (; c < d; c += 4) {
         float4 a = ld4(u + c);
         float4 x = ld4(v + c);
+        if constexpr (REG) {
+            a = make_float4(__fmul_rn(wu, a.x), __fmul_rn(wu, a.y), __fmul_rn(wu, a.z), __fmul_rn(wu, a.w));
+            x = make_float4(__fmul_rn(wi, x.x), __fmul_rn(wi, x.y), __fmul_rn(wi, x.z), __fmul_rn(wi, x.w));
+        }
         acc = __fadd_rn(acc, __fmul_rn(a.x, x.x));
         acc = __fadd_rn(acc, __fmul_rn(a.y, x.y));
         acc = __fadd_rn(acc, __fmul_rn(a.z, x.z));
@@ -181,7 +197,13 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 // another (MI355X_MICROARCH.md, LDS), i.e. twelve different bank quadruples.  The four user rows
 // are fetched by one instruction per group whose LDS base is skewed by 16 bytes per group.
 // Without the staging registers the kernel fits three workgroups per CU (12 wavefronts).
-template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false>
+//
+// REG: item_alpha / user_alpha != 0 (lazy L2 regularisation, PYX:640-691).  The tile keeps RAW rows; a pass
+// reads the two live scales (device.hpp: RegScale) once, scales representations on the fly in the scoring
+// and update phases, multiplies every updated cell by 1 + alpha * lr (cell_math), sums the cells' learning
+// rates and adds log1p(alpha * avg_lr) of its interactions to the global log-scales with one float64 atomic
+// per side and pass.
+template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false, bool REG = false>
 __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fit_warp_tile_kernel(FitArgs a)
 {
     static_assert(!DMA4 || (LPR == 16 && VEC == 4), "the LDS-DMA tile layout is the four-group one");
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         lcgC = lcgC * 1103515245u + 12345u;
     }
 
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // meaningful on lanes p == 0
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // per-wave event counts: wave-uniform (ballots / lane reads), i.e. SGPRs
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
     const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
@@ -277,6 +299,10 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         stamp(0);
 
         if (__ballot(act) != 0ull) {
+            // REG: the live regularisation scales of this pass as (float)(1.0 * scale) (PYX:306), wave-uniform.
+            // Their logarithms are requested together with the first batch of candidate rows and turned
+            // into scales right after that batch's wait (a short register lifetime, no extra round trip).
+            float wu = 1.0f, wi = 1.0f;
             // ---- gather: user row, positive row, user bias
             const bool gl = act && pc;
             // One interaction per wavefront with one float per lane: a row is exactly what one
@@ -366,6 +392,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
+                // REG: the line of live regularisation state (device.hpp: RegScale), requested with the candidate rows
+                RegScale::Live live{0.0f, 0.0f, 1.0f, 1.0f};
+                if constexpr (REG) {
+                    if (done == 0) live = RegScale::load(a.reg_live);
+                }
                 // up to 10 candidate rows per round, ALL requested before the first is staged
                 const bool gln = need && pc;
                 if constexpr (DMA) {
@@ -447,8 +478,15 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 }
                 wave_sync();
                 stamp(1);  // gathers landed and staged
+                if constexpr (REG) {
+                    if (done == 0) {
+                        RegScale::scales(live, wi, wu);  // (float)(1.0 * scale), PYX:306
+                        wi = unif(wi);
+                        wu = unif(wu);
+                    }
+                }
                 float score = 0.0f;
-                if (rowlane) score = row_dot(urow, vrows + (size_t)p * KS, d, bu, bi);
+                if (rowlane) score = row_dot<REG>(urow, vrows + (size_t)p * KS, d, bu, bi, wu, wi);
                 // (one interaction per wavefront: lane reads instead of shuffles keep the whole
                 // sampling control flow below in SGPRs and scalar branches)
                 if (done == 0) pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
@@ -480,8 +518,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     const int cand = LPR == 64 ? read_lane(myitem, r) : __shfl(myitem, gbase + r, WAVE);
                     const bool found = group_in_positives<LPR>(indices, cand, LPR == 64 ? uni(c_lo) : c_lo,
                                                                LPR == 64 ? uni(c_hi) : c_hi, part, gbase, p);
+                    c3 += (uint32_t)__popcll(__ballot(part && p == 0));  // PYX:878-879: the draw still counts
                     if (part) {
-                        c3++;  // PYX:878-879: the draw still counts
                         if (!found) {
                             chosen = cand;
                             chosen_r = r;
@@ -498,11 +536,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 done += nb;
                 stamp(3);  // in_positives searches
             }
-            if (act) {
-                c0++;
-                c1 += (unsigned long long)sampled;
-                if (chosen >= 0) c2++;
-            }
+            c0 += (uint32_t)__popcll(__ballot(act && p == 0));
+            c2 += (uint32_t)__popcll(__ballot(act && chosen >= 0 && p == 0));
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg)  // inactive groups hold sampled == 0
+                c1 += (uint32_t)__builtin_amdgcn_readlane(sampled, gg * LPR);
 
             // ---- updates: one group at a time, the whole wave on its three rows ----
             // The prefetched records are forced into registers on EVERY path before any atomic
@@ -545,6 +583,10 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     }
                 }
                 stamp(4);  // accumulator rows landed
+                float avg_lr[NG];  // REG: average learning rate of each updated interaction (wave-uniform)
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) avg_lr[gg] = 0.0f;
+                const double ia = REG ? a.item_alpha : 0.0, ua = REG ? a.user_alpha : 0.0;
                 // cell arithmetic (PYX:416-449 in float64) and atomic publication
 #pragma unroll
                 for (int gg = 0; gg < NG; ++gg) {
@@ -562,27 +604,42 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         // 3*NC row cells and the bias cell are independent float64 dependency
                         // chains the scheduler interleaves), then every publication.
                         float oWr[NC][3], nWr[NC][3], nGr[NC][3], nMr[NC][3];
-                        double lr;
+                        double lr, lr_acc = 0.0;
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
                             const int c = lane + WAVE * q;
                             const int cc = c < d ? c : 0;
-                            const float Uc = tu[cc], Pc = tp[cc], Nc = tn[cc];
+                            const float Ur = tu[cc], Pr = tp[cc], Nr = tn[cc];  // raw embedding cells
+                            // representation cells (identity features): fl(w * x), PYX:306-313
+                            const float Uc = REG ? __fmul_rn(wu, Ur) : Ur, Pc = REG ? __fmul_rn(wi, Pr) : Pr,
+                                        Nc = REG ? __fmul_rn(wi, Nr) : Nr;
                             const double u = (double)Uc;
                             const double df = (double)__fsub_rn(Nc, Pc);  // float32 subtraction, PYX:634-635
-                            oWr[q][0] = Pc;
-                            oWr[q][1] = Nc;
-                            oWr[q][2] = Uc;
-                            cell_math(Pc, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, 0.0,
+                            oWr[q][0] = Pr;
+                            oWr[q][1] = Nr;
+                            oWr[q][2] = Ur;
+                            cell_math(Pr, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, ia,
                                       nWr[q][0], nGr[q][0], nMr[q][0], lr);
-                            cell_math(Nc, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, 0.0,
+                            if (REG && c < d) lr_acc += lr;
+                            if constexpr (REG) __builtin_amdgcn_sched_barrier(0);  // one cell's float64 chain at a time: registers
+                            cell_math(Nr, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, ia,
                                       nWr[q][1], nGr[q][1], nMr[q][1], lr);
-                            cell_math(Uc, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, 0.0,
+                            if (REG && c < d) lr_acc += lr;
+                            if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
+                            cell_math(Ur, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, ua,
                                       nWr[q][2], nGr[q][2], nMr[q][2], lr);
+                            if (REG && c < d) lr_acc += lr;
+                            if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
                         }
                         float bnW, bnG, bnM;
                         const float ooM = ADADELTA ? obM[gg] : 0.0f;
-                        cell_math(obW[gg], obG[gg], ooM, 1.0, lane == 0 ? -loss : loss, h, 0.0, bnW, bnG, bnM, lr);
+                        const double balpha = lane == 2 ? ua : ia;
+                        cell_math(obW[gg], obG[gg], ooM, 1.0, lane == 0 ? -loss : loss, h, balpha, bnW, bnG, bnM, lr);
+                        if constexpr (REG) {
+                            // avg_learning_rate of PYX:640-646: the 3 (d + 1) cells of three identity rows
+                            if (lane < 3) lr_acc += lr;
+                            avg_lr[gg] = unif((float)(wave_sum(lr_acc) / (double)(3 * (d + 1))));
+                        }
                         // keep the arithmetic above one block: nothing of it may sink below a publication
 #pragma unroll
                         for (int q = 0; q < NC; ++q)
@@ -595,14 +652,17 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             if (c < d) {
                                 if constexpr (ADADELTA) {
                                     // moving-average accumulators: compare-and-swap (device.hpp: publish_adadelta)
-                                    const double u = (double)oWr[q][2];
-                                    const double df = (double)__fsub_rn(oWr[q][1], oWr[q][0]);
+                                    const float Uc = REG ? __fmul_rn(wu, oWr[q][2]) : oWr[q][2];
+                                    const float Pc = REG ? __fmul_rn(wi, oWr[q][0]) : oWr[q][0];
+                                    const float Nc = REG ? __fmul_rn(wi, oWr[q][1]) : oWr[q][1];
+                                    const double u = (double)Uc;
+                                    const double df = (double)__fsub_rn(Nc, Pc);
                                     publish_cell(WiW + bp + c, Gi + bp + c, Mi + bp + c, oWr[q][0], gP[gg][q], mP[gg][q],
-                                                 nWr[q][0], nGr[q][0], nMr[q][0], 1.0, -loss * u, h, 0.0, um);
+                                                 nWr[q][0], nGr[q][0], nMr[q][0], 1.0, -loss * u, h, ia, um);
                                     publish_cell(WiW + bn + c, Gi + bn + c, Mi + bn + c, oWr[q][1], gN[gg][q], mN[gg][q],
-                                                 nWr[q][1], nGr[q][1], nMr[q][1], 1.0, loss * u, h, 0.0, um);
+                                                 nWr[q][1], nGr[q][1], nMr[q][1], 1.0, loss * u, h, ia, um);
                                     publish_cell(WuW + bu_ + c, Gu + bu_ + c, Mu + bu_ + c, oWr[q][2], gU[gg][q], mU[gg][q],
-                                                 nWr[q][2], nGr[q][2], nMr[q][2], 1.0, loss * df, h, 0.0, um);
+                                                 nWr[q][2], nGr[q][2], nMr[q][2], 1.0, loss * df, h, ua, um);
                                 } else {
                                     publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
                                     publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
@@ -619,9 +679,22 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
                             float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
                             publish_cell(bWp + brow, bGp + brow, bMp + brow, obW[gg], obG[gg], ooM, bnW, bnG, bnM, 1.0,
-                                         lane == 0 ? -loss : loss, h, 0.0, um);
+                                         lane == 0 ? -loss : loss, h, balpha, um);
                         }
                     }
+                }
+                if constexpr (REG) {
+                    // PYX:648-649 for the pass's interactions (after the publications: the logarithms'
+                    // temporaries must not overlap the cell arithmetic's registers): one float64 atomic per side
+                    float add_i = 0.0f, add_u = 0.0f;
+#pragma unroll
+                    for (int gg = 0; gg < NG; ++gg) {
+                        if ((upd >> (gg * LPR)) & 1ull) {
+                            add_i += RegScale::log1p_f32((float)ia * avg_lr[gg]);
+                            add_u += RegScale::log1p_f32((float)ua * avg_lr[gg]);
+                        }
+                    }
+                    if (lane == 0 && um != 2) RegScale::add(a.reg_live, add_i, add_u);
                 }
                 wave_sync();  // the tile is rewritten by the next pass
                 stamp(5);  // cell arithmetic, atomics issued (acknowledged, in the timed build)
@@ -643,24 +716,16 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         row2 = row3;
     }
 
-    // counters: sum over the group leaders, one atomic per wave and counter
-    if (p != 0) c0 = c1 = c2 = c3 = 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        c0 += __shfl_xor(c0, off, WAVE);
-        c1 += __shfl_xor(c1, off, WAVE);
-        c2 += __shfl_xor(c2, off, WAVE);
-        c3 += __shfl_xor(c3, off, WAVE);
-    }
+    // counters: one atomic per wave and counter
     if constexpr (TIMED) {
         if (lane == 0)
             for (int k = 0; k < 8; ++k) atomicAdd(a.counters + 4 + k, ph[k]);
     }
     if (lane == 0) {
-        if (c0) atomicAdd(a.counters + 0, c0);
-        if (c1) atomicAdd(a.counters + 1, c1);
-        if (c2) atomicAdd(a.counters + 2, c2);
-        if (c3) atomicAdd(a.counters + 3, c3);
+        if (c0) atomicAdd(a.counters + 0, (unsigned long long)c0);
+        if (c1) atomicAdd(a.counters + 1, (unsigned long long)c1);
+        if (c2) atomicAdd(a.counters + 2, (unsigned long long)c2);
+        if (c3) atomicAdd(a.counters + 3, (unsigned long long)c3);
     }
 }
 
@@ -670,14 +735,15 @@ hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStrea
                                int *grid_used)
 {
     void (*kernel)(FitArgs);
+    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
+    if (a.m.adadelta && reg) return hipErrorInvalidValue;  // session.hip routes adadelta + regularisation to the generic kernel
     if (a.m.adadelta) kernel = fit_warp_tile_kernel<LPR, VEC, false, true, DMA4>;
+    else if (reg) kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, true>;
     else if (timed) kernel = fit_warp_tile_kernel<LPR, VEC, true, false, DMA4>;
     else kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4>;
     if (cus > 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) == hipSuccess &&
-            per_cu > 0)
-            grid = std::min(grid, per_cu * cus);
+        const int per_cu = occupancy_cached(kernel, 256, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
     }
     if (grid_used) *grid_used = grid;
     kernel<<<grid, 256, smem, st>>>(a);

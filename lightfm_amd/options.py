@@ -55,6 +55,8 @@ class _Options(object):
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None
+        self.last_kernel_used = None  # 0 generic kernels, 1 lane-group tile kernel, 2 row-stream kernels
+        self.last_launches = None
         self.last_phase_cycles = None
         self.last_logs = None
 

@@ -101,9 +101,14 @@ def test_excessive_regularisation_parallel_mode(loss):
         assert np.isfinite(getattr(m, name)).all(), name
     assert _auc(m, train) < 0.65
     assert _auc(m, test) < 0.65
+    # a launch covers its slice of the epoch whatever alpha is (round 2 cut it after 56 interactions:
+    # ~1 700 launches per epoch here); every loss runs its production kernel
+    assert all(st["launches"] <= 100 for st in m._last_epoch_stats), [st["launches"] for st in m._last_epoch_stats]
+    assert all(st["kernel_used"] == (1 if loss == "warp" else 2) for st in m._last_epoch_stats)
 
 
-def test_moderate_regularisation_parallel_mode_matches_the_reference():
+@pytest.mark.parametrize("loss", ["logistic", "warp"])
+def test_moderate_regularisation_parallel_mode_matches_the_reference(loss):
     """tests/test_movielens.py:587-599: alpha = 1e-4, no_components=50, 30 epochs generalises (the
     unregularised model of :572-584 overfits).  The compiled reference is fit beside it on the same
     data; train / test AUC must agree within 0.02 and show the same ordering against overfitting."""
@@ -114,32 +119,36 @@ def test_moderate_regularisation_parallel_mode_matches_the_reference():
     train, test = _labelled_problem()
     res = {}
     for name, cls in (("hip", LightFM), ("ref", RefLightFM)):
-        reg = cls(no_components=50, item_alpha=0.0001, user_alpha=0.0001, random_state=10)
+        reg = cls(no_components=50, item_alpha=0.0001, user_alpha=0.0001, random_state=10, loss=loss)
         reg.fit_partial(train, epochs=30)
-        over = cls(no_components=50, random_state=10)
+        over = cls(no_components=50, random_state=10, loss=loss)
         over.fit_partial(train, epochs=30)
         res[name] = (_auc(reg, train), _auc(reg, test), _auc(over, train), _auc(over, test))
     print(res)
     for j in range(4):
         assert abs(res["hip"][j] - res["ref"][j]) < 0.02, (j, res)
-    assert res["hip"][2] > res["hip"][0]          # the unregularised model fits the train set better ...
-    assert res["hip"][1] > res["hip"][3] - 0.005  # ... and does not generalise better
+    if loss == "logistic":
+        assert res["hip"][2] > res["hip"][0]          # the unregularised model fits the train set better ...
+        assert res["hip"][1] > res["hip"][3] - 0.005  # ... and does not generalise better
 
 
+@pytest.mark.parametrize("layout", ["tags", "identity"])
 @pytest.mark.parametrize("loss", ["logistic", "warp", "bpr"])
-def test_frozen_weight_scale_folding_matches_the_oracle(loss):
+def test_frozen_weight_scale_folding_matches_the_oracle(loss, layout):
     """sample_weight = 0 freezes every gradient, so with alpha != 0 only the lazy regularisation
     acts: each visited interaction multiplies the global scale by (1 + alpha * avg_lr) and its cells
-    by (1 + alpha * lr) (PYX:640-691).  Multiplications commute, so the parallel fold
-    (atomic_mul_double per wavefront, fold per launch, one division at the end) must reproduce the
-    serial oracle -- up to what Hogwild's additive publication makes of concurrent multiplicative
+    by (1 + alpha * lr) (PYX:640-691).  Multiplications commute, so the parallel scheme (device.hpp:
+    RegScale -- the live log-scale, one fold at the end) must reproduce the serial oracle -- up to what Hogwild's additive publication makes of concurrent multiplicative
     steps: k wavefronts that scale the same cell at once leave 1 + k a instead of (1 + a)^k
     (a = alpha * lr = 5e-5..1e-4 here), i.e. k a^2 / 2 per collision on the shared tag rows:
     the bar is 5e-4 relative."""
     from lightfm_amd import options
     import lightfm_amd._lightfm_fast as fast
     coo = H.make_interactions(300, 200, 8000, seed=4)
-    item_f, user_f = H.tag_features(200, 12, 3, seed=1), H.identity_features(300)
+    # "tags": the row-stream kernels (feat_kernel.hpp, REG); "identity": the lane-group tile kernel for WARP
+    # (warp_tile_kernel.hpp, REG), the row-stream kernels for the others
+    item_f = H.tag_features(200, 12, 3, seed=1) if layout == "tags" else H.identity_features(200)
+    user_f = H.identity_features(300)
     rng = np.random.RandomState(0)
     st = oracle.State(item_f.shape[1], 300, 16, rng)
     a, b = st.copy(), st.copy()
@@ -165,6 +174,7 @@ def test_frozen_weight_scale_folding_matches_the_oracle(loss):
                           alpha * 2, 1)
         oracle.fit_logistic(item_f, user_f, coo.row, coo.col, coo.data, zeros, shuffle, b, alpha, alpha * 2)
     assert not np.array_equal(b.item_embeddings, st.item_embeddings)  # the regularisation did act
+    assert options.last_kernel_used == ((1 if loss == "warp" else 2) if layout == "identity" else 2)
     H.assert_states_equal(a, b, exact=False, rtol=5e-4, atol=1e-9)
 
 
