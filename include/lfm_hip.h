@@ -214,6 +214,17 @@ typedef struct lfm_session lfm_session;
 /* Uploads the model and both feature matrices to `device`. */
 int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
                        const lfm_csr *item_features, const lfm_csr *user_features);
+/* A SCORING session: only what predict / predict_rank / get_*_representations read is uploaded and kept
+ * resident -- embeddings and biases of both sides (the accumulator / momentum pointers of `model` may be
+ * NULL).  The host class keeps one per model between calls (call sites LFM:862-870, 979-987, which hand
+ * the full FastLightFM to every call) and re-uploads nothing while the weights are unchanged.
+ * lfm_session_epoch and the merge calls fail on it with LFM_EINVAL; lfm_session_load_model re-uploads
+ * just these four arrays.  The one-shot lfm_predict / lfm_predict_ranks use it internally. */
+int lfm_session_create_scoring(lfm_session **out, int device, const lfm_model *model,
+                               const lfm_csr *item_features, const lfm_csr *user_features);
+/* Replaces the resident feature matrices (predict / predict_rank take them per call, LFM:843-860,
+ * 961-977); NULL keeps a side's matrix.  The weight tables stay where they are. */
+int lfm_session_set_features(lfm_session *s, const lfm_csr *item_features, const lfm_csr *user_features);
 /* Uploads the training COO (+ positives lookup CSR; NULL for logistic).  Y and
  * sample_weight may alias (LFM:412-415).  item_ids/Y/sample_weight NULL for k-OS. */
 int lfm_session_set_interactions(lfm_session *s, const lfm_csr *positives,

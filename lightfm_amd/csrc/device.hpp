@@ -71,9 +71,9 @@ struct FitArgs {
     int32_t cand_base;     // feat_kernel.hpp: first candidate-negative row of the representation tile
     int32_t *neg_log, *sampled_log;
     unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
-    float *reg_live;               // [4] parallel mode, lazy L2 regularisation (see RegScale): the growth of
-                                   // log(item_scale), log(user_scale) since the last launch boundary (LIVE,
-                                   // float atomics) and min(item_scale, MAX), min(user_scale, MAX) at that boundary
+    float *reg_live;               // [RegScale::FLOATS] parallel mode, lazy L2 regularisation (see RegScale): line 0 =
+                                   // min(item_scale, MAX), min(user_scale, MAX) at the last launch boundary, lines 1.. =
+                                   // the slots collecting the growth of log(scale) since then (float atomics)
 };
 
 // counters[12]: set when a shuffle entry outside [0, n) was read.  A shuffle slot is a permutation of
@@ -779,41 +779,42 @@ __device__ __forceinline__ int row_len(const DCsr &f, int row)
     return f.identity ? 1 : (f.indptr[row + 1] - f.indptr[row]);
 }
 
-struct Scales {
-    double item, user;  // scales used when computing representations (PYX:311)
-};
-
 // Lazy L2 regularisation in PARALLEL mode (PYX:640-691).  The reference keeps ONE global scale per side
 // that every interaction multiplies by (1 + alpha * avg_lr) and that multiplies every representation
-// computed afterwards; all OpenMP threads share it.  Here the scale of a side is
+// computed afterwards; all OpenMP threads share it (a plain, racy read-modify-write of a double).  Here
+// the scale of a side is
 //     S = S0 * exp(D)
 // with S0 = the scale at the last launch boundary (float32, constant while a launch runs) and D = the
-// LIVE growth of its logarithm since then: a.reg_live[4] = {D_item, D_user, S0_item, S0_user}, one 16-byte
-// line in uncached device memory.  An interaction reads the line when it starts and adds
-// log(1 + alpha * avg_lr) to D with one hardware float atomic per side when its update is done --
-// additions commute, so thousands of interactions in flight compose like the reference's product; a
-// reader misses only the factors of the interactions in flight at that moment (as the reference's
-// threads miss each other's).  D stays small (a launch's worth), so float32 holds it: an addition's
-// rounding is unbiased and a few per cent of one increment; the running total is kept in float64 by the
-// boundary kernels (fit_kernels.hip: regularize_kernel / reg_boundary_kernel), which also fold the
-// scale into the weights (W / scale, scale := 1: regularize, PYX:652-675) once it has passed
-// MAX_REG_SCALE, and at the end of the epoch.  A launch therefore covers its full slice of the epoch
-// whatever alpha is, and no kernel evaluates a float64 exp / log in its inner loop.
+// growth of its logarithm since then, summed over every interaction of the launch that has updated.
+// One address that a billion interactions per second read and add to serialises the chip on ONE L2
+// channel (measured in round 3: ~85 M same-line operations/s -- C2 fell from 1.05 G to 0.10 G
+// interactions/s), so during a launch nothing shared is read or written:
+//   * WRITERS: a wavefront collects the log(1 + alpha * avg_lr) of its own interactions in two registers
+//     and publishes them ONCE, when it leaves the kernel, to one of SLOTS accumulator lines (wave id mod
+//     SLOTS; float atomics, additions commute).  The boundary kernels (fit_kernels.hip) add the slots to
+//     float64 running totals -- the exact product of the launch -- reset them, and fold the scale into
+//     the weights (W / scale, scale := 1: regularize, PYX:652-675) once it has passed MAX_REG_SCALE, and
+//     at the end of the epoch.
+//   * READERS extrapolate: D(position q of the launch) = rho * (q - begin), rho = the growth per position
+//     MEASURED over the previous launch (boundary kernel: D / positions).  Positions are visited in order
+//     by the grid-stride loops, so this is first-order exact; the error is the drift of the rate from one
+//     launch to the next (the Adagrad rates and the update frequency change by a few per cent per
+//     launch at most) times D, and the session bounds a launch to D <= ~0.5 (session.hip): a relative
+//     scale error of ~1e-2 at the very worst, 1e-4 at alpha = 1e-6 -- less than the reference's own threads
+//     lose in their racy multiply.  At every boundary the exact total replaces the estimate.
+// a.reg_live = [1 + SLOTS] lines of 128 B (uncached device memory): line 0 = {S0_item, S0_user, rho_item,
+// rho_user} (written between launches only), line 1 + s = {D_item, D_user} of slot s.
+// A launch covers its slice of the epoch whatever alpha is.  (An alpha so large that the scale passes
+// MAX_REG_SCALE INSIDE a launch: representations use the clamped scale until the boundary applies the
+// whole product -- the "excessive regularisation" regime of the reference's tests, where the model is
+// flattened either way.)
 struct RegScale {
-    struct Live { float d_item, d_user, s0_item, s0_user; };
-    __device__ static __forceinline__ Live load(const float *reg_live)
-    {
-        // two 8-byte agent-scope loads: the line is written by other XCDs' atomics
-        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(reg_live);
-        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Live l;
-        l.d_item = __uint_as_float((unsigned)lo);
-        l.d_user = __uint_as_float((unsigned)(lo >> 32));
-        l.s0_item = __uint_as_float((unsigned)hi);
-        l.s0_user = __uint_as_float((unsigned)(hi >> 32));
-        return l;
-    }
+    static constexpr int SLOTS = 16;
+    static constexpr int LINE = 32;                    // floats per 128-B line
+    static constexpr int FLOATS = LINE * (1 + SLOTS);  // size of the reg_live buffer
+
+    float p_i, p_u;  // wave-uniform: collected by this wavefront, published when it leaves
+
     // exp(t), t >= 0 small (a launch's growth); the hardware exponential beyond
     __device__ static __forceinline__ float exp_f32(float t)
     {
@@ -827,25 +828,52 @@ struct RegScale {
             return x * (1.0f - x * (0.5f - x * ((1.0f / 3) - x * (0.25f - x * (0.2f - x * (1.0f / 6))))));
         return __logf(1.0f + x);
     }
-    // (float)(1.0 * scale) of both sides, as compute_representation uses it (PYX:306)
-    __device__ static __forceinline__ void scales(const Live &l, float &w_item, float &w_user)
+    __device__ static __forceinline__ float first_lane(float x)
     {
-        w_item = fminf(l.s0_item * exp_f32(fmaxf(l.d_item, 0.0f)), (float)MAX_REG_SCALE);
-        w_user = fminf(l.s0_user * exp_f32(fmaxf(l.d_user, 0.0f)), (float)MAX_REG_SCALE);
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
     }
-    __device__ static __forceinline__ void add(float *reg_live, float add_item, float add_user)
+    // (float)(1.0 * scale) of both sides at position `done` (= q - begin) of the launch, as
+    // compute_representation uses it (PYX:306); wave-uniform
+    __device__ static __forceinline__ void scales(const float *reg_live, int64_t done, float &w_item, float &w_user)
     {
-        if (add_item != 0.0f) atomicAdd(reg_live + 0, add_item);  // global_atomic_add_f32
-        if (add_user != 0.0f) atomicAdd(reg_live + 1, add_user);
+        const float4 h = *reinterpret_cast<const float4 *>(reg_live);  // constant while the launch runs
+        const float n = (float)done;
+        w_item = first_lane(fminf(h.x * exp_f32(fmaxf(h.z * n, 0.0f)), (float)MAX_REG_SCALE));
+        w_user = first_lane(fminf(h.y * exp_f32(fmaxf(h.w * n, 0.0f)), (float)MAX_REG_SCALE));
+    }
+    __device__ __forceinline__ void begin() { p_i = p_u = 0.0f; }
+    // one updated interaction of this wavefront (all lanes call it; lane 0's values count)
+    __device__ __forceinline__ void add(float add_item, float add_user)
+    {
+        p_i = first_lane(p_i + add_item);
+        p_u = first_lane(p_u + add_user);
+    }
+    __device__ static __forceinline__ void publish(float *reg_live, float pi, float pu, int lane, unsigned wave_id)
+    {
+        if (lane == 0) {
+            float *q = reg_live + LINE * (1 + (int)(wave_id % (unsigned)SLOTS));
+            if (pi != 0.0f) atomicAdd(q + 0, pi);  // global_atomic_add_f32
+            if (pu != 0.0f) atomicAdd(q + 1, pu);
+        }
     }
 };
 
-// Start of an interaction in parallel mode: pick up the live scales.
-__device__ __forceinline__ void refresh_scales(const FitArgs &a, Scales &sc)
+struct Scales {
+    double item, user;  // scales used when computing representations (PYX:311)
+    RegScale live;      // parallel mode with alpha != 0
+};
+
+__device__ __forceinline__ bool reg_active(const FitArgs &a)
 {
-    if (a.serial || (a.item_alpha == 0.0 && a.user_alpha == 0.0)) return;
+    return !a.serial && (a.item_alpha != 0.0 || a.user_alpha != 0.0);
+}
+
+// Start of the interaction at shuffled position i in parallel mode: the estimate of the live scales.
+__device__ __forceinline__ void refresh_scales(const FitArgs &a, Scales &sc, int64_t i)
+{
+    if (!reg_active(a)) return;
     float wi, wu;
-    RegScale::scales(RegScale::load(a.reg_live), wi, wu);
+    RegScale::scales(a.reg_live, i - a.begin, wi, wu);
     sc.item = (double)wi;
     sc.user = (double)wu;
 }
@@ -858,8 +886,8 @@ __device__ __forceinline__ void apply_scale_step(const FitArgs &a, Scales &sc, d
     if (a.serial) {
         sc.item *= (1.0 + ia * avg);
         sc.user *= (1.0 + ua * avg);
-    } else if (lane == 0) {
-        RegScale::add(a.reg_live, RegScale::log1p_f32((float)(ia * avg)), RegScale::log1p_f32((float)(ua * avg)));
+    } else {
+        sc.live.add(RegScale::log1p_f32((float)(ia * avg)), RegScale::log1p_f32((float)(ua * avg)));
     }
 }
 

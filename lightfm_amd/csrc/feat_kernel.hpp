@@ -87,22 +87,20 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const int max_sampled = a.m.max_sampled;
     const int cand_base = a.cand_base, CB = RR - cand_base;  // candidate rows of the tile
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    // REG: (float)(1.0 * scale) of the two sides for the current interaction (PYX:306), wave-uniform
+    // REG: (float)(1.0 * scale) of the two sides for the current interaction (PYX:306), wave-uniform;
+    // `reg` = this wavefront's view of the live scales (device.hpp: RegScale)
     float wsc_i = 1.0f, wsc_u = 1.0f;
     const double alpha_i = REG ? a.item_alpha : 0.0, alpha_u = REG ? a.user_alpha : 0.0;
-    auto refresh = [&]() {
-        if constexpr (REG) {
-            RegScale::scales(RegScale::load(a.reg_live), wsc_i, wsc_u);
-            wsc_i = unif(wsc_i);
-            wsc_u = unif(wsc_u);
-        }
+    RegScale reg;
+    reg.begin();
+    auto refresh = [&](int64_t pos) {
+        if constexpr (REG) RegScale::scales(a.reg_live, pos - a.begin, wsc_i, wsc_u);
     };
     // PYX:640-649 after an update: lr_sum = this lane's share of the cells' learning rates, T = entries updated
     auto scale_step = [&](double lr_sum, int T) {
         if constexpr (REG) {
             const double avg = wave_sum(lr_sum) / ((double)(d + 1) * (double)max(T, 1));
-            if (lane == 0 && um != 2)
-                RegScale::add(a.reg_live, RegScale::log1p_f32((float)(alpha_i * avg)), RegScale::log1p_f32((float)(alpha_u * avg)));
+            if (um != 2) reg.add(RegScale::log1p_f32((float)(alpha_i * avg)), RegScale::log1p_f32((float)(alpha_u * avg)));
         }
     };
 
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         const float y = unif(__int_as_float(cur.z)), wgt = unif(__int_as_float(cur.w));
         cur = nxt;
         row1 = row2;
-        refresh();
+        refresh(i);
 
         if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
             // fit_logistic, PYX:726-775
@@ -584,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             }
         }
     }
+    if constexpr (REG) RegScale::publish(a.reg_live, reg.p_i, reg.p_u, lane, (unsigned)(blockIdx.x * (blockDim.x >> 6) + wib));
     if constexpr (TIMED) {
         stamp(7);
         if (lane == 0)

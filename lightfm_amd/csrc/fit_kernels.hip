@@ -63,10 +63,12 @@ __device__ __forceinline__ void wave_begin(const FitArgs &a, WaveCtx &w, Scales 
     w.c0 = w.c1 = w.c2 = w.c3 = 0;
     sc.item = a.m.scales[0];  // serial mode; parallel mode refreshes per interaction (device.hpp: RegScale)
     sc.user = a.m.scales[1];
+    sc.live.begin();  // device.hpp: RegScale
 }
 
 __device__ __forceinline__ void wave_end(const FitArgs &a, WaveCtx &w, Scales &sc)
 {
+    if (reg_active(a)) RegScale::publish(a.reg_live, sc.live.p_i, sc.live.p_u, w.lane, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (w.lane == 0) {
         if (w.c0) atomicAdd(a.counters + 0, w.c0);
         if (w.c1) atomicAdd(a.counters + 1, w.c1);
@@ -164,7 +166,7 @@ __device__ __forceinline__ void warp_example(const FitArgs &a, WaveCtx &w, Scale
         return;
     }
     if (FAST || !a.serial) state = position_seed(base_seed, (uint64_t)i);
-    if constexpr (!FAST) refresh_scales(a, sc);
+    if constexpr (!FAST) refresh_scales(a, sc, i);
     w.c0++;
     // issued together with the row gathers; consumed by in_positives after the dots
     int pos_lo = a.pos.indptr[user], pos_hi = a.pos.indptr[user + 1];
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void fit_bpr_kernel(FitArgs a)
         float weight = unif(a.weight[row]);
         int user = uni(a.user_ids[row]), pos = uni(a.item_ids[row]);
         if (!a.serial) state = position_seed(base_seed, (uint64_t)i);
-        refresh_scales(a, sc);
+        refresh_scales(a, sc, i);
         w.c0++;
         int neg = 0, draws = 0;
         for (int64_t j = 0; j < a.n; ++j) {  // PYX:1123-1127
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void fit_logistic_kernel(FitArgs a)
         int row = guard_row(a, uni(a.shuffle[i]));
         int user = uni(a.user_ids[row]), item = uni(a.item_ids[row]);
         float weight = unif(a.weight[row]);
-        refresh_scales(a, sc);
+        refresh_scales(a, sc, i);
         Rep<NC> U, I;
         load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
         load_rep<NC>(a.itf, a.m.W[0], a.m.b[0], d, item, sc.item, lane, I);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
             continue;
         }
         w.c0++;
-        refresh_scales(a, sc);
+        refresh_scales(a, sc, i);
         Rep<NC> U, P;
         load_rep<NC>(a.usf, a.m.W[1], a.m.b[1], d, user, sc.user, lane, U);
         rep_to_tile<NC>(w.tile, U, d, lane);
@@ -415,25 +417,38 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
 // ---------------------------------------------------- lazy regularisation ---
 
 // Parallel mode (device.hpp: RegScale): reg_log[2] = log(item_scale), log(user_scale) at the last launch
-// boundary (float64 running totals), reg_live[4] = {growth of the logs since then (live), the scales then}.
-// Serial mode and the host see m.scales[2].  Start of a parallel epoch: reg_log := log(scales).
+// boundary (float64 running totals); reg_live = line 0 {the scales then, the growth of their logs per
+// position measured over the last launch}, lines 1.. {slots collecting the growth of the logs since then}.
+// Serial mode and the host see m.scales[2].
+// Start of a parallel epoch: reg_log := log(scales), slots := 0 (the measured rates stay).
 __global__ void reg_log_init_kernel(const double *scales, double *reg_log, float *reg_live)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int k = 0; k < 2; ++k) {
-            reg_log[k] = log(scales[k]);
-            reg_live[k] = 0.0f;
-            reg_live[2 + k] = (float)fmin(scales[k], MAX_REG_SCALE);
-        }
+    const int t = threadIdx.x;
+    if (blockIdx.x != 0) return;
+    if (t < 2) {
+        reg_log[t] = log(scales[t]);
+        reg_live[t] = (float)fmin(scales[t], MAX_REG_SCALE);
+    }
+    if (t < RegScale::SLOTS) {
+        reg_live[RegScale::LINE * (1 + t) + 0] = 0.0f;
+        reg_live[RegScale::LINE * (1 + t) + 1] = 0.0f;
     }
 }
 
+// growth of log(scale) of `side` collected by the launch that just ended
+__device__ __forceinline__ double reg_slots_sum(const float *reg_live, int side)
+{
+    double acc = 0.0;
+    for (int s = 0; s < RegScale::SLOTS; ++s) acc += (double)reg_live[RegScale::LINE * (1 + s) + side];
+    return acc;
+}
+
 // regularize (PYX:652-675) when `force`, locked_regularize's test (PYX:678-691) otherwise.  reg_log != nullptr:
-// the scales are exp(reg_log + reg_live) (parallel mode, between two launches), else m.scales (serial mode).
+// the scales are exp(reg_log + slots) (parallel mode, between two launches), else m.scales (serial mode).
 __global__ void regularize_kernel(DModel m, const double *reg_log, const float *reg_live, int force)
 {
-    double si = reg_log ? exp(reg_log[0] + (double)reg_live[0]) : m.scales[0];
-    double su = reg_log ? exp(reg_log[1] + (double)reg_live[1]) : m.scales[1];
+    double si = reg_log ? exp(reg_log[0] + reg_slots_sum(reg_live, 0)) : m.scales[0];
+    double su = reg_log ? exp(reg_log[1] + reg_slots_sum(reg_live, 1)) : m.scales[1];
     if (!force && !(si > MAX_REG_SCALE || su > MAX_REG_SCALE)) return;
     if (si == 1.0 && su == 1.0) return;  // x / 1.0 == x bit for bit
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,7 +463,7 @@ __global__ void regularize_kernel(DModel m, const double *reg_log, const float *
 }
 
 // After regularize_kernel: the launch's growth moves into the running totals; a fold resets them.
-__global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_live, int force)
+__global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_live, int force, int64_t positions)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (!reg_log) {  // serial mode
@@ -458,7 +473,12 @@ __global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_
             }
             return;
         }
-        double l0 = reg_log[0] + (double)reg_live[0], l1 = reg_log[1] + (double)reg_live[1];
+        const double d0 = reg_slots_sum(reg_live, 0), d1 = reg_slots_sum(reg_live, 1);
+        double l0 = reg_log[0] + d0, l1 = reg_log[1] + d1;
+        if (positions >= 256) {  // the rate the next launch's readers extrapolate with (device.hpp: RegScale)
+            reg_live[2] = (float)(d0 / (double)positions);
+            reg_live[3] = (float)(d1 / (double)positions);
+        }
         if (force || exp(l0) > MAX_REG_SCALE || exp(l1) > MAX_REG_SCALE) {
             l0 = 0.0;
             l1 = 0.0;
@@ -467,10 +487,12 @@ __global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_
         }
         reg_log[0] = l0;
         reg_log[1] = l1;
-        reg_live[0] = 0.0f;
-        reg_live[1] = 0.0f;
-        reg_live[2] = (float)fmin(exp(l0), MAX_REG_SCALE);
-        reg_live[3] = (float)fmin(exp(l1), MAX_REG_SCALE);
+        for (int s = 0; s < RegScale::SLOTS; ++s) {
+            reg_live[RegScale::LINE * (1 + s) + 0] = 0.0f;
+            reg_live[RegScale::LINE * (1 + s) + 1] = 0.0f;
+        }
+        reg_live[0] = (float)fmin(exp(l0), MAX_REG_SCALE);
+        reg_live[1] = (float)fmin(exp(l1), MAX_REG_SCALE);
     }
 }
 
@@ -537,7 +559,7 @@ hipError_t launch_reg_log_init(const double *scales, double *reg_log, float *reg
     return hipGetLastError();
 }
 
-hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st)
+hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st, int64_t positions)
 {
     // one pass over W and b of both sides (it returns at once unless a fold is due)
     const int64_t cells = (int64_t)m.d * std::max(m.n_feat[0], m.n_feat[1]);
@@ -545,7 +567,7 @@ hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, 
     regularize_kernel<<<grid, 256, 0, st>>>(m, reg_log, reg_live, force);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    reg_boundary_kernel<<<1, 64, 0, st>>>(m.scales, reg_log, reg_live, force);
+    reg_boundary_kernel<<<1, 64, 0, st>>>(m.scales, reg_log, reg_live, force, positions);
     return hipGetLastError();
 }
 

@@ -74,7 +74,7 @@ hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids,
 // lazy L2 regularisation in parallel mode (device.hpp: RegScale): reg_log[2] float64 totals at the last launch
 // boundary, reg_live[4] the live state; both nullptr in serial mode (m.scales)
 hipError_t launch_reg_log_init(const double *scales, double *reg_log, float *reg_live, hipStream_t st);
-hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st);
+hipError_t launch_regularize(const DModel &m, double *reg_log, float *reg_live, int force, hipStream_t st, int64_t positions = 0);
 hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st);
 
 hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream_t st);

@@ -344,9 +344,10 @@ struct lfm_session {
     int32_t n_feat[2] = {0, 0};
     int32_t d = 0, adadelta = 0, max_sampled = 0;
     float lr = 0, rho = 0, eps = 0;
+    bool scoring_only = false;  // lfm_session_create_scoring: only W and b of both sides are resident
     DBuf<double> scales;      // [2]
     DBuf<double> reg_log;     // [2] parallel mode: log of the regularisation scales at the last launch boundary
-    DBuf<float> reg_live;     // [4] ... and their live state (device.hpp: RegScale), uncached memory
+    DBuf<float> reg_live;     // [RegScale::FLOATS] ... and their live state (device.hpp: RegScale), uncached memory
     DBuf<unsigned long long> counters;
     DBuf<uint32_t> seeds;
     DBuf<double> logtab;
@@ -424,9 +425,13 @@ static size_t tab_count(const lfm_session *s, int side, int kind)
     return kind < 3 ? (size_t)s->n_feat[side] * s->d : (size_t)s->n_feat[side];
 }
 
-static bool kind_used(const lfm_session *s, int kind) { return s->adadelta || (kind != 2 && kind != 5); }
+static bool kind_used(const lfm_session *s, int kind)
+{
+    if (s->scoring_only) return kind == 0 || kind == 3;  // scoring reads embeddings and biases only
+    return s->adadelta || (kind != 2 && kind != 5);
+}
 
-static int validate_model(const lfm_model *m)
+static int validate_model(const lfm_model *m, bool scoring = false)
 {
     if (!m) return fail(LFM_EINVAL, "null model");
     if (m->d <= 0) return fail(LFM_EINVAL, "no_components must be positive");
@@ -434,7 +439,7 @@ static int validate_model(const lfm_model *m)
     if (m->n_item_feat < 0 || m->n_user_feat < 0) return fail(LFM_EINVAL, "negative feature count");
     for (int s = 0; s < 2; ++s)
         for (int k = 0; k < 6; ++k)
-            if (!host_tab(m, s, k) && (s == 0 ? m->n_item_feat : m->n_user_feat) > 0)
+            if (!host_tab(m, s, k) && (s == 0 ? m->n_item_feat : m->n_user_feat) > 0 && (!scoring || k == 0 || k == 3))
                 return fail(LFM_EINVAL, "null weight array");
     return LFM_OK;
 }
@@ -483,12 +488,12 @@ static int check_id_range(lfm_session *s, const int32_t *dev, int64_t n, int64_t
     return LFM_OK;
 }
 
-extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
-                                  const lfm_csr *item_features, const lfm_csr *user_features)
+static int create_session(lfm_session **out, int device, const lfm_model *model, const lfm_csr *item_features,
+                          const lfm_csr *user_features, bool scoring)
 {
     if (!out) return fail(LFM_EINVAL, "null out pointer");
     *out = nullptr;
-    LFM_TRY(validate_model(model));
+    LFM_TRY(validate_model(model, scoring));
     LFM_TRY(validate_csr(item_features, "item_features"));
     LFM_TRY(validate_csr(user_features, "user_features"));
     if (item_features->cols > model->n_item_feat || user_features->cols > model->n_user_feat)
@@ -517,6 +522,7 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     s->lr = model->lr;
     s->rho = model->rho;
     s->eps = model->eps;
+    s->scoring_only = scoring;
     // Tables that fit ONE XCD's 4 MiB L2 stay cached (small models, the parity tests); beyond that
     // they are allocated uncached (see table_alloc_flags): measured on a 1/8 row shard of the
     // ML-20M shape (23 MB of tables) 880 vs 726 M interactions/s.
@@ -524,7 +530,8 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     for (int side = 0; side < 2; ++side)
         for (int k = 0; k < 6; ++k)
             if (kind_used(s, k)) table_bytes += tab_count(s, side, k) * sizeof(float);
-    const bool big_tables = table_bytes > (4u << 20) || getenv("LIGHTFM_AMD_TABLE_ALLOC") != nullptr;
+    // (a scoring session only reads its tables: ordinary cached memory)
+    const bool big_tables = !scoring && (table_bytes > (4u << 20) || getenv("LIGHTFM_AMD_TABLE_ALLOC") != nullptr);
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
             s->tab[side][k].flags = (big_tables && ((table_alloc_mask() >> k) & 1)) ? table_alloc_flags() : 0;
@@ -534,9 +541,10 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
     double sc[2] = {model->item_scale, model->user_scale}, zero[2] = {0.0, 0.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
     if (rc == LFM_OK) guard(s->reg_log.upload(zero, 2));
-    const float live0[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+    std::vector<float> live0(RegScale::FLOATS, 0.0f);  // device.hpp: RegScale (line 0 = the scales, then the slots)
+    live0[0] = live0[1] = 1.0f;
     s->reg_live.flags = (int)hipDeviceMallocUncached;  // read and added to by every XCD while a launch runs
-    if (rc == LFM_OK) guard(s->reg_live.upload(live0, 4));
+    if (rc == LFM_OK) guard(s->reg_live.upload(live0.data(), live0.size()));
     if (rc == LFM_OK) guard(s->counters.alloc(13));
     if (rc == LFM_OK) guard(s->flag.alloc(1));
     if (rc == LFM_OK) guard(s->itf.upload(item_features, true, true));
@@ -551,6 +559,38 @@ extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model
         return rc;
     }
     *out = s;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_create(lfm_session **out, int device, const lfm_model *model,
+                                  const lfm_csr *item_features, const lfm_csr *user_features)
+{
+    return create_session(out, device, model, item_features, user_features, false);
+}
+
+extern "C" int lfm_session_create_scoring(lfm_session **out, int device, const lfm_model *model,
+                                          const lfm_csr *item_features, const lfm_csr *user_features)
+{
+    return create_session(out, device, model, item_features, user_features, true);
+}
+
+extern "C" int lfm_session_set_features(lfm_session *s, const lfm_csr *item_features, const lfm_csr *user_features)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const lfm_csr *f[2] = {item_features, user_features};
+    DevCsr *dst[2] = {&s->itf, &s->usf};
+    const char *names[2] = {"item_features", "user_features"}, *idx[2] = {"item_features.indices", "user_features.indices"};
+    for (int side = 0; side < 2; ++side) {
+        if (!f[side]) continue;  // NULL keeps the resident matrix
+        LFM_TRY(validate_csr(f[side], names[side]));
+        if (f[side]->cols > s->n_feat[side]) return fail(LFM_EINVAL, "feature matrix has more columns than there are embeddings");
+        dst[side]->clear();
+        LFM_TRY(dst[side]->upload(f[side], true, true));
+        if (!dst[side]->identity) LFM_TRY(check_id_range(s, dst[side]->indices.p, dst[side]->nnz, s->n_feat[side], idx[side]));
+    }
+    s->guard_sums.clear();
     return LFM_OK;
 }
 
@@ -754,6 +794,7 @@ static int snapshot_side(lfm_session *s, int side)
 extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
 {
     if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge_begin arguments");
+    if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session has no merge intervals");
     HIP_TRY(hipSetDevice(s->device));
     for (int side = 0; side < 2; ++side)
         if ((sides >> side) & 1) LFM_TRY(snapshot_side(s, side));
@@ -1061,6 +1102,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                  const uint32_t *seeds, int32_t n_seeds, lfm_opts *opts)
 {
     if (!s) return fail(LFM_EINVAL, "null session");
+    if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session (lfm_session_create_scoring) cannot train");
     if (loss < 0 || loss > 3) return fail(LFM_EINVAL, "unknown loss");
     if (slot < 0 || slot >= (int)s->shuffles.size() || s->shuffles[slot]->n != (size_t)s->n)
         return fail(LFM_EINVAL, "shuffle slot not uploaded");
@@ -1226,6 +1268,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 0, recs_in_use));
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
     if (reg && !serial) HIP_TRY(launch_reg_log_init(s->scales.p, s->reg_log.p, s->reg_live.p, s->stream));
+    const double reg_step = log1p(std::max(item_alpha, user_alpha) * (double)std::max(s->lr, 1e-6f));
+    const int64_t reg_len_cap = reg ? (int64_t)std::max(65536.0, std::min(1e12, 0.5 / std::max(reg_step, 1e-300))) : INT64_MAX;
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
@@ -1295,6 +1339,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const int64_t flight = (int64_t)max_grid * wpb * per_wave;
             int64_t len = std::min<int64_t>(slice, seg_end - begin);
             if (!fixed_cap && below_residency) len = std::min<int64_t>(len, std::max<int64_t>(flight * 64, 1024));
+            // Lazy regularisation: the launch's readers extrapolate the scale's growth from the rate of the
+            // previous launch (device.hpp: RegScale); a launch is kept to a growth of at most ~0.5 in log
+            // scale (at the bound log1p(alpha * lr) per position) so that the extrapolation error stays
+            // around a per cent -- but never below 64 Ki positions: past that alpha the model is flattened
+            // whatever the scale's third digit is ("excessive regularisation").
+            if (reg) len = std::min<int64_t>(len, reg_len_cap);
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
@@ -1331,7 +1381,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // Lazy L2 regularisation (device.hpp: RegScale): the scales live in s->reg_log while the
             // launch runs; between launches they are folded into the weights when one has passed
             // MAX_REG_SCALE (locked_regularize, PYX:678-691) -- decided on the device, no host round trip.
-            if (reg) HIP_TRY(launch_regularize(a.m, s->reg_log.p, s->reg_live.p, 0, s->stream));
+            if (reg) HIP_TRY(launch_regularize(a.m, s->reg_log.p, s->reg_live.p, 0, s->stream, len));
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp
             in_flight = (int)std::min<int64_t>((int64_t)grid_used * wpb * per_wave, INT32_MAX);
@@ -1401,7 +1451,7 @@ extern "C" int lfm_session_load_model(lfm_session *s, const lfm_model *model)
     if (!s || !model) return fail(LFM_EINVAL, "null argument");
     if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
         return fail(LFM_EINVAL, "model shape differs from the session's");
-    LFM_TRY(validate_model(model));
+    LFM_TRY(validate_model(model, s->scoring_only));
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int side = 0; side < 2; ++side)
@@ -1466,6 +1516,7 @@ extern "C" int lfm_session_representations(lfm_session *s, int32_t side, const l
     DBuf<float> demb, dbias;
     DrainOnExit drain(s->stream);
     LFM_TRY(f.upload(features, true, true));
+    if (!f.identity) LFM_TRY(check_id_range(s, f.indices.p, f.nnz, s->n_feat[side], "features.indices"));
     LFM_TRY(demb.alloc((size_t)features->rows * s->d));
     LFM_TRY(dbias.alloc((size_t)features->rows));
     HIP_TRY(launch_rep_rows(f.view(), s->tab[side][0].p, s->tab[side][3].p, s->d, s->d, demb.p, s->stream, 0, dbias.p));
@@ -1557,7 +1608,17 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     // LIGHTFM_AMD_RANKS_MFMA: 0 the scalar kernel, 1 the first MFMA formulation (users as tile rows),
     // unset / 2 the second (a lane owns a user); the tests compare all three
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
-    const int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
+    int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
+    // the MFMA sweeps mask train positives by walking each user's train row alongside the item tiles: they
+    // need ascending column indices (tocsr() of a COO gives them; a CSR handed in by the caller may not).
+    // Unsorted rows run the scalar kernel, whose lookup does not care.
+    if (mfma_mode != 0) {
+        bool sorted = true;
+        for (int32_t u = 0; u < train->rows && sorted; ++u)
+            for (int32_t j = train->indptr[u] + 1; j < train->indptr[u + 1]; ++j)
+                if (train->indices[j] < train->indices[j - 1]) { sorted = false; break; }
+        if (!sorted) mfma_mode = 0;
+    }
     a.work = nullptr;
     a.n_work = 0;
     if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
@@ -1668,7 +1729,7 @@ extern "C" int lfm_predict(const lfm_csr *itf, const lfm_csr *usf, const int32_t
                            const int32_t *item_ids, float *predictions, int64_t n, const lfm_model *model)
 {
     SessionHolder h;
-    LFM_TRY(lfm_session_create(&h.s, 0, model, itf, usf));
+    LFM_TRY(lfm_session_create_scoring(&h.s, 0, model, itf, usf));
     return lfm_session_predict(h.s, user_ids, item_ids, predictions, n);
 }
 
@@ -1676,7 +1737,7 @@ extern "C" int lfm_predict_ranks(const lfm_csr *itf, const lfm_csr *usf, const l
                                  const lfm_csr *train, float *ranks, const lfm_model *model)
 {
     SessionHolder h;
-    LFM_TRY(lfm_session_create(&h.s, 0, model, itf, usf));
+    LFM_TRY(lfm_session_create_scoring(&h.s, 0, model, itf, usf));
     return lfm_session_predict_ranks(h.s, test, train, ranks);
 }
 

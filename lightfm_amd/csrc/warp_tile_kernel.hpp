@@ -259,6 +259,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
 
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // per-wave event counts: wave-uniform (ballots / lane reads), i.e. SGPRs
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
+    RegScale reg;  // REG: the regularisation steps this wavefront has collected (device.hpp: RegScale)
+    reg.begin();
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
     const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
     float *WiW = a.m.W[0], *Gi = a.m.G[0], *Mi = a.m.M[0];
@@ -351,15 +353,18 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     // plain loads, lanes past d re-read coordinate 0: no exec-masked branches,
                     // so all rows of all groups are in flight together
                     const int c = lane + WAVE * q;
-                    const int cc = c < d ? c : 0;
-                    gN[gg][q] = Gi[bn + cc];
-                    if (ADADELTA) mN[gg][q] = Mi[bn + cc];
+                    // (uniform row base + a 32-bit lane offset the compiler cannot hoist: global_load saddr form
+                    // instead of one loop-invariant per-lane 64-bit pointer per table held across the pass)
+                    unsigned cc = c < d ? (unsigned)c : 0u;
+                    asm volatile("" : "+v"(cc));
+                    gN[gg][q] = (Gi + bn)[cc];
+                    if (ADADELTA) mN[gg][q] = (Mi + bn)[cc];
                     if (!only_neg) {
-                        gP[gg][q] = Gi[bp + cc];
-                        gU[gg][q] = Gu[bu_ + cc];
+                        gP[gg][q] = (Gi + bp)[cc];
+                        gU[gg][q] = (Gu + bu_)[cc];
                         if (ADADELTA) {
-                            mP[gg][q] = Mi[bp + cc];
-                            mU[gg][q] = Mu[bu_ + cc];
+                            mP[gg][q] = (Mi + bp)[cc];
+                            mU[gg][q] = (Mu + bu_)[cc];
                         }
                     }
                 }
@@ -392,11 +397,6 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
-                // REG: the line of live regularisation state (device.hpp: RegScale), requested with the candidate rows
-                RegScale::Live live{0.0f, 0.0f, 1.0f, 1.0f};
-                if constexpr (REG) {
-                    if (done == 0) live = RegScale::load(a.reg_live);
-                }
                 // up to 10 candidate rows per round, ALL requested before the first is staged
                 const bool gln = need && pc;
                 if constexpr (DMA) {
@@ -479,11 +479,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 wave_sync();
                 stamp(1);  // gathers landed and staged
                 if constexpr (REG) {
-                    if (done == 0) {
-                        RegScale::scales(live, wi, wu);  // (float)(1.0 * scale), PYX:306
-                        wi = unif(wi);
-                        wu = unif(wu);
-                    }
+                    if (done == 0) RegScale::scales(a.reg_live, ib - a.begin, wi, wu);  // (float)(1.0 * scale), PYX:306; wave-uniform
                 }
                 float score = 0.0f;
                 if (rowlane) score = row_dot<REG>(urow, vrows + (size_t)p * KS, d, bu, bi, wu, wi);
@@ -650,6 +646,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         for (int q = 0; q < NC; ++q) {
                             const int c = lane + WAVE * q;
                             if (c < d) {
+                                // uniform row bases + a 32-bit lane offset the compiler cannot hoist (see load_rows)
+                                unsigned cq = (unsigned)c;
+                                asm volatile("" : "+v"(cq));
+                                float *const wP = WiW + bp, *const wN = WiW + bn, *const wU = WuW + bu_;
+                                float *const aP = Gi + bp, *const aN = Gi + bn, *const aU = Gu + bu_;
                                 if constexpr (ADADELTA) {
                                     // moving-average accumulators: compare-and-swap (device.hpp: publish_adadelta)
                                     const float Uc = REG ? __fmul_rn(wu, oWr[q][2]) : oWr[q][2];
@@ -657,19 +658,19 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                     const float Nc = REG ? __fmul_rn(wi, oWr[q][1]) : oWr[q][1];
                                     const double u = (double)Uc;
                                     const double df = (double)__fsub_rn(Nc, Pc);
-                                    publish_cell(WiW + bp + c, Gi + bp + c, Mi + bp + c, oWr[q][0], gP[gg][q], mP[gg][q],
+                                    publish_cell(wP + cq, aP + cq, Mi + bp + cq, oWr[q][0], gP[gg][q], mP[gg][q],
                                                  nWr[q][0], nGr[q][0], nMr[q][0], 1.0, -loss * u, h, ia, um);
-                                    publish_cell(WiW + bn + c, Gi + bn + c, Mi + bn + c, oWr[q][1], gN[gg][q], mN[gg][q],
+                                    publish_cell(wN + cq, aN + cq, Mi + bn + cq, oWr[q][1], gN[gg][q], mN[gg][q],
                                                  nWr[q][1], nGr[q][1], nMr[q][1], 1.0, loss * u, h, ia, um);
-                                    publish_cell(WuW + bu_ + c, Gu + bu_ + c, Mu + bu_ + c, oWr[q][2], gU[gg][q], mU[gg][q],
+                                    publish_cell(wU + cq, aU + cq, Mu + bu_ + cq, oWr[q][2], gU[gg][q], mU[gg][q],
                                                  nWr[q][2], nGr[q][2], nMr[q][2], 1.0, loss * df, h, ua, um);
                                 } else {
-                                    publish(WiW + bp + c, nWr[q][0], oWr[q][0], um);
-                                    publish(Gi + bp + c, nGr[q][0], gP[gg][q], um);
-                                    publish(WiW + bn + c, nWr[q][1], oWr[q][1], um);
-                                    publish(Gi + bn + c, nGr[q][1], gN[gg][q], um);
-                                    publish(WuW + bu_ + c, nWr[q][2], oWr[q][2], um);
-                                    publish(Gu + bu_ + c, nGr[q][2], gU[gg][q], um);
+                                    publish(wP + cq, nWr[q][0], oWr[q][0], um);
+                                    publish(aP + cq, nGr[q][0], gP[gg][q], um);
+                                    publish(wN + cq, nWr[q][1], oWr[q][1], um);
+                                    publish(aN + cq, nGr[q][1], gN[gg][q], um);
+                                    publish(wU + cq, nWr[q][2], oWr[q][2], um);
+                                    publish(aU + cq, nGr[q][2], gU[gg][q], um);
                                 }
                             }
                         }
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 }
                 if constexpr (REG) {
                     // PYX:648-649 for the pass's interactions (after the publications: the logarithms'
-                    // temporaries must not overlap the cell arithmetic's registers): one float64 atomic per side
+                    // temporaries must not overlap the cell arithmetic's registers); collected in registers,
+                    // published every RegScale::PERIOD passes
                     float add_i = 0.0f, add_u = 0.0f;
 #pragma unroll
                     for (int gg = 0; gg < NG; ++gg) {
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             add_u += RegScale::log1p_f32((float)ua * avg_lr[gg]);
                         }
                     }
-                    if (lane == 0 && um != 2) RegScale::add(a.reg_live, add_i, add_u);
+                    if (um != 2) reg.add(add_i, add_u);
                 }
                 wave_sync();  // the tile is rewritten by the next pass
                 stamp(5);  // cell arithmetic, atomics issued (acknowledged, in the timed build)
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         nxt = rec2;
         row2 = row3;
     }
+    if constexpr (REG) RegScale::publish(a.reg_live, reg.p_i, reg.p_u, lane, (unsigned)gw);
 
     // counters: one atomic per wave and counter
     if constexpr (TIMED) {

@@ -48,11 +48,32 @@ _NOT_FINITE = ("Not all estimated parameters are finite, your model may have div
 class _Session(object):
     """RAII wrapper of lfm_session (include/lfm_hip.h)."""
 
-    def __init__(self, model_struct, item_features, user_features, device=0):
+    def __init__(self, model_struct, item_features, user_features, device=0, scoring=False):
+        """scoring=True: only embeddings and biases are uploaded (lfm_session_create_scoring); such a
+        session serves predict / predict_ranks / representations and cannot train."""
         self.handle = C.c_void_p()
         self._keep = (model_struct, item_features, user_features)
-        N.check(N.lib().lfm_session_create(C.byref(self.handle), device, model_struct.byref(),
-                                           item_features.byref(), user_features.byref()))
+        create = N.lib().lfm_session_create_scoring if scoring else N.lib().lfm_session_create
+        N.check(create(C.byref(self.handle), device, model_struct.byref(), item_features.byref(),
+                       user_features.byref()))
+
+    def set_features(self, item_features, user_features):
+        """Replaces the resident feature matrices (None keeps a side's)."""
+        N.check(N.lib().lfm_session_set_features(
+            self.handle, item_features.byref() if item_features is not None else None,
+            user_features.byref() if user_features is not None else None))
+        self._keep = (self._keep[0], self._keep[1] if item_features is None else item_features,
+                      self._keep[2] if user_features is None else user_features)
+
+    def predict(self, user_ids, item_ids, predictions):
+        N.check(N.lib().lfm_session_predict(
+            self.handle, N.i32p(N.require(user_ids, np.int32, 1, "user_ids")),
+            N.i32p(N.require(item_ids, np.int32, 1, "item_ids")),
+            N.f32p(N.require(predictions, np.float32, 1, "predictions")), C.c_int64(len(predictions))))
+
+    def predict_ranks(self, test, train, ranks):
+        N.check(N.lib().lfm_session_predict_ranks(self.handle, test.byref(), train.byref(),
+                                                  N.f32p(N.require(ranks, np.float32, 1, "ranks"))))
 
     def set_interactions(self, positives, rows, cols, data, weight):
         n = len(rows)
@@ -201,8 +222,68 @@ class LightFM(object):
 
     def _reset_state(self):
         self._trained_interactions = 0  # drives the concurrency ramp (lfm_opts.history)
+        self._drop_scoring_session()
         for name in _WEIGHTS:
             setattr(self, name, None)
+
+    # ------------------------------------------------- resident scoring session
+    # predict / predict_rank of the reference hand the whole FastLightFM to every native call
+    # (LFM:862-870, 979-987).  Here the embeddings and biases stay on the device between calls: a
+    # scoring session is kept on the model and reused while the four arrays it was built from are the
+    # same objects with the same content (a checksum per call: ~4 ms for the ML-20M tables, against
+    # re-uploading 43 MB -- or 172 MB with the accumulators, as round 2 did).
+
+    _SCORED = ("item_embeddings", "item_biases", "user_embeddings", "user_biases")
+
+    def _drop_scoring_session(self):
+        cached = self.__dict__.pop("_scoring", None)
+        if cached is not None:
+            cached[0].close()
+
+    @staticmethod
+    def _array_signature(a):
+        """Identity + content of a weight array: an exact wrap-around sum of its bit patterns (any
+        single-cell edit changes it) and a position-sensitive float probe (row / column moves)."""
+        flat = a.reshape(-1)
+        if flat.size == 0:
+            return (id(a), a.shape, 0, 0.0)
+        if a.flags.c_contiguous and a.dtype == np.float32:
+            bits = flat.view(np.uint64) if flat.size % 2 == 0 else flat.view(np.uint32)
+            exact = int(np.add.reduce(bits, dtype=np.uint64))
+        else:
+            exact = hash(flat.tobytes())
+        m = a if a.ndim == 2 else flat.reshape(-1, 1)
+        rows, cols = m.shape
+        probe = float(np.dot(np.dot(m, np.cos(np.arange(1, cols + 1, dtype=np.float32))),
+                             np.sin(np.arange(1, rows + 1, dtype=np.float32) * np.float32(0.37))))
+        return (id(a), a.__array_interface__["data"][0], a.shape, exact, probe)
+
+    def _scoring_session(self, item_features, user_features):
+        """A device session holding the current embeddings and biases, with the given feature matrices."""
+        sig = tuple(self._array_signature(getattr(self, name)) for name in self._SCORED)
+        cached = self.__dict__.get("_scoring")
+        if cached is not None and (cached[1] != sig or not options.cache_scoring_session):
+            self._drop_scoring_session()
+            cached = None
+        itf, usf = CSRMatrix(item_features), CSRMatrix(user_features)
+        if cached is None:
+            session = _Session(self._get_lightfm_data(), itf, usf, scoring=True)
+            if options.cache_scoring_session:
+                self.__dict__["_scoring"] = (session, sig)
+            return session, not options.cache_scoring_session
+        cached[0].set_features(itf, usf)
+        return cached[0], False
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_scoring", None)  # a device handle
+        return state
+
+    def __del__(self):
+        try:
+            self._drop_scoring_session()
+        except Exception:
+            pass
 
     def _check_initialized(self):
         if any(getattr(self, name) is None for name in _WEIGHTS):
@@ -367,6 +448,7 @@ class LightFM(object):
         """The epoch loop of LFM:654-664 + _run_epoch (LFM:668-759) on one device session."""
         if epochs <= 0:
             return
+        self._drop_scoring_session()  # its tables are about to be stale; hand the memory to the fit
         loss = self.loss
         needs_lookup = loss in ("warp", "bpr", "warp-kos")
         positives = None
@@ -462,9 +544,13 @@ class LightFM(object):
             n_users, n_items, user_features, item_features)
 
         predictions = np.empty(len(user_ids), dtype=np.float32)
-        predict_lightfm(CSRMatrix(item_features), CSRMatrix(user_features),
-                        np.ascontiguousarray(user_ids), np.ascontiguousarray(item_ids),
-                        predictions, self._get_lightfm_data(), num_threads)
+        # predict_lightfm (PYX:1185-1229) on the resident scoring session
+        session, one_shot = self._scoring_session(item_features, user_features)
+        try:
+            session.predict(np.ascontiguousarray(user_ids), np.ascontiguousarray(item_ids), predictions)
+        finally:
+            if one_shot:
+                session.close()
         return predictions
 
     def _check_test_train_intersections(self, test_mat, train_mat):
@@ -499,11 +585,19 @@ class LightFM(object):
         else:
             train_interactions = self._to_cython_dtype(train_interactions.tocsr())
 
+        if not train_interactions.has_sorted_indices:
+            # the train-positive mask is a sorted-row lookup (PYX:1303-1304: in_positives' binary search)
+            train_interactions = train_interactions.sorted_indices()
+
         ranks = sp.csr_matrix((np.zeros_like(test_interactions.data), test_interactions.indices,
                                test_interactions.indptr), shape=test_interactions.shape)
-        predict_ranks(CSRMatrix(item_features), CSRMatrix(user_features),
-                      CSRMatrix(test_interactions), CSRMatrix(train_interactions), ranks.data,
-                      self._get_lightfm_data(), num_threads)
+        # predict_ranks (PYX:1232-1323) on the resident scoring session
+        session, one_shot = self._scoring_session(item_features, user_features)
+        try:
+            session.predict_ranks(CSRMatrix(test_interactions), CSRMatrix(train_interactions), ranks.data)
+        finally:
+            if one_shot:
+                session.close()
         return ranks
 
     # -------------------------------------------------------- representations
@@ -516,11 +610,12 @@ class LightFM(object):
         if features.shape[1] != table.shape[0]:  # what scipy's `features * embeddings` raises
             raise ValueError("dimension mismatch")
         empty = sp.csr_matrix((0, 0), dtype=CYTHON_DTYPE)
-        session = _Session(self._get_lightfm_data(), CSRMatrix(empty), CSRMatrix(empty))
+        session, one_shot = self._scoring_session(empty, empty)
         try:
             return session.representations(side, CSRMatrix(features))
         finally:
-            session.close()
+            if one_shot:
+                session.close()
 
     def get_item_representations(self, features=None):
         """(biases, embeddings) of items, optionally through a feature matrix (LFM:991-1018)."""

@@ -27,6 +27,9 @@ device_shuffle     LightFM.fit_partial, parallel mode: True (default) builds eac
                    consumed exactly like the reference; False draws numpy's
                    random_state.shuffle(arange(n)) on the host like the reference (LFM:689-690)
                    and uploads it.  Serial mode always uses the host shuffle.
+cache_scoring_session  True (default): LightFM keeps a device session with its embeddings and biases
+                   between predict / predict_rank / get_*_representations calls (re-validated by checksum
+                   per call, dropped by fit_partial); False: every call uploads them anew.
 host_positives     True: the positives lookup is built on the host (interactions.tocsr(), LFM:365-372)
                    and uploaded; False (default): built on the device from the uploaded COO.
 
@@ -52,6 +55,7 @@ class _Options(object):
         self.history = 0
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.host_positives = os.environ.get("LIGHTFM_AMD_HOST_POSITIVES", "0") != "0"
+        self.cache_scoring_session = os.environ.get("LIGHTFM_AMD_CACHE_SCORING", "1") != "0"
         self.log_samples = False
         self.last_counters = None
         self.last_kernel_ms = None

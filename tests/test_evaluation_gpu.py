@@ -157,3 +157,110 @@ def test_mfma_ranks_shapes_and_ties(d, n_items):
     fresh.item_embeddings *= 1e-3
     out = _ranks_by_kernel(fresh, test, train)
     assert np.array_equal(out["lane-per-user"], out["scalar"])
+
+
+# ------------------------------------------------ resident scoring session ---
+
+def _fresh_copy(model):
+    """A new model object with copies of the weights (no cached device state)."""
+    import copy
+    from lightfm_amd.lightfm import _WEIGHTS
+    other = copy.copy(model)
+    other.__dict__.pop("_scoring", None)
+    for name in _WEIGHTS:
+        setattr(other, name, getattr(model, name).copy())
+    return other
+
+
+def test_scoring_session_is_reused_and_revalidated(fitted):
+    """predict / predict_rank keep the embeddings and biases on the device between calls (reference
+    call sites LFM:862-870, 979-987 re-wrap the host arrays per call): the same session object serves
+    repeated calls, and ANY change of the host arrays -- in place or by assignment -- is seen."""
+    model, train, test = fitted
+    model = _fresh_copy(model)
+    nu, ni = test.shape
+    s0 = _scores(model, nu, ni)
+    session = model._scoring[0]
+    r0 = model.predict_rank(test, train_interactions=train).toarray()
+    assert model._scoring[0] is session                     # reused
+    np.testing.assert_array_equal(_scores(model, nu, ni), s0)
+    # in-place edit of one cell
+    model.item_embeddings[3, 2] += 0.5
+    s1 = _scores(model, nu, ni)
+    np.testing.assert_array_equal(s1, _scores(_fresh_copy(model), nu, ni))
+    assert not np.array_equal(s1[:, 3], s0[:, 3]) and np.array_equal(s1[:, 4], s0[:, 4])
+    # in-place permutation of rows (same multiset of values)
+    model.user_embeddings[[0, 1]] = model.user_embeddings[[1, 0]]
+    s2 = _scores(model, nu, ni)
+    np.testing.assert_array_equal(s2, _scores(_fresh_copy(model), nu, ni))
+    # assignment of a new array
+    model.item_biases = model.item_biases + 1.0
+    r1 = model.predict_rank(test, train_interactions=train).toarray()
+    np.testing.assert_array_equal(r1, _fresh_copy(model).predict_rank(test, train_interactions=train).toarray())
+    assert r0.shape == r1.shape
+
+
+def test_scoring_session_dropped_by_fit_and_pickle(fitted):
+    import pickle
+    model, train, test = fitted
+    model = _fresh_copy(model)
+    nu, ni = test.shape
+    _scores(model, nu, ni)
+    assert "_scoring" in model.__dict__
+    clone = pickle.loads(pickle.dumps(model))               # the device handle is not pickled
+    assert "_scoring" not in clone.__dict__
+    np.testing.assert_array_equal(_scores(clone, nu, ni), _scores(model, nu, ni))
+    model.fit_partial(train, epochs=1)
+    assert "_scoring" not in model.__dict__                 # stale tables are dropped before training
+    np.testing.assert_array_equal(_scores(model, nu, ni), _scores(_fresh_copy(model), nu, ni))
+
+
+def test_scoring_session_cannot_train(fitted):
+    from lightfm_amd import _native as N
+    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
+    from lightfm_amd.lightfm import _Session
+    model, train, test = fitted
+    nu, ni = test.shape
+    s = _Session(model._get_lightfm_data(), CSRMatrix(sp.identity(ni, dtype=np.float32, format="csr")),
+                 CSRMatrix(sp.identity(nu, dtype=np.float32, format="csr")), scoring=True)
+    try:
+        coo = train.tocoo()
+        s.set_interactions(None, coo.row.astype(np.int32), coo.col.astype(np.int32), coo.data, coo.data)
+        s.upload_shuffle(np.arange(coo.nnz, dtype=np.int32))
+        opts, _ = make_opts()
+        with pytest.raises(ValueError, match="scoring session"):
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([1], np.uint32), opts)
+        with pytest.raises(ValueError):
+            s.merge_begin(1)
+    finally:
+        s.close()
+
+
+def test_unsorted_train_rows_give_the_same_ranks(fitted):
+    """the MFMA sweeps walk each user's train row in column order.  predict_rank sorts a CSR
+    that arrives unsorted; the C entry point falls back to the scalar kernel for one that is handed to it."""
+    model, train, test = fitted
+    ref = model.predict_rank(test, train_interactions=train).toarray()
+    rng = np.random.RandomState(0)
+    shuffled = train.copy()
+    for u in range(shuffled.shape[0]):
+        lo, hi = shuffled.indptr[u], shuffled.indptr[u + 1]
+        perm = rng.permutation(hi - lo)
+        shuffled.indices[lo:hi] = shuffled.indices[lo:hi][perm]
+        shuffled.data[lo:hi] = shuffled.data[lo:hi][perm]
+    shuffled.has_sorted_indices = False
+    np.testing.assert_array_equal(model.predict_rank(test, train_interactions=shuffled).toarray(), ref)
+
+
+def test_representations_reject_out_of_range_feature_ids(fitted):
+    """lfm_session_representations range-checks the feature ids against the embedding table."""
+    model, train, test = fitted
+    n_feat = model.item_embeddings.shape[0]
+    feats = sp.csr_matrix((np.ones(2, np.float32), np.array([0, n_feat - 1], np.int32), np.array([0, 2], np.int32)),
+                          shape=(1, n_feat))
+    b, e = model.get_item_representations(feats)
+    np.testing.assert_allclose(e[0], model.item_embeddings[0] + model.item_embeddings[n_feat - 1], rtol=1e-6)
+    bad = sp.csr_matrix((1, n_feat), dtype=np.float32)
+    bad.indices, bad.indptr, bad.data = np.array([n_feat + 5], np.int32), np.array([0, 1], np.int32), np.ones(1, np.float32)
+    with pytest.raises(ValueError):
+        model.get_item_representations(bad)

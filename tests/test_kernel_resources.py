@@ -62,8 +62,8 @@ def test_tile_kernel_budgets(tmp_path):
     # fit_warp_tile_kernel<16, 4, TIMED = false, ADADELTA = false, DMA4 = true / false, REG = false / true>
     dma = _one(k, "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb1ELb0EEE")
     regs = _one(k, "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb0ELb0EEE")
-    assert dma["VGPRs"] + dma["AGPRs"] <= 160 and dma["Occupancy"] == 3, dma
-    assert regs["Occupancy"] == 2 and dma["VGPRs"] < regs["VGPRs"], (dma, regs)
+    assert dma["VGPRs"] + dma["AGPRs"] <= 148 and dma["Occupancy"] == 3, dma  # round 2: 163, round 3: 145
+    assert regs["Occupancy"] >= 2 and dma["VGPRs"] < regs["VGPRs"], (dma, regs)
     # the L2-regularised variant (item_alpha / user_alpha != 0) keeps the third workgroup per CU
     reg = _one(k, "fit_warp_tile_kernelILi16ELi4ELb0ELb0ELb1ELb1EEE")
     assert reg["VGPRs"] + reg["AGPRs"] <= 168 and reg["Occupancy"] == 3, reg

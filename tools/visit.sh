@@ -82,6 +82,41 @@ suite)
     echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 12
   done
   ;;
+r3a)
+  # first visit of round 3 after the re-entry: suite x3, atomic flavours, C2 line (alpha = 0 and 1e-6), C3 short
+  for i in 1 2 3; do
+    timeout -k 5 900 $PYT tests -m gpu -x -q -s > $OUT/suite_$i.log 2>&1
+    echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 12
+  done
+  timeout 200 tools/_bin/membench > $OUT/membench.txt 2>&1; echo "membench exit $?"; grep -a "waves/CU [fu]" $OUT/membench.txt | head -40
+  timeout 400 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; echo "bench c2 exit $?"; cut -c1-1500 $OUT/bench_c2.json
+  S="--no-cpu-baseline --no-quality --no-fit --steps 6 --warmup 2"
+  timeout 200 python bench.py $S --item-alpha 1e-6 --user-alpha 1e-6 > $OUT/bench_c2_reg.json 2> $OUT/bench_c2_reg.err; echo "bench c2 reg exit $?"; cut -c1-700 $OUT/bench_c2_reg.json
+  timeout 300 python bench.py $S --config c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; echo "bench c3 exit $?"; cut -c1-700 $OUT/bench_c3.json
+  timeout 300 python bench.py $S --config c3 --item-alpha 1e-6 --user-alpha 1e-6 > $OUT/bench_c3_reg.json 2> $OUT/bench_c3_reg.err; echo "bench c3 reg exit $?"; cut -c1-700 $OUT/bench_c3_reg.json
+  ;;
+r3b)
+  # RegScale v3 (extrapolating readers, publish at wave end), scoring session, hoisted-pointer fix
+  N=${1:-1}
+  for i in $(seq 1 $N); do
+    timeout -k 5 900 $PYT tests -m gpu -x -q -s > $OUT/suite_$i.log 2>&1
+    echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 12
+  done
+  S="--no-cpu-baseline --no-quality --no-fit --steps 6 --warmup 2"
+  for cfg in "c2" "c2 --item-alpha 1e-6 --user-alpha 1e-6" "c3" "c3 --item-alpha 1e-6 --user-alpha 1e-6" "c4shard" "c4shard --item-alpha 1e-6 --user-alpha 1e-6"; do
+    tag=$(echo "$cfg" | tr ' ' '_' | tr -d '-')
+    timeout 300 python bench.py $S --config $cfg > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err; echo "bench $cfg exit $?"
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_$tag.json"))
+    r = d["roofline"]
+    print("  %.1f M/s  frac %.3f  atomic %.3f  launch %.3f ms  U %.3f  kernel %s" % (d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r["kernel"]))
+except Exception as e:
+    print("  no result:", e)
+PY
+  done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
