@@ -36,6 +36,14 @@ Cython/OpenMP path on this box's host cores, N = 1 only), `quality` (precision@1
 backend and of the reference trained on the same data, N = 1, c2 / c3) and `end_to_end_fit`
 (LightFM.fit through the public API, uploads and downloads included).
 
+At N = 1 with no --config the line also carries `extra_configs`: short timed legs of the other
+BASELINE shapes (c3, c4shard, and c5shard at its full per-GPU size) run after c2 in the same
+process, each with its own `value` and `roofline` (--no-extra skips them; --extra picks).
+`roofline.traffic` is the HBM traffic per launch of the dominant kernel taken from the committed
+rocprofv3 --pmc summary of the same command (profiles/traffic.json names the source file per
+config and kernel; counters cannot be collected inside this run), null when the committed
+summary is of another kernel.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -55,6 +63,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 ATOMIC_PEAK_GOPS = 320.0  # global_atomic_add_f32 lanes per second, measured (tools/membench.hip)
 MAX_SAMPLED = 10
+KNOBS = ("update_mode", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "feat_kernel", "debug",
+         "ramp_k", "shared_cap")
 
 CONFIGS = {
     "c2": dict(loss="warp", d=64, shape="ml-20m", features=None, default_scaling="strong",
@@ -127,12 +137,18 @@ def build_workload(name, rank, world, scaling, scale, want_test):
         n_users, n_items, nnz = cfg["shape"]
         train = synthetic.big_interactions(n_users, n_items, int(nnz * scale), seed=4 + rank)
         global_n = train.nnz * world
-    feats = None
+    return train, build_features(name, n_items), test, global_n, train.shape[0], n_items
+
+
+def build_features(name, n_items):
+    """The item feature CSR of a config (None = identity)."""
+    from lightfm_amd import synthetic
+    cfg = CONFIGS[name]
     if cfg["features"] == "tags":
-        feats = synthetic.tag_item_features(n_items)
-    elif cfg["features"] == "hashed":
-        feats = synthetic.hashed_item_features(n_items)
-    return train, feats, test, global_n, train.shape[0], n_items
+        return synthetic.tag_item_features(n_items)
+    if cfg["features"] == "hashed":
+        return synthetic.hashed_item_features(n_items)
+    return None
 
 
 def precision_at_10(model, train, test, item_features):
@@ -176,12 +192,29 @@ def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note):
     return cpu, p_ref
 
 
-def main():
+def committed_traffic(config_name, kernel_name):
+    """(HBM bytes per launch, source) of the dominant kernel from profiles/traffic.json."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = table.get(config_name)
+        if e and e.get("kernel") == kernel_name:
+            return float(e["hbm_bytes_per_launch"]), e.get("source")
+        if e:
+            return None, "profiles/traffic.json holds %s for this config, this run's kernel is %s" % (e.get("kernel"), kernel_name)
+    except Exception as e:  # reporting only
+        return None, "profiles/traffic.json unreadable: %r" % (e,)
+    return None, "no committed counter summary for this config"
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="default: c2, followed at N = 1 by short legs of c3 / c4shard / c5shard (extra_configs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs of the default run")
+    ap.add_argument("--extra", default="c3,c4shard,c5shard", help="which extra legs (comma separated)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the interactions (debug)")
     ap.add_argument("--emulate-shard", type=int, default=0,
@@ -195,44 +228,43 @@ def main():
     ap.add_argument("--merge-mode", default=None, help="sum | mean | adagrad (N > 1)")
     ap.add_argument("--merge-k", type=int, default=None)
     ap.add_argument("--merge-max", type=int, default=None)
-    for knob in ("update_mode", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "feat_kernel",
-                 "debug", "ramp_k", "shared_cap"):
+    ap.add_argument("--merge-dense", action="store_true", help="N > 1: the dense synchronous merge of round 2")
+    for knob in KNOBS:
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    cfg = CONFIGS[args.config]
-    scaling = args.scaling or cfg["default_scaling"]
-    if world == 1:
-        scaling = cfg["default_scaling"]
 
-    def log(msg):
-        if rank == 0:
+class Env(object):
+    """Process-wide context of a bench run (ranks, the distributed plane, logging)."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        self.dist = None
+        self.cache = {}  # generated workloads shared between legs (c2 and c3 train on the same COO)
+
+    def log(self, msg):
+        if self.rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+
+def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale, want_test):
+    """Builds the workload `name`, makes its inputs resident, warms up, times `steps` steps and returns
+    (contract fields + roofline of this config, the pieces the reporting-only legs need)."""
     from lightfm_amd import _native as N
-    from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
+    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
     from lightfm_amd.distributed import MergePolicy, merge_schedule, segment_positions
     from lightfm_amd.lightfm import LightFM, _Session
     from lightfm_amd.options import options
-    # liblfm_hip.so (and with it /opt/rocm's HIP runtime, the one its kernels and librccl were built
-    # for) is loaded BEFORE torch brings its own copy of the runtime into the process
-    n_devices = N.device_count()
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
-    tuned = {k: getattr(args, k) for k in ("update_mode", "first_batch", "launches_per_epoch", "max_waves",
-                                           "warp_kernel", "feat_kernel", "debug", "ramp_k", "shared_cap")
-             if getattr(args, k) is not None}
-    options.set(**tuned)
+    args, rank, world, dist, log = env.args, env.rank, env.world, env.dist, env.log
+    cfg = CONFIGS[name]
+    scaling = args.scaling or cfg["default_scaling"]
+    if world == 1:
+        scaling = cfg["default_scaling"]
     policy = MergePolicy()
     if args.merge_mode:
         policy.mode = args.merge_mode
@@ -240,14 +272,18 @@ def main():
         policy.merge_k = args.merge_k
     if args.merge_max:
         policy.merge_max = args.merge_max
-    if n_devices <= local_rank:
-        raise SystemExit("no HIP device for local rank %d" % local_rank)
-    dev_name, cus, hbm = N.device_info(local_rank)
+    dev_name, cus, hbm = N.device_info(env.local_rank)
 
     t0 = time.time()
-    want_quality = world == 1 and not args.no_quality and cfg["shape"] == "ml-20m"
-    train, feats, test, global_n, n_users, n_items = build_workload(args.config, rank, world, scaling, args.scale,
-                                                                     want_quality)
+    key = (cfg["shape"] if isinstance(cfg["shape"], str) else name, scaling, scale, want_test)
+    if key in env.cache and world == 1:
+        train, test, global_n, n_users, n_items = env.cache[key]
+        feats = build_features(name, n_items)
+    else:
+        train, feats, test, global_n, n_users, n_items = build_workload(name, rank, world, scaling, scale, want_test)
+        if world == 1:
+            env.cache.clear()  # one workload at a time in host memory
+            env.cache[key] = (train, test, global_n, n_users, n_items)
     if world > 1 and scaling == "weak":
         # every rank generated its own shard: the merge schedule must be derived from ONE global count
         import torch
@@ -257,8 +293,8 @@ def main():
     if args.emulate_shard > 1 and world == 1:
         from lightfm_amd.distributed import local_shard
         train, _ = local_shard(train, 0, args.emulate_shard, rebase=True)
-        n_users, global_n, want_quality = train.shape[0], train.nnz, False
-    log("generated %d interactions (%d x %d) in %.1fs" % (train.nnz, n_users, n_items, time.time() - t0))
+        n_users, global_n, test = train.shape[0], train.nnz, None
+    log("%s: %d interactions (%d x %d) ready in %.1fs" % (name, train.nnz, n_users, n_items, time.time() - t0))
     loss, d = cfg["loss"], cfg["d"]
     n_item_feat = feats.shape[1] if feats is not None else n_items
 
@@ -270,7 +306,7 @@ def main():
     item_f = feats if feats is not None else sp.identity(n_items, dtype=np.float32, format="csr")
     user_f = sp.identity(n_users, dtype=np.float32, format="csr")
     fl = model._get_lightfm_data()
-    session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f), device=local_rank)
+    session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f), device=env.local_rank)
     rows = np.ascontiguousarray(train.row, dtype=np.int32)
     cols = np.ascontiguousarray(train.col, dtype=np.int32)
     vals = np.ascontiguousarray(train.data, dtype=np.float32)
@@ -284,11 +320,12 @@ def main():
         t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
         dist.broadcast(t, src=0)
         session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()), N.UNIQUE_ID_BYTES), rank, world)
-    log("setup done in %.1fs on %s (%d CUs)" % (time.time() - t0, dev_name, cus))
+    log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))
 
     n_local = train.nnz
-    state = {"history": 0, "merges": 0}
+    state = {"history": 0, "merges": 0, "merge_bytes": 0}
     all_stats = []
+    n_repl_rows = n_item_feat  # rows of the replicated (item-side) tables: sets the longest merge interval
 
     def epoch():
         """What LightFM.fit_partial / DistributedFit.run do per epoch."""
@@ -302,7 +339,7 @@ def main():
             session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
             all_stats.append(opts)
         else:
-            pos = segment_positions(merge_schedule(state["history"], global_n, world, policy), n_local)
+            pos = segment_positions(merge_schedule(state["history"], global_n, world, policy, n_repl_rows), n_local)
             for j in range(len(pos) - 1):
                 opts, _ = make_opts()
                 opts.history = (state["history"] + int(round(global_n * pos[j] / max(1, n_local)))) // world
@@ -310,8 +347,13 @@ def main():
                 if pos[j + 1] > pos[j]:
                     session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
                     all_stats.append(opts)
-                session.comm_merge(1, policy.mode_id())
+                if args.merge_dense:
+                    session.comm_merge(1, policy.mode_id())
+                else:
+                    state["merge_bytes"] += session.comm_merge_sparse(1, policy.mode_id(), overlap=True)
                 state["merges"] += 1
+            if not args.merge_dense:
+                session.comm_merge_flush()
         state["history"] += global_n if world > 1 else n_local
         bad = not session.check_finite()
         if world > 1:
@@ -325,25 +367,26 @@ def main():
             dist.barrier()
 
     # warm-up: the first epoch ramps the concurrency up; its duration calibrates epochs_per_step
-    eps = max(1, args.epochs_per_step)
+    eps = max(1, epochs_per_step)
     epoch()
     t1 = time.perf_counter()
     epoch()
     t_epoch = time.perf_counter() - t1
-    if args.epochs_per_step <= 0:
-        eps = int(min(64, max(1, math.ceil(6.0 / max(1, args.steps) / max(t_epoch, 1e-4)))))
+    if epochs_per_step <= 0:
+        eps = int(min(64, max(1, math.ceil(target_seconds / max(1, steps) / max(t_epoch, 1e-4)))))
         if world > 1:
             import torch
             te = torch.tensor([eps], dtype=torch.int64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             eps = int(te[0])
-    for _ in range(max(0, args.warmup * eps - 2)):
+    for _ in range(max(0, warmup * eps - 2)):
         epoch()
     barrier()  # lfm_session_epoch / check_finite synchronise the session's stream before returning
     all_stats.clear()
-    merges0 = state["merges"]
+    merges0, mbytes0 = state["merges"], state["merge_bytes"]
+    epoch0 = state["history"] // max(1, (global_n if world > 1 else n_local))
     t_start = time.perf_counter()
-    for _ in range(args.steps * eps):
+    for _ in range(steps * eps):
         epoch()
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -367,23 +410,25 @@ def main():
     lens = pos_csr_lens[rows]
     mean_probe = float(np.mean(8 + 4 * np.ceil(np.log2(lens + 1.0))))
     f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
-    n_examples = float(n_local) * (args.steps * eps)
+    n_epochs = steps * eps
+    n_examples = float(n_local) * n_epochs
     alg = algorithmic_bytes(loss, counters, d, 1.0, f_i, mean_probe, n_examples,
                             mean_kos_pos=float(np.mean(np.minimum(10, lens))))
     launches = sum(int(s.launches) for s in stats)
     ng, used = int(stats[-1].tile_ng), int(stats[-1].kernel_used)
+    reg = bool(args.item_alpha or args.user_alpha)
     if used == 1:
-        kernel_name = "fit_warp_tile_kernel<%d, %d, false, false>" % (64 // ng, {4: 4, 2: 2, 1: 1}[ng])
+        kernel_name = "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
+            64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
+            "true" if reg else "false")
     elif used == 2:
-        kernel_name = "fit_feat_kernel (%s)" % loss
+        kernel_name = "fit_feat_kernel<%s, %d, false, %s>" % (loss, 1 if d <= 64 else 2, "true" if reg else "false")
     else:
         kernel_name = "fit_%s_kernel (generic)" % loss.replace("-", "_")
     achieved = alg / kernel_s / 1e9
-    n_epochs = args.steps * eps
+    traffic, traffic_source = committed_traffic(name, kernel_name)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "traffic_note": "PMC traffic is not measurable inside this run; see profiles/README.md for "
-                                "the rocprofv3 --pmc summary of the same command",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
                 "algorithmic_bytes_per_interaction": alg / max(1.0, counters[0]),
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches / n_epochs,
@@ -391,11 +436,14 @@ def main():
                 "interactions_per_wavefront_pass": ng, "interactions_in_flight": int(stats[-1].in_flight),
                 "draws_per_interaction": counters[1] / max(1.0, counters[0]),
                 "updates_per_interaction": counters[2] / max(1.0, counters[0])}
+    if traffic is not None:
+        roofline["traffic_over_algorithmic"] = traffic / (alg / launches)
 
     # Second ceiling of the update-heavy configurations: every updated cell is published with one
     # global_atomic_add_f32 per table (W, G), and the chip executes a fixed ~320 G of them per second
     # whatever the table size or allocation (tools/membench.hip, profiles/r02_membench.txt: 10 G
-    # 128-B line-ops/s = 1.28 TB/s of atomic payload).  Reported next to the HBM roofline.
+    # 128-B line-ops/s = 1.28 TB/s of atomic payload; round 3: the rate is per DWORD, a 64-bit CAS or a
+    # float64 add costs two -- profiles/r03_membench_atomics.txt).  Reported next to the HBM roofline.
     n_upd = counters[2] if loss != "logistic" else n_examples
     rows_upd = (1.0 + 2.0 * f_i) if loss != "logistic" else (1.0 + f_i)
     atomics = float(n_upd) * rows_upd * (d + 1) * 2.0
@@ -414,93 +462,169 @@ def main():
         roofline["phase_cycles_per_pass"] = dict(zip(
             ("head", "gather", "score", "lookup", "acc_loads", "update", "tail", "unused"),
             [round(float(x) / passes, 1) for x in ph]))
+    session.close()
+
+    par = ("1 GPU" if world == 1 else
+           "%s scaling over %d GPUs: %s; item tables merged over RCCL (%s; %s), %.1f merges per epoch, %.1f MB "
+           "exchanged per rank and merge"
+           % (scaling, world,
+              "one COO row-sharded by user" if scaling == "strong" else "every rank its own full-size row shard",
+              policy.mode, "dense all-reduce, synchronous" if args.merge_dense else
+              "all-reduce over the compacted union of the rows touched since the last merge, overlapped with the "
+              "next segment", (state["merges"] - merges0) / float(n_epochs),
+              (state["merge_bytes"] - mbytes0) / 1e6 / max(1, state["merges"] - merges0)))
+    result = {
+        "value": total_pos / elapsed, "unit": "interactions/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed * 1e3 / steps,
+        "config": {"workload": cfg["label"] % (global_n if scaling == "strong" or world == 1 else n_local),
+                   "name": name, "epochs_per_step": eps, "ms_per_epoch": elapsed * 1e3 / n_epochs,
+                   "timed_epochs": "epochs %d..%d of one continuing training run" % (epoch0 + 1, epoch0 + n_epochs),
+                   "parallelism": par, "device": dev_name},
+        "roofline": roofline, "scaling": scaling,
+    }
+    if scale != 1.0:
+        result["config"]["scale"] = scale
+    if args.item_alpha or args.user_alpha:
+        result["config"]["item_alpha"], result["config"]["user_alpha"] = args.item_alpha, args.user_alpha
+    pieces = dict(train=train, test=test, feats=feats, n_users=n_users, n_items=n_items, loss=loss, d=d, cfg=cfg)
+    return result, pieces
+
+
+def reporting_legs(name, env, pieces, want_quality):
+    """quality (precision@10, 3 seeds), cpu_baseline (the reference on the host cores) and end_to_end_fit:
+    reporting only, outside every timed region."""
+    from lightfm_amd.lightfm import LightFM
+    args, log = env.args, env.log
+    train, test, feats = pieces["train"], pieces["test"], pieces["feats"]
+    n_users, n_items, loss, d, cfg = pieces["n_users"], pieces["n_items"], pieces["loss"], pieces["d"], pieces["cfg"]
+    quality, cpu, fit = None, None, None
+    q_epochs = 3
+    # the quality / CPU legs of c3 run on a row sub-sample (the reference needs ~10 us per
+    # interaction there); c2 on the full COO
+    q_train, q_test, q_note = train, test, "the full %d-interaction COO of this workload" % train.nnz
+    if name == "c3":
+        nu = n_users // 8
+
+        def head(coo):
+            keep = coo.row < nu
+            return sp.coo_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(nu, n_items),
+                                 dtype=np.float32)
+        q_train, q_test = head(train), (head(test) if test is not None else None)
+        q_note = ("the first %d users' %d interactions of this workload (1/8 row sub-sample), full item-side "
+                  "tables" % (nu, q_train.nnz))
+    if want_quality and q_test is not None:
+        q_seeds = (7, 8, 9)
+        p = []
+        for seed in q_seeds:
+            m = LightFM(no_components=d, loss=loss, random_state=seed, max_sampled=MAX_SAMPLED)
+            m.fit(q_train, item_features=feats, epochs=q_epochs)
+            p.append(precision_at_10(m, q_train, q_test, feats))
+        quality = {"epochs": q_epochs, "precision_at_10": float(np.mean(p)), "precision_at_10_seeds": p,
+                   "seeds": list(q_seeds), "eval_users": int(len(np.unique(q_test.row))), "data": q_note,
+                   "metric": "precision_at_k(k=10) of lightfm/evaluation.py:14-87 on a held-out 5 percent of "
+                             "the same synthetic process; mean over %d seeds of %d-epoch fits (the reference: one fit, "
+                             "seed 7, its 16-thread Hogwild)" % (len(q_seeds), q_epochs)}
+    if not args.no_cpu_baseline:
+        try:
+            if cfg["shape"] == "ml-20m":
+                cpu, p_ref = reference_leg(name, q_train, q_test if quality is not None else None, feats,
+                                           q_epochs, log, q_note)
+                if quality is not None and p_ref is not None:
+                    quality["precision_at_10_ref"] = p_ref
+                    quality["delta"] = quality["precision_at_10"] - p_ref
+            else:
+                # C4 / C5 shards: a row sub-sample (1/50 of the users, their interactions, the
+                # full item-side tables), SURVEY.md 8(d)
+                nu = max(1000, n_users // 50)
+                keep = train.row < nu
+                sub = sp.coo_matrix((train.data[keep], (train.row[keep], train.col[keep])),
+                                    shape=(nu, n_items), dtype=np.float32)
+                cpu, _ = reference_leg(name, sub, None, feats, 3, log,
+                                       "the first %d users' %d interactions of this shard (1/50 row sub-"
+                                       "sample) over the full item-side tables" % (nu, sub.nnz))
+        except Exception as e:  # the baseline is reporting only; never fail the bench on it
+            log("cpu_baseline failed: %r" % (e,))
+    if not args.no_fit and cfg["shape"] == "ml-20m":
+        fit_epochs = 10
+        m = LightFM(no_components=d, loss=loss, random_state=3, max_sampled=MAX_SAMPLED)
+        t1 = time.perf_counter()
+        m.fit(train, item_features=feats, epochs=fit_epochs)
+        dt = time.perf_counter() - t1
+        fit = {"value": train.nnz * fit_epochs / dt, "unit": "interactions/s", "epochs": fit_epochs,
+               "seconds": dt, "what": "LightFM.fit(train, epochs=%d) through the public API: host coercion, "
+               "uploads, device positives build, epochs, finite checks, download" % fit_epochs}
+    return quality, cpu, fit
+
+
+def main():
+    args = parse_args()
+    env = Env(args)
+    rank, world = env.rank, env.world
+    from lightfm_amd import _native as N
+    from lightfm_amd.options import options
+    # liblfm_hip.so (and with it /opt/rocm's HIP runtime, the one its kernels and librccl were built
+    # for) is loaded BEFORE torch brings its own copy of the runtime into the process
+    n_devices = N.device_count()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        env.dist = dist
+    tuned = {k: getattr(args, k) for k in KNOBS if getattr(args, k) is not None}
+    options.set(**tuned)
+    if n_devices <= env.local_rank:
+        raise SystemExit("no HIP device for local rank %d" % env.local_rank)
+
+    name = args.config or "c2"
+    cfg = CONFIGS[name]
+    want_quality = world == 1 and not args.no_quality and cfg["shape"] == "ml-20m" and args.emulate_shard <= 1
+    result, pieces = run_config(name, env, args.steps, args.warmup, args.epochs_per_step, 6.0, args.scale, want_quality)
+
+    extras = []
+    if world == 1 and args.config is None and not args.no_extra and not tuned:
+        # the other BASELINE shapes, short legs timed the same way (contract: barrier + sync around K steps)
+        plans = {"c3": dict(steps=3, warmup=1, target=2.5), "c4shard": dict(steps=3, warmup=1, target=1.5),
+                 "c5shard": dict(steps=2, warmup=1, target=0.0)}
+        for extra in [e for e in args.extra.split(",") if e in plans and e != name]:
+            try:
+                pl = plans[extra]
+                r, _ = run_config(extra, env, pl["steps"], pl["warmup"], 0 if pl["target"] else 1, pl["target"], 1.0,
+                                  want_quality and CONFIGS[extra]["shape"] == "ml-20m")
+                extras.append({"name": extra, "metric": "positive interactions/sec/epoch (%s, %s)" % (CONFIGS[extra]["loss"], extra),
+                               "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
+                               "ms_per_step": r["ms_per_step"], "config": r["config"], "roofline": r["roofline"]})
+            except BaseException as e:  # an extra leg never takes the contract line down
+                env.log("extra config %s failed: %r" % (extra, e))
+                extras.append({"name": extra, "error": repr(e)})
+        env.cache.clear()
 
     quality, cpu, fit = None, None, None
     if rank == 0 and world == 1:
-        session.close()
-        q_epochs = 3
-        # the quality / CPU legs of c3 run on a row sub-sample (the reference needs ~10 us per
-        # interaction there); c2 on the full COO
-        q_train, q_test, q_note = train, test, "the full %d-interaction COO of this workload" % train.nnz
-        if args.config == "c3":
-            nu = n_users // 8
-            def head(coo):
-                keep = coo.row < nu
-                return sp.coo_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(nu, n_items),
-                                     dtype=np.float32)
-            q_train, q_test = head(train), (head(test) if test is not None else None)
-            q_note = ("the first %d users' %d interactions of this workload (1/8 row sub-sample), full item-side "
-                      "tables" % (nu, q_train.nnz))
-        if want_quality:
-            m = LightFM(no_components=d, loss=loss, random_state=7, max_sampled=MAX_SAMPLED)
-            m.fit(q_train, item_features=feats, epochs=q_epochs)
-            quality = {"epochs": q_epochs, "precision_at_10": precision_at_10(m, q_train, q_test, feats),
-                       "eval_users": int(len(np.unique(q_test.row))), "data": q_note,
-                       "metric": "precision_at_k(k=10) of lightfm/evaluation.py:14-87 on a held-out 5 percent of "
-                                 "the same synthetic process; both backends fit %d epochs from the same seed" % q_epochs}
-        if not args.no_cpu_baseline:
-            try:
-                if cfg["shape"] == "ml-20m":
-                    cpu, p_ref = reference_leg(args.config, q_train, q_test if want_quality else None, feats,
-                                               q_epochs, log, q_note)
-                    if quality is not None and p_ref is not None:
-                        quality["precision_at_10_ref"] = p_ref
-                        quality["delta"] = quality["precision_at_10"] - p_ref
-                else:
-                    # C4 / C5 shards: a row sub-sample (1/50 of the users, their interactions, the
-                    # full item-side tables), SURVEY.md 8(d)
-                    nu = max(1000, n_users // 50)
-                    keep = train.row < nu
-                    sub = sp.coo_matrix((train.data[keep], (train.row[keep], train.col[keep])),
-                                        shape=(nu, n_items), dtype=np.float32)
-                    cpu, _ = reference_leg(args.config, sub, None, feats, 3, log,
-                                           "the first %d users' %d interactions of this shard (1/50 row sub-"
-                                           "sample) over the full item-side tables" % (nu, sub.nnz))
-            except Exception as e:  # the baseline is reporting only; never fail the bench on it
-                log("cpu_baseline failed: %r" % (e,))
-        if not args.no_fit and cfg["shape"] == "ml-20m":
-            fit_epochs = 10
-            m = LightFM(no_components=d, loss=loss, random_state=3, max_sampled=MAX_SAMPLED)
-            t1 = time.perf_counter()
-            m.fit(train, item_features=feats, epochs=fit_epochs)
-            dt = time.perf_counter() - t1
-            fit = {"value": train.nnz * fit_epochs / dt, "unit": "interactions/s", "epochs": fit_epochs,
-                   "seconds": dt, "what": "LightFM.fit(train, epochs=%d) through the public API: host coercion, "
-                   "uploads, device positives build, epochs, finite checks, download" % fit_epochs}
-    else:
-        session.close()
+        quality, cpu, fit = reporting_legs(name, env, pieces, want_quality)
 
     if rank == 0:
-        value = total_pos / elapsed
-        par = ("1 GPU" if world == 1 else
-               "%s scaling over %d GPUs: %s; item tables merged by RCCL all-reduce (%s), %.1f merges per epoch"
-               % (scaling, world,
-                  "one COO row-sharded by user" if scaling == "strong" else "every rank its own full-size row shard",
-                  policy.mode, (state["merges"] - merges0) / float(n_epochs)))
         out = {
-            "metric": "positive interactions/sec/epoch (WARP, ML-20M)" if args.config == "c2" else
-                      "positive interactions/sec/epoch (%s, %s)" % (loss, args.config),
-            "value": value, "unit": "interactions/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None,
+            "metric": "positive interactions/sec/epoch (WARP, ML-20M)" if name == "c2" else
+                      "positive interactions/sec/epoch (%s, %s)" % (cfg["loss"], name),
+            "value": result["value"], "unit": "interactions/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": result["ms_per_step"],
+            "higher_is_better": True, "scaling": result["scaling"] if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"] % (global_n if scaling == "strong" or world == 1 else n_local),
-                       "name": args.config, "epochs_per_step": eps, "ms_per_epoch": elapsed * 1e3 / n_epochs,
-                       "parallelism": par, "device": dev_name},
-            "roofline": roofline,
+            "config": result["config"],
+            "roofline": result["roofline"],
             "cpu_baseline": cpu,
             "quality": quality,
             "end_to_end_fit": fit,
         }
+        if extras:
+            out["extra_configs"] = extras
         if tuned:
             out["config"]["non_default_options"] = tuned
-        if args.item_alpha or args.user_alpha:
-            out["config"]["item_alpha"], out["config"]["user_alpha"] = args.item_alpha, args.user_alpha
         if cpu:
-            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+            out["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -292,6 +292,16 @@ int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID_BYTES], in
 #define LFM_MERGE_MEAN 1
 #define LFM_MERGE_ADAGRAD 2
 int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode);
+/* The same merge, proportional to what the interval touched (csrc/session.hip: merge_group_sparse): the
+ * epoch kernels mark every row they update in a byte map; the ranks' maps are OR-ed (an all-reduce over
+ * n_feat bytes), and only the rows of the union travel -- packed deltas of W, G, b, bG, all-reduced on the
+ * session's communication stream.  overlap != 0: the call returns once the exchange is enqueued; the next
+ * segment trains while it runs, and its result is applied at the start of the next merge call or by
+ * lfm_session_comm_merge_flush (call it before reading the tables: check_finite, sync_to_host, the end of
+ * an epoch).  *bytes (may be NULL) = what this rank handed to RCCL.  Adagrad models only (LFM_EUNSUPPORTED
+ * for adadelta: use lfm_session_comm_merge).  Same modes and the same arithmetic as the dense merge. */
+int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes);
+int lfm_session_comm_merge_flush(lfm_session *s);
 /* Marks the current tables of `sides` as the start of a merge interval (lfm_session_comm_init
  * does it for the replicated sides; sessions merged with lfm_sessions_merge_local call it once
  * before training). */
@@ -302,6 +312,10 @@ int lfm_session_comm_barrier(lfm_session *s);
 /* The same merge arithmetic for K sessions living in ONE process on ONE device (no RCCL): how the
  * multi-GPU semantics are measured on a single GPU (tools/multi_gpu_emulation.py) and tested. */
 int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode);
+/* ... and of the sparse merge; overlap != 0 defers the application of the merged deltas to the next call
+ * (or to lfm_sessions_merge_local_flush): the one-segment delay of the overlapped multi-GPU exchange. */
+int lfm_sessions_merge_local_sparse(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap);
+int lfm_sessions_merge_local_flush(lfm_session **sessions, int32_t k);
 
 #ifdef __cplusplus
 }

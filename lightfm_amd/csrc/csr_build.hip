@@ -102,4 +102,35 @@ hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids,
     return hipSuccess;
 }
 
+// ids_out[0 .. *count) = the positions j < n with flags[j] != 0, ascending (multi-GPU merge: the rows touched
+// since the last merge).  ids_out has capacity n.  Synchronises the stream (the count goes to the host).
+hipError_t compact_flagged_rows(const unsigned char *flags, int64_t n, int32_t *ids_out, int64_t *count, hipStream_t st)
+{
+    *count = 0;
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipError_t e;
+    int *d_count = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        pool_free(d_count);
+        pool_free(tmp);
+    };
+#define CMP_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
+    CMP_TRY(pool_alloc((void **)&d_count, sizeof(int)));
+    hipcub::CountingInputIterator<int32_t> rows(0);
+    size_t bytes = 0;
+    CMP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, rows, flags, ids_out, d_count, (int)n, st));
+    CMP_TRY(pool_alloc(&tmp, std::max<size_t>(bytes, 16)));
+    CMP_TRY(hipcub::DeviceSelect::Flagged(tmp, bytes, rows, flags, ids_out, d_count, (int)n, st));
+    int c = 0;
+    CMP_TRY(hipMemcpyAsync(&c, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    CMP_TRY(hipStreamSynchronize(st));
+#undef CMP_TRY
+    cleanup();
+    *count = c;
+    return hipSuccess;
+}
+
 }  // namespace lfm

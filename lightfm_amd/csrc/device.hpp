@@ -43,7 +43,15 @@ struct DModel {
     float lr, rho, eps;
     int32_t max_sampled;
     double *scales;  // device [2]: item_scale, user_scale (PYX:214-215)
+    unsigned char *dirty[2];  // multi-GPU: byte per feature row of a side, set to 1 by every update of the row
+                              // (the rows the next merge exchanges, session.hip: merge_group_sparse); or nullptr
 };
+
+// Multi-GPU dirty-row tracking: plain byte stores of the same value race benignly.
+__device__ __forceinline__ void mark_dirty(const DModel &m, int side, int row)
+{
+    if (m.dirty[side]) m.dirty[side][row] = 1;
+}
 
 struct FitArgs {
     DCsr itf, usf, pos;
@@ -445,9 +453,11 @@ __device__ __forceinline__ void update_row(const DCsr &f, int row, int side, con
         int feat = f.identity ? k : uni(f.indices[k]);
         double w = f.identity ? 1.0 : (double)unif(f.data[k]);
         double lr = 0.0;
-        if (lane == 0)
+        if (lane == 0) {
             lr = cell_update(m.b[side] + feat, m.bG[side] + feat, m.bM[side] + feat, w, gbias, h,
                              alpha, atomic);
+            mark_dirty(m, side, feat);
+        }
         lr_bias += read_laned(lr, 0);
     }
     // then every coordinate (PYX:602-638); lane owns its coordinates
@@ -496,9 +506,11 @@ __device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int s
         }
         // biases (PYX:571-599): lane j owns entry j
         double lrb = 0.0;
-        if (lane < cnt)
+        if (lane < cnt) {
             lrb = cell_update(m.b[side] + myfeat, m.bG[side] + myfeat, m.bM[side] + myfeat, (double)myw,
                               gbias, h, alpha, atomic);
+            mark_dirty(m, side, myfeat);
+        }
         if (alpha != 0.0) lr_bias += wave_sum(lrb);
         // coordinates (PYX:602-638): lane owns its coordinates, 4 entries in flight
         for (int j0 = 0; j0 < cnt; j0 += 4) {
@@ -652,6 +664,7 @@ __device__ __forceinline__ double rows_update_parallel(const DModel &m, const Ro
                 put(m.b[s] + ft, nW[r], oW[r]);
                 put(m.bG[s] + ft, nG[r], oG[r]);
                 if (h.adadelta) put(m.bM[s] + ft, nM[r], oM[r]);
+                mark_dirty(m, s, ft);
             }
         }
     }
@@ -795,19 +808,27 @@ __device__ __forceinline__ int row_len(const DCsr &f, int row)
 //     float64 running totals -- the exact product of the launch -- reset them, and fold the scale into
 //     the weights (W / scale, scale := 1: regularize, PYX:652-675) once it has passed MAX_REG_SCALE, and
 //     at the end of the epoch.
-//   * READERS extrapolate: D(position q of the launch) = rho * (q - begin), rho = the growth per position
+//   * READERS extrapolate: the logarithm of the scale at position q of the launch is
+//     T(q) = L0 + rho * (q - begin), L0 = its value at the boundary, rho = the growth per position
 //     MEASURED over the previous launch (boundary kernel: D / positions).  Positions are visited in order
 //     by the grid-stride loops, so this is first-order exact; the error is the drift of the rate from one
 //     launch to the next (the Adagrad rates and the update frequency change by a few per cent per
-//     launch at most) times D, and the session bounds a launch to D <= ~0.5 (session.hip): a relative
-//     scale error of ~1e-2 at the very worst, 1e-4 at alpha = 1e-6 -- less than the reference's own threads
-//     lose in their racy multiply.  At every boundary the exact total replaces the estimate.
-// a.reg_live = [1 + SLOTS] lines of 128 B (uncached device memory): line 0 = {S0_item, S0_user, rho_item,
+//     launch at most) times D, and the session bounds a launch to D <= ~0.5 (session.hip) unless alpha is
+//     excessive: a relative scale error of ~1e-2 at the very worst, 1e-4 at alpha = 1e-6 -- less than the
+//     reference's own threads lose in their racy multiply.  At every boundary the exact total replaces
+//     the estimate.
+//   * FOLDS.  The reference folds the moment a scale passes MAX_REG_SCALE (locked_regularize, PYX:678-691):
+//     W := W / scale, scale := 1 -- after which representations (scale * W, PYX:306-313) are smaller by
+//     scale^2.  A launch cannot divide the tables, so a crossing inside a launch is a VIRTUAL fold: with
+//     LMAX = log(MAX_REG_SCALE) and nf = floor(T / LMAX) crossings so far, the reference's running scale is
+//     exp(T - nf LMAX) and its stored weights are ours / exp(nf LMAX); readers therefore multiply our
+//     weights by exp(T - 2 nf LMAX).  The boundary kernel applies the nf folds for real (W / exp(nf LMAX),
+//     L0 := T - nf LMAX).  At sane alpha nf is 0 for every launch but one in many epochs; at excessive
+//     alpha (the reference's alpha = 1 test: a crossing every ~280 interactions) the multiplier underflows
+//     and the model is flattened to zero exactly as the reference's is -- in full-length launches.
+//     (Cell updates between a virtual fold and the next boundary are applied at the pre-fold magnitude.)
+// a.reg_live = [1 + SLOTS] lines of 128 B (uncached device memory): line 0 = {L0_item, L0_user, rho_item,
 // rho_user} (written between launches only), line 1 + s = {D_item, D_user} of slot s.
-// A launch covers its slice of the epoch whatever alpha is.  (An alpha so large that the scale passes
-// MAX_REG_SCALE INSIDE a launch: representations use the clamped scale until the boundary applies the
-// whole product -- the "excessive regularisation" regime of the reference's tests, where the model is
-// flattened either way.)
 struct RegScale {
     static constexpr int SLOTS = 16;
     static constexpr int LINE = 32;                    // floats per 128-B line
@@ -832,14 +853,23 @@ struct RegScale {
     {
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
     }
+    static constexpr float LMAX = 13.815510557964274f;  // log(MAX_REG_SCALE)
+    // multiplier of this table's stored weights at log-scale T (see FOLDS above)
+    __device__ static __forceinline__ float multiplier(float T)
+    {
+        T = fmaxf(T, 0.0f);
+        const float nf = floorf(T * (1.0f / LMAX));
+        const float e = T - 2.0f * nf * LMAX;
+        return (e >= 0.0f && e < 0.03125f) ? exp_f32(e) : __expf(e);
+    }
     // (float)(1.0 * scale) of both sides at position `done` (= q - begin) of the launch, as
     // compute_representation uses it (PYX:306); wave-uniform
     __device__ static __forceinline__ void scales(const float *reg_live, int64_t done, float &w_item, float &w_user)
     {
         const float4 h = *reinterpret_cast<const float4 *>(reg_live);  // constant while the launch runs
         const float n = (float)done;
-        w_item = first_lane(fminf(h.x * exp_f32(fmaxf(h.z * n, 0.0f)), (float)MAX_REG_SCALE));
-        w_user = first_lane(fminf(h.y * exp_f32(fmaxf(h.w * n, 0.0f)), (float)MAX_REG_SCALE));
+        w_item = first_lane(multiplier(h.x + h.z * n));
+        w_user = first_lane(multiplier(h.y + h.w * n));
     }
     __device__ __forceinline__ void begin() { p_i = p_u = 0.0f; }
     // one updated interaction of this wavefront (all lanes call it; lane 0's values count)
@@ -1029,6 +1059,7 @@ __device__ __forceinline__ void warp_update_identity(double loss, const FitArgs 
         const double gb = lane == 0 ? -loss : loss;
         cell_math(obW, obG, obM, 1.0, gb, h, 0.0, nW, nG, nM, lr);
         publish_cell(bW, bG, bM, obW, obG, obM, nW, nG, nM, 1.0, gb, h, 0.0, um);
+        mark_dirty(a.m, side, brow);
     }
 }
 

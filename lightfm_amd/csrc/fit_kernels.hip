@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
 // ---------------------------------------------------- lazy regularisation ---
 
 // Parallel mode (device.hpp: RegScale): reg_log[2] = log(item_scale), log(user_scale) at the last launch
-// boundary (float64 running totals); reg_live = line 0 {the scales then, the growth of their logs per
+// boundary (float64 running totals); reg_live = line 0 {the same as float32, the growth of the logs per
 // position measured over the last launch}, lines 1.. {slots collecting the growth of the logs since then}.
 // Serial mode and the host see m.scales[2].
 // Start of a parallel epoch: reg_log := log(scales), slots := 0 (the measured rates stay).
@@ -427,7 +427,7 @@ __global__ void reg_log_init_kernel(const double *scales, double *reg_log, float
     if (blockIdx.x != 0) return;
     if (t < 2) {
         reg_log[t] = log(scales[t]);
-        reg_live[t] = (float)fmin(scales[t], MAX_REG_SCALE);
+        reg_live[t] = (float)log(scales[t]);
     }
     if (t < RegScale::SLOTS) {
         reg_live[RegScale::LINE * (1 + t) + 0] = 0.0f;
@@ -443,18 +443,46 @@ __device__ __forceinline__ double reg_slots_sum(const float *reg_live, int side)
     return acc;
 }
 
-// regularize (PYX:652-675) when `force`, locked_regularize's test (PYX:678-691) otherwise.  reg_log != nullptr:
-// the scales are exp(reg_log + slots) (parallel mode, between two launches), else m.scales (serial mode).
+// What a launch boundary folds (device.hpp: RegScale, FOLDS): `force` (end of the epoch, PYX:910-912) folds
+// the whole scale of both sides; otherwise a side that has crossed log(MAX_REG_SCALE) nf times folds
+// exp(nf LMAX) and keeps the remainder, and -- locked_regularize regularises BOTH sides when either
+// scale has passed the bound (PYX:686-689) -- the other side folds its whole scale with it.
+// fold[side] = log of the divisor, rest[side] = log-scale afterwards.
+__device__ __forceinline__ void reg_fold_plan(const double l[2], int force, double fold[2], double rest[2])
+{
+    const double LMAX = log(MAX_REG_SCALE);
+    double nf[2];
+    for (int k = 0; k < 2; ++k) nf[k] = l[k] > LMAX ? floor(l[k] / LMAX) : 0.0;
+    const bool any = nf[0] > 0.0 || nf[1] > 0.0;
+    for (int k = 0; k < 2; ++k) {
+        if (force || (any && nf[k] == 0.0)) fold[k] = l[k];
+        else fold[k] = nf[k] * LMAX;
+        rest[k] = l[k] - fold[k];
+    }
+}
+
+// regularize (PYX:652-675).  reg_log != nullptr: parallel mode between two launches (the plan above),
+// else serial mode: m.scales, folded whole when `force` or past the bound (PYX:678-691).
 __global__ void regularize_kernel(DModel m, const double *reg_log, const float *reg_live, int force)
 {
-    double si = reg_log ? exp(reg_log[0] + reg_slots_sum(reg_live, 0)) : m.scales[0];
-    double su = reg_log ? exp(reg_log[1] + reg_slots_sum(reg_live, 1)) : m.scales[1];
-    if (!force && !(si > MAX_REG_SCALE || su > MAX_REG_SCALE)) return;
-    if (si == 1.0 && su == 1.0) return;  // x / 1.0 == x bit for bit
+    double div[2];
+    if (reg_log) {
+        const double l[2] = {reg_log[0] + reg_slots_sum(reg_live, 0), reg_log[1] + reg_slots_sum(reg_live, 1)};
+        double fold[2], rest[2];
+        reg_fold_plan(l, force, fold, rest);
+        div[0] = exp(fold[0]);
+        div[1] = exp(fold[1]);
+    } else {
+        div[0] = m.scales[0];
+        div[1] = m.scales[1];
+        if (!force && !(div[0] > MAX_REG_SCALE || div[1] > MAX_REG_SCALE)) return;
+    }
+    if (div[0] == 1.0 && div[1] == 1.0) return;  // x / 1.0 == x bit for bit
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int side = 0; side < 2; ++side) {
-        double s = side == 0 ? si : su;
+        const double s = div[side];
+        if (s == 1.0) continue;
         int64_t nW = (int64_t)m.n_feat[side] * m.d;
         for (int64_t j = t; j < nW; j += stride) m.W[side][j] = (float)((double)m.W[side][j] / s);
         for (int64_t j = t; j < m.n_feat[side]; j += stride)
@@ -462,7 +490,7 @@ __global__ void regularize_kernel(DModel m, const double *reg_log, const float *
     }
 }
 
-// After regularize_kernel: the launch's growth moves into the running totals; a fold resets them.
+// After regularize_kernel: the launch's growth moves into the running totals, minus what was folded.
 __global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_live, int force, int64_t positions)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -474,25 +502,22 @@ __global__ void reg_boundary_kernel(double *scales, double *reg_log, float *reg_
             return;
         }
         const double d0 = reg_slots_sum(reg_live, 0), d1 = reg_slots_sum(reg_live, 1);
-        double l0 = reg_log[0] + d0, l1 = reg_log[1] + d1;
+        const double l[2] = {reg_log[0] + d0, reg_log[1] + d1};
+        double fold[2], rest[2];
+        reg_fold_plan(l, force, fold, rest);
         if (positions >= 256) {  // the rate the next launch's readers extrapolate with (device.hpp: RegScale)
             reg_live[2] = (float)(d0 / (double)positions);
             reg_live[3] = (float)(d1 / (double)positions);
         }
-        if (force || exp(l0) > MAX_REG_SCALE || exp(l1) > MAX_REG_SCALE) {
-            l0 = 0.0;
-            l1 = 0.0;
-            scales[0] = 1.0;
-            scales[1] = 1.0;
+        for (int k = 0; k < 2; ++k) {
+            reg_log[k] = rest[k];
+            reg_live[k] = (float)rest[k];
+            scales[k] = exp(rest[k]);  // 1.0 after the end-of-epoch fold: what the host and serial mode see
         }
-        reg_log[0] = l0;
-        reg_log[1] = l1;
         for (int s = 0; s < RegScale::SLOTS; ++s) {
             reg_live[RegScale::LINE * (1 + s) + 0] = 0.0f;
             reg_live[RegScale::LINE * (1 + s) + 1] = 0.0f;
         }
-        reg_live[0] = (float)fmin(exp(l0), MAX_REG_SCALE);
-        reg_live[1] = (float)fmin(exp(l1), MAX_REG_SCALE);
     }
 }
 

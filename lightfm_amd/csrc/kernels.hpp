@@ -87,6 +87,8 @@ hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d,
 hipError_t build_positives_csr(const int32_t *user_ids, const int32_t *item_ids, int64_t n, int32_t n_users,
                                int32_t n_items, int32_t *indices_out, int32_t *indptr_out, int64_t *nnz_out,
                                hipStream_t st);
+// csr_build.hip: ascending positions of the non-zero bytes of flags[0 .. n) (synchronises the stream)
+hipError_t compact_flagged_rows(const unsigned char *flags, int64_t n, int32_t *ids_out, int64_t *count, hipStream_t st);
 hipError_t launch_ranks(const RanksArgs &a, hipStream_t st);
 // MFMA pre-filtered variant (d <= 128): false if the shape is outside what it supports
 bool ranks_mfma_supported(int d);

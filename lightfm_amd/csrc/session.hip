@@ -174,6 +174,12 @@ struct DBuf {
         if (trace_enabled()) fprintf(stderr, "LFM_ALLOC %p %zu flags %d\n", (void *)p, n * sizeof(T), flags);
         return LFM_OK;
     }
+    // capacity semantics (buffers whose size changes from call to call): grows, never shrinks
+    int reserve(size_t count)
+    {
+        if (p && n >= count) return LFM_OK;
+        return alloc(std::max(count, n + n / 2));
+    }
     int upload(const T *src, size_t count)
     {
         LFM_TRY(alloc(count));
@@ -370,6 +376,21 @@ struct lfm_session {
     DBuf<float> snap[2][6];     // the tables at the start of the current merge interval
     int snap_sides = 0;         // bit 0 item, bit 1 user: which sides have a valid snapshot
     DBuf<float> scratch[2];     // merge temporaries (ADAGRAD mode: this rank's dG; local reduce: sums)
+    // sparse merge (merge_group_sparse): rows touched since the last merge, two byte maps per side (the
+    // kernels of the segment after a merge mark the other one), and the exchange that may still be in flight
+    DBuf<unsigned char> dirty[2][2];
+    int dirty_cur[2] = {0, 0};
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+    struct PendingMerge {
+        bool active = false, on_comm_stream = false;
+        int sides = 0;
+        float wscale = 1.0f;
+        int64_t n_u[2] = {0, 0};
+        DBuf<int32_t> ids[2];     // the union of touched rows, ascending
+        DBuf<float> sum[2][4];    // packed deltas of W, G, b, bG: this rank's, then the sum over ranks
+        DBuf<float> loc[2][4];    // this rank's own packed deltas (unscaled)
+    } pend;
 
     // LIGHTFM_AMD_VALIDATE=1 (debugging): checksums of the read-only device inputs at the end of the
     // previous epoch, by (address, bytes): see validate_inputs()
@@ -383,7 +404,11 @@ struct lfm_session {
         // the buffers go back to the pool without any implicit synchronisation (hipFree had one)
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto *s : shuffles) delete s;
+        if (comm_stream) (void)hipStreamSynchronize(comm_stream);
         if (comm && rccl()) rccl()->CommDestroy(comm);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
+        if (ev_pack) (void)hipEventDestroy(ev_pack);
+        if (ev_comm) (void)hipEventDestroy(ev_comm);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -408,6 +433,7 @@ struct lfm_session {
         m.eps = eps;
         m.max_sampled = max_sampled;
         m.scales = scales.p;
+        for (int s = 0; s < 2; ++s) m.dirty[s] = dirty[s][dirty_cur[s]].p;  // nullptr unless a merge interval is open
         return m;
     }
 };
@@ -541,8 +567,7 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
     double sc[2] = {model->item_scale, model->user_scale}, zero[2] = {0.0, 0.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
     if (rc == LFM_OK) guard(s->reg_log.upload(zero, 2));
-    std::vector<float> live0(RegScale::FLOATS, 0.0f);  // device.hpp: RegScale (line 0 = the scales, then the slots)
-    live0[0] = live0[1] = 1.0f;
+    std::vector<float> live0(RegScale::FLOATS, 0.0f);  // device.hpp: RegScale (line 0 = log-scales and rates, then the slots)
     s->reg_live.flags = (int)hipDeviceMallocUncached;  // read and added to by every XCD while a launch runs
     if (rc == LFM_OK) guard(s->reg_live.upload(live0.data(), live0.size()));
     if (rc == LFM_OK) guard(s->counters.alloc(13));
@@ -791,13 +816,24 @@ static int snapshot_side(lfm_session *s, int side)
     return LFM_OK;
 }
 
+static int enable_dirty_tracking(lfm_session *s, int side);
+static int complete_pending(lfm_session *s, bool exact = false);
+
 extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
 {
     if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge_begin arguments");
     if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session has no merge intervals");
     HIP_TRY(hipSetDevice(s->device));
     for (int side = 0; side < 2; ++side)
-        if ((sides >> side) & 1) LFM_TRY(snapshot_side(s, side));
+        if ((sides >> side) & 1) {
+            LFM_TRY(snapshot_side(s, side));
+            if (!s->adadelta) LFM_TRY(enable_dirty_tracking(s, side));
+        }
+    if (!s->comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     return LFM_OK;
 }
@@ -818,6 +854,14 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
     // local groups run on sessions[0]'s stream; the others' streams are drained first
     hipStream_t st = s0->stream;
     for (int i = 1; i < k; ++i) HIP_TRY(hipStreamSynchronize(ss[i]->stream));
+    for (int i = 0; i < k; ++i) {  // a sparse exchange still in flight lands first; the dense merge covers every row
+        LFM_TRY(complete_pending(ss[i]));
+        HIP_TRY(hipStreamSynchronize(ss[i]->stream));
+        for (int side = 0; side < 2; ++side)
+            for (int m = 0; m < 2; ++m)
+                if (((sides >> side) & 1) && ss[i]->dirty[side][m].p)
+                    HIP_TRY(hipMemsetAsync(ss[i]->dirty[side][m].p, 0, ss[i]->dirty[side][m].n, st));
+    }
     auto reduce_kinds = [&](int side, std::initializer_list<int> kinds) -> int {
         if (use_rccl) {
             if (r->GroupStart) NCCL_TRY(r->GroupStart());
@@ -889,6 +933,286 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    return LFM_OK;
+}
+
+// ------------------------------------------------- sparse (dirty-row) merge ---
+// The dense merge above moves every replicated table through the fabric six times and through xGMI once per
+// merge, whatever the interval touched: 2.6 GB for the 5 M-row item tables of BASELINE config C4, against
+// ~1 ms of training per 2^20 interactions.  This one is proportional to what changed:
+//   1. every update marks its rows in a byte map (device.hpp: mark_dirty; two maps per side, ping-pong);
+//   2. the ranks' maps are OR-ed (all-reduce MAX over bytes: n_feat bytes) -- every rank then holds the same
+//      union U of touched rows -- and compacted to an ascending id list (csr_build.hip: compact_flagged_rows);
+//   3. each rank packs its deltas (table - snapshot) of the rows of U into dense [|U|, d] buffers;
+//   4. the packed buffers are all-reduced (RCCL over xGMI; LFM_MERGE_ADAGRAD: accumulators first, then the
+//      embedding deltas rescaled exactly as in the dense merge) on the session's COMMUNICATION stream;
+//   5. apply, rows of U only: table += sum - local delta, snapshot += sum.
+// With `overlap` steps 4-5 are asynchronous: the call returns after enqueueing the exchange, the next segment
+// trains on tables that hold only the rank's own updates, and step 5 runs at the start of the NEXT merge call
+// (or lfm_session_comm_merge_flush): the exchange of segment j overlaps the kernels of segment j + 1, at the
+// price of the other ranks' updates arriving one segment late.  The arithmetic does not depend on it: whatever
+// the local table gained between pack and apply stays in (table - snapshot) for the next merge.
+__global__ void pack_delta_kernel(const float *tab, const float *snap, const int32_t *ids, int64_t n_u, int d, float *loc, float *sum)
+{
+    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t0; j < total; j += st) {
+        const int64_t u = j / d;
+        const int c = (int)(j - u * d);
+        const size_t at = (size_t)ids[u] * d + c;
+        const float v = tab[at] - snap[at];
+        loc[j] = v;
+        sum[j] = v;
+    }
+}
+// LFM_MERGE_ADAGRAD on packed rows: dW *= sqrt((G0 + dG_rank / 2) / (G0 + dG_all / 2)), G0 from the snapshot
+__global__ void rescale_packed_kernel(float *dW, const float *snapG, const int32_t *ids, const float *dg_rank, const float *dg_all,
+                                      int64_t n_u, int d)
+{
+    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t0; j < total; j += st) {
+        const int64_t u = j / d;
+        const int c = (int)(j - u * d);
+        const float g0 = snapG[(size_t)ids[u] * d + c];
+        const float num = g0 + 0.5f * dg_rank[j], den = g0 + 0.5f * dg_all[j];
+        if (den > 0.0f && num >= 0.0f && den > num) dW[j] *= sqrtf(num / den);
+    }
+}
+// table += scale * sum - local ; snapshot += scale * sum   (rows of U).  exact: nothing trained since the pack
+// (synchronous merge): table := snapshot := snapshot + scale * sum, bit-identical on every rank.
+__global__ void apply_packed_kernel(float *tab, float *snap, const int32_t *ids, const float *sum, const float *loc, float scale,
+                                    int64_t n_u, int d, int exact)
+{
+    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t0; j < total; j += st) {
+        const int64_t u = j / d;
+        const int c = (int)(j - u * d);
+        const size_t at = (size_t)ids[u] * d + c;
+        const float s = sum[j] * scale;
+        const float v = snap[at] + s;
+        tab[at] = exact ? v : tab[at] + (s - loc[j]);
+        snap[at] = v;
+    }
+}
+struct BytePack { unsigned char *p[16]; };
+__global__ void local_or_kernel(BytePack xs, int k, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t; j < n; j += st) {
+        unsigned char v = 0;
+        for (int r = 0; r < k; ++r) v |= xs.p[r][j];
+        for (int r = 0; r < k; ++r) xs.p[r][j] = v;
+    }
+}
+
+static const int SPARSE_KINDS[4] = {0, 1, 3, 4};  // W, G, b, bG (adagrad models)
+
+static int enable_dirty_tracking(lfm_session *s, int side)
+{
+    for (int m = 0; m < 2; ++m) {
+        if (s->dirty[side][m].p && s->dirty[side][m].n == (size_t)s->n_feat[side]) continue;
+        LFM_TRY(s->dirty[side][m].alloc((size_t)s->n_feat[side]));
+        if (s->n_feat[side]) HIP_TRY(hipMemsetAsync(s->dirty[side][m].p, 0, (size_t)s->n_feat[side], s->stream));
+    }
+    return LFM_OK;
+}
+
+// step 5 of a merge whose exchange may still be in flight
+static int complete_pending(lfm_session *s, bool exact)
+{
+    if (!s->pend.active) return LFM_OK;
+    if (s->pend.on_comm_stream) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    for (int side = 0; side < 2; ++side) {
+        if (!((s->pend.sides >> side) & 1)) continue;
+        const int64_t n_u = s->pend.n_u[side];
+        if (n_u == 0) continue;
+        for (int q = 0; q < 4; ++q) {
+            const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;
+            const bool is_weight = kind == 0 || kind == 3;
+            apply_packed_kernel<<<grid_for(n_u * d), 256, 0, s->stream>>>(s->tab[side][kind].p, s->snap[side][kind].p, s->pend.ids[side].p,
+                                                                         s->pend.sum[side][q].p, s->pend.loc[side][q].p,
+                                                                         is_weight ? s->pend.wscale : 1.0f, n_u, d, exact ? 1 : 0);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    s->pend.active = false;
+    return LFM_OK;
+}
+
+static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sides, int mode, bool overlap, int64_t *bytes_out)
+{
+    lfm_session *s0 = ss[0];
+    const bool use_rccl = (k == 1 && s0->comm != nullptr);
+    Rccl *r = use_rccl ? rccl() : nullptr;
+    if (use_rccl && !r) return fail(LFM_ECOMM, "librccl.so not available");
+    if (k > 16) return fail(LFM_EINVAL, "at most 16 local sessions per merge group");
+    if (mode < 0 || mode > 2) return fail(LFM_EINVAL, "unknown merge mode");
+    if (s0->adadelta) return fail(LFM_EUNSUPPORTED, "the sparse merge covers adagrad models (adadelta: lfm_session_comm_merge)");
+    int64_t bytes = 0;
+    // local groups run on sessions[0]'s stream; the others' streams are drained first
+    hipStream_t st = s0->stream;
+    for (int i = 1; i < k; ++i) HIP_TRY(hipStreamSynchronize(ss[i]->stream));
+    // the previous merge's exchange has to land before this one's deltas are formed
+    for (int i = 0; i < k; ++i) {
+        if (!ss[i]->pend.active) continue;
+        if (i > 0 && ss[i]->pend.on_comm_stream) return fail(LFM_EINVAL, "local merge group with a communicator");
+        hipStream_t own = ss[i]->stream;
+        ss[i]->stream = st;  // (local groups: everything on sessions[0]'s stream)
+        const int rc = complete_pending(ss[i]);
+        ss[i]->stream = own;
+        LFM_TRY(rc);
+    }
+    for (int side = 0; side < 2; ++side) {
+        if (!((sides >> side) & 1)) continue;
+        const int64_t nf = s0->n_feat[side];
+        for (int i = 0; i < k; ++i) {
+            if (!((ss[i]->snap_sides >> side) & 1) || !ss[i]->dirty[side][0].p)
+                return fail(LFM_EINVAL, "sparse merge without lfm_session_merge_begin");
+            if (ss[i]->n_feat[side] != nf || ss[i]->d != s0->d) return fail(LFM_EINVAL, "sessions differ in shape");
+        }
+        if (nf == 0) continue;
+        // 2. union of the maps
+        const int cur = s0->dirty_cur[side];
+        if (use_rccl) {
+            NCCL_TRY(r->AllReduce(s0->dirty[side][cur].p, s0->dirty[side][cur].p, (size_t)nf, ncclUint8, ncclMax, s0->comm, st));
+            bytes += nf;
+        } else if (k > 1) {
+            BytePack pk;
+            for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->dirty[side][ss[i]->dirty_cur[side]].p;
+            local_or_kernel<<<grid_for(nf), 256, 0, st>>>(pk, k, nf);
+        }
+        // ... compacted (identical on every rank: same map, ascending order)
+        for (int i = 0; i < k; ++i) {
+            lfm_session *s = ss[i];
+            const int c = s->dirty_cur[side];
+            LFM_TRY(s->pend.ids[side].reserve((size_t)nf));
+            int64_t n_u = 0;
+            hipError_t e = compact_flagged_rows(s->dirty[side][c].p, nf, s->pend.ids[side].p, &n_u, st);
+            if (e != hipSuccess) return fail(LFM_ENODEV, std::string("compact_flagged_rows: ") + hipGetErrorString(e));
+            s->pend.n_u[side] = n_u;
+            HIP_TRY(hipMemsetAsync(s->dirty[side][c].p, 0, (size_t)nf, st));  // ready for the interval after next
+            s->dirty_cur[side] = c ^ 1;                                       // the next segment marks the other map
+            // 3. pack
+            for (int q = 0; q < 4 && n_u; ++q) {
+                const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;
+                LFM_TRY(s->pend.sum[side][q].reserve((size_t)n_u * d));
+                LFM_TRY(s->pend.loc[side][q].reserve((size_t)n_u * d));
+                pack_delta_kernel<<<grid_for(n_u * d), 256, 0, st>>>(s->tab[side][kind].p, s->snap[side][kind].p, s->pend.ids[side].p, n_u, d,
+                                                                     s->pend.loc[side][q].p, s->pend.sum[side][q].p);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        const int64_t n_u = s0->pend.n_u[side];
+        for (int i = 1; i < k; ++i)
+            if (ss[i]->pend.n_u[side] != n_u) return fail(LFM_ECORRUPT, "local merge group: the sessions' unions differ");
+        if (use_rccl) bytes += n_u * (2 * (int64_t)s0->d + 2) * (int64_t)sizeof(float);
+    }
+    // 4. the exchange: RCCL on the communication stream (overlaps the next segment), local groups in place
+    hipStream_t cs = st;
+    if (use_rccl) {
+        cs = s0->comm_stream;
+        HIP_TRY(hipEventRecord(s0->ev_pack, st));
+        HIP_TRY(hipStreamWaitEvent(cs, s0->ev_pack, 0));
+    }
+    auto reduce = [&](int side, std::initializer_list<int> qs) -> int {
+        const int64_t n_u = s0->pend.n_u[side];
+        if (n_u == 0) return LFM_OK;
+        if (use_rccl) {
+            if (r->GroupStart) NCCL_TRY(r->GroupStart());
+            for (int q : qs) {
+                const size_t cnt = (size_t)n_u * (SPARSE_KINDS[q] < 3 ? s0->d : 1);
+                NCCL_TRY(r->AllReduce(s0->pend.sum[side][q].p, s0->pend.sum[side][q].p, cnt, ncclFloat, ncclSum, s0->comm, cs));
+            }
+            if (r->GroupEnd) NCCL_TRY(r->GroupEnd());
+        } else if (k > 1) {
+            for (int q : qs) {
+                const int64_t cnt = n_u * (SPARSE_KINDS[q] < 3 ? s0->d : 1);
+                PtrPack pk;
+                for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->pend.sum[side][q].p;
+                local_allreduce_kernel<<<grid_for(cnt), 256, 0, cs>>>(pk, k, cnt);
+            }
+        }
+        return LFM_OK;
+    };
+    float wscale = 1.0f;
+    for (int side = 0; side < 2; ++side) {
+        if (!((sides >> side) & 1) || s0->n_feat[side] == 0) continue;
+        if (mode == LFM_MERGE_ADAGRAD) {
+            LFM_TRY(reduce(side, {1, 3}));  // accumulators (G, bG) first
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                const int64_t n_u = s->pend.n_u[side];
+                if (!n_u) continue;
+                rescale_packed_kernel<<<grid_for(n_u * s->d), 256, 0, cs>>>(s->pend.sum[side][0].p, s->snap[side][1].p, s->pend.ids[side].p,
+                                                                           s->pend.loc[side][1].p, s->pend.sum[side][1].p, n_u, s->d);
+                rescale_packed_kernel<<<grid_for(n_u), 256, 0, cs>>>(s->pend.sum[side][2].p, s->snap[side][4].p, s->pend.ids[side].p,
+                                                                    s->pend.loc[side][3].p, s->pend.sum[side][3].p, n_u, 1);
+            }
+            LFM_TRY(reduce(side, {0, 2}));
+        } else {
+            LFM_TRY(reduce(side, {0, 1, 2, 3}));
+            if (mode == LFM_MERGE_MEAN) wscale = 1.0f / (float)nranks_total;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (use_rccl) HIP_TRY(hipEventRecord(s0->ev_comm, cs));
+    for (int i = 0; i < k; ++i) {
+        ss[i]->pend.active = true;
+        ss[i]->pend.sides = sides;
+        ss[i]->pend.wscale = wscale;
+        ss[i]->pend.on_comm_stream = use_rccl;
+    }
+    if (!overlap) {
+        for (int i = 0; i < k; ++i) {
+            hipStream_t own = ss[i]->stream;
+            ss[i]->stream = st;
+            const int rc = complete_pending(ss[i], true);
+            ss[i]->stream = own;
+            LFM_TRY(rc);
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (bytes_out) *bytes_out = bytes;
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes)
+{
+    if (bytes) *bytes = 0;
+    if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    if (!s->comm || sides == 0) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    lfm_session *g[1] = {s};
+    return merge_group_sparse(g, 1, s->nranks, sides, mode, overlap != 0, bytes);
+}
+
+extern "C" int lfm_session_comm_merge_flush(lfm_session *s)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    LFM_TRY(complete_pending(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LFM_OK;
+}
+
+extern "C" int lfm_sessions_merge_local_sparse(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap)
+{
+    if (!sessions || k < 1 || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    for (int i = 0; i < k; ++i)
+        if (!sessions[i] || sessions[i]->device != sessions[0]->device || sessions[i]->comm)
+            return fail(LFM_EINVAL, "local merge needs sessions of one device without a communicator");
+    HIP_TRY(hipSetDevice(sessions[0]->device));
+    return merge_group_sparse(sessions, k, k, sides, mode, overlap != 0, nullptr);
+}
+
+extern "C" int lfm_sessions_merge_local_flush(lfm_session **sessions, int32_t k)
+{
+    if (!sessions || k < 1) return fail(LFM_EINVAL, "bad arguments");
+    HIP_TRY(hipSetDevice(sessions[0]->device));
+    for (int i = 0; i < k; ++i) {
+        if (!sessions[i]) return fail(LFM_EINVAL, "null session");
+        LFM_TRY(complete_pending(sessions[i]));
+        HIP_TRY(hipStreamSynchronize(sessions[i]->stream));
+    }
     return LFM_OK;
 }
 
@@ -1269,7 +1593,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
     if (reg && !serial) HIP_TRY(launch_reg_log_init(s->scales.p, s->reg_log.p, s->reg_live.p, s->stream));
     const double reg_step = log1p(std::max(item_alpha, user_alpha) * (double)std::max(s->lr, 1e-6f));
-    const int64_t reg_len_cap = reg ? (int64_t)std::max(65536.0, std::min(1e12, 0.5 / std::max(reg_step, 1e-300))) : INT64_MAX;
+    // accuracy: a growth of <= 0.5 per launch; never below 64 Ki positions for that -- but never so long that
+    // the scale could grow by more than e^55 (four virtual folds) either: cells an interaction touches are
+    // multiplied by (1 + alpha lr) in place (PYX:433, 446), and only a boundary divides them again
+    const int64_t reg_len_cap = !reg ? INT64_MAX : (int64_t)std::max(256.0, std::max(
+        std::min(1e12, 0.5 / std::max(reg_step, 1e-300)), std::min(65536.0, 55.0 / std::max(reg_step, 1e-300))));
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
@@ -1342,8 +1670,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // Lazy regularisation: the launch's readers extrapolate the scale's growth from the rate of the
             // previous launch (device.hpp: RegScale); a launch is kept to a growth of at most ~0.5 in log
             // scale (at the bound log1p(alpha * lr) per position) so that the extrapolation error stays
-            // around a per cent -- but never below 64 Ki positions: past that alpha the model is flattened
-            // whatever the scale's third digit is ("excessive regularisation").
+            // around a per cent -- but not below 64 Ki positions for accuracy's sake: past that alpha the model is
+            // flattened whatever the scale's third digit is ("excessive regularisation"; see reg_len_cap).
             if (reg) len = std::min<int64_t>(len, reg_len_cap);
             a.begin = begin;
             a.end = begin + len;

@@ -4,15 +4,20 @@ One process per GPU.  The interaction matrix is sharded by USER into contiguous 
 balanced by interaction count.  With identity user features a rank holds ONLY its own users'
 rows of the user tables (ids rebased to the range; never communicated); the item tables are
 replicated.  An epoch runs as SEGMENTS of the rank's shuffled shard with a merge of the
-replicated tables after every segment (csrc/session.hip: merge_group, one grouped RCCL
-all-reduce of the tables' deltas over xGMI):
+replicated tables after every segment (csrc/session.hip: merge_group_sparse -- the rows touched
+since the last merge, found by OR-ing the ranks' dirty-row maps, travel as packed deltas through
+an RCCL all-reduce over xGMI on a communication stream of their own; the exchange of segment j
+overlaps the kernels of segment j + 1 and lands at the next merge):
 
 * every rank derives the same segment list from global numbers only (`merge_schedule`), so all
   ranks call the collective the same number of times;
 * the interval between merges GROWS with the training history -- like the number of
   interactions in flight inside one GPU (DESIGN.md "Hogwild at GPU width"), replicas that
   have not exchanged their updates are harmless once the model has left its initial state and
-  ruinous before -- from `merge_min` interactions up to `merge_max` (all ranks together).
+  ruinous before -- from `merge_min` interactions up to `merge_max` (all ranks together);
+* both bounds scale with the replicated table: what matters is how many un-exchanged updates
+  a ROW collects, so a 5 M-row item table merges every 64 updates per row (320 M
+  interactions), not every 8 Mi interactions like ML-20M's 27 k rows.
 
 `torch.distributed` (any backend, gloo is enough) is used ONLY for the rendezvous: broadcasting
 the RCCL unique id and the initial tables, and gathering the user rows at the end.  The data
@@ -77,28 +82,38 @@ class MergePolicy(object):
     """When and how the replicated tables are merged.
 
     merge_k    the interval between merges is (interactions all ranks have trained on so far)
-               / merge_k, clamped to [merge_min, merge_max]
-    merge_min  smallest interval (interactions of ALL ranks together)
-    merge_max  largest interval; 0 = world * 2**20 (one full-size launch per rank)
+               / merge_k, clamped to [lo, cap]
+    merge_min  lo = max(merge_min, rows_lo * replicated rows) interactions of ALL ranks together
+    merge_max  cap; 0 = max(world * 2**20 (one full-size launch per rank), rows_k * replicated rows)
+    rows_lo, rows_k  un-exchanged updates per replicated ROW the shortest / longest interval may
+               collect (an interaction updates 1.4 item rows on the BASELINE shapes): the measured
+               ML-20M policy (8 Mi interactions over 26 744 item rows at 8 ranks = ~450 per row,
+               precision@10 within the gate) bounds rows_k from above
     mode       "sum" | "mean" | "adagrad" (include/lfm_hip.h: LFM_MERGE_*)
+    sparse     exchange only the rows touched since the last merge (default); False = the dense
+               all-reduce of whole tables
+    overlap    sparse merges: the exchange overlaps the next segment and lands one merge later
     """
 
-    def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad"):
+    def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad", rows_lo=1, rows_k=64,
+                 sparse=True, overlap=True):
         self.merge_k, self.merge_min, self.merge_max, self.mode = merge_k, merge_min, merge_max, mode
+        self.rows_lo, self.rows_k, self.sparse, self.overlap = rows_lo, rows_k, sparse, overlap
 
     def mode_id(self):
         return N.MERGE_MODES[self.mode]
 
 
-def merge_schedule(global_history, global_n, world, policy=None):
+def merge_schedule(global_history, global_n, world, policy=None, n_rows=0):
     """Segment boundaries of one epoch as FRACTIONS of the epoch, 0 = f[0] < ... < f[-1] = 1,
     computed from global numbers only (identical on every rank).  A rank runs its shuffled
-    positions [round(f[j] * n_local), round(f[j+1] * n_local)) and merges after each."""
+    positions [round(f[j] * n_local), round(f[j+1] * n_local)) and merges after each.
+    n_rows = rows of the replicated tables (0: the bounds do not scale with the table)."""
     policy = policy or MergePolicy()
     if global_n <= 0:
         return np.array([0.0, 1.0])
-    cap = policy.merge_max if policy.merge_max > 0 else world * (1 << 20)
-    lo = max(1, min(policy.merge_min, cap))
+    cap = policy.merge_max if policy.merge_max > 0 else max(world * (1 << 20), policy.rows_k * int(n_rows))
+    lo = max(1, min(max(policy.merge_min, policy.rows_lo * int(n_rows)), cap))
     fr, g = [0.0], 0
     while g < global_n:
         seg = int(min(cap, max(lo, (global_history + g) // max(1, policy.merge_k))))
@@ -163,6 +178,8 @@ class DistributedFit(object):
         self.session.set_interactions(None, np.ascontiguousarray(shard.row),
                                       np.ascontiguousarray(shard.col), shard.data, shard.data)
         self.session.build_positives(b1 - b0, n_items)
+        self.n_replicated_rows = n_items
+        self.merges, self.merge_bytes = 0, 0
         if world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
@@ -179,7 +196,9 @@ class DistributedFit(object):
         m = self.model
         n = self.shard.nnz
         history = int(getattr(m, "_trained_interactions", 0))  # interactions of ALL ranks so far
-        pos = segment_positions(merge_schedule(history, self.global_n, self.world, self.policy), n)
+        pos = segment_positions(merge_schedule(history, self.global_n, self.world, self.policy,
+                                               self.n_replicated_rows), n)
+        sparse = self.policy.sparse and m.learning_schedule == "adagrad"
         stats = []
         for j in range(len(pos) - 1):
             opts, _ = make_opts()
@@ -188,8 +207,14 @@ class DistributedFit(object):
             opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
             if pos[j + 1] > pos[j]:
                 self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts, slot=slot)
-            self.session.comm_merge(1, self.policy.mode_id())
+            if sparse:
+                self.merge_bytes += self.session.comm_merge_sparse(1, self.policy.mode_id(), self.policy.overlap)
+            else:
+                self.session.comm_merge(1, self.policy.mode_id())
+            self.merges += 1
             stats.append(opts)
+        if sparse:
+            self.session.comm_merge_flush()  # the last exchange lands before anything reads the tables
         m._trained_interactions = history + self.global_n
         return stats
 

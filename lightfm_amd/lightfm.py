@@ -119,6 +119,16 @@ class _Session(object):
     def comm_merge(self, sides=1, mode=0):
         N.check(N.lib().lfm_session_comm_merge(self.handle, sides, mode))
 
+    def comm_merge_sparse(self, sides=1, mode=0, overlap=True):
+        """The merge over the rows touched since the last one (lfm_session_comm_merge_sparse); returns the
+        bytes this rank handed to RCCL.  With overlap the result lands at the next merge or flush."""
+        nbytes = C.c_int64()
+        N.check(N.lib().lfm_session_comm_merge_sparse(self.handle, sides, mode, int(bool(overlap)), C.byref(nbytes)))
+        return nbytes.value
+
+    def comm_merge_flush(self):
+        N.check(N.lib().lfm_session_comm_merge_flush(self.handle))
+
     def merge_begin(self, sides=1):
         N.check(N.lib().lfm_session_merge_begin(self.handle, sides))
 
@@ -127,6 +137,16 @@ class _Session(object):
         """K sessions of this process on one device merged like K ranks (no RCCL)."""
         arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
         N.check(N.lib().lfm_sessions_merge_local(arr, len(sessions), sides, mode))
+
+    @staticmethod
+    def merge_local_sparse(sessions, sides=1, mode=0, overlap=False):
+        arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
+        N.check(N.lib().lfm_sessions_merge_local_sparse(arr, len(sessions), sides, mode, int(bool(overlap))))
+
+    @staticmethod
+    def merge_local_flush(sessions):
+        arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
+        N.check(N.lib().lfm_sessions_merge_local_flush(arr, len(sessions)))
 
     def comm_any(self, flag):
         return bool(N.check(N.lib().lfm_session_comm_any(self.handle, int(bool(flag)))))

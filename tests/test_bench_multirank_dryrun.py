@@ -75,7 +75,17 @@ def _worker(rank, world, port, out, argv):
             calls["merge"] += 1
             dist.barrier()  # a collective: all ranks must call it the same number of times
 
+        def comm_merge_sparse(self, sides, mode, overlap=True):
+            calls["merge"] += 1
+            self.pending = bool(overlap)
+            dist.barrier()
+            return 1000
+
+        def comm_merge_flush(self):
+            self.pending = False
+
         def check_finite(self):
+            assert not getattr(self, "pending", False), "an overlapped exchange must be flushed before the tables are read"
             return True
 
         def comm_any(self, flag):
@@ -130,7 +140,7 @@ def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling):
     timed = sum(g["calls"]["positions"] for g in got)  # warm-up + timed positions of both ranks
     assert 0 < line["value"] * line["ms_per_step"] * 1e-3 * line["steps"] <= timed
     assert "roofline" in line and line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
-    assert "GPUs" in line["config"]["parallelism"]
+    assert "GPUs" in line["config"]["parallelism"] and "rows touched" in line["config"]["parallelism"]
 
 
 def _fit_worker(rank, world, port, out):
@@ -172,14 +182,24 @@ def _fit_worker(rank, world, port, out):
                 log["merge"] += 1
                 dist.barrier()
 
+            def comm_merge_sparse(self, sides, mode, overlap=True):
+                log["merge"] += 1
+                self.pending = bool(overlap)
+                dist.barrier()
+                return 1000
+
+            def comm_merge_flush(self):
+                self.pending = False
+
             def check_finite(self):
+                assert not getattr(self, "pending", False), "flush before the finite check"
                 return True
 
             def comm_any(self, flag):
                 return bool(flag)
 
             def sync_to_host(self, struct):
-                pass
+                assert not getattr(self, "pending", False), "flush before the download"
 
             def close(self):
                 pass

@@ -262,37 +262,59 @@ def test_fit_with_device_and_host_positives_agree():
 
 # ------------------------------------------------------------ merge (local) ---
 
-@pytest.mark.parametrize("mode", ["sum", "mean", "adagrad"])
-def test_local_merge_matches_numpy(mode):
-    """lfm_sessions_merge_local over K = 3 sessions == the numpy restatement of the merge the RCCL
-    path performs (csrc/session.hip: merge_group)."""
+_MERGE_CASES = ([(m, f, "tile") for m in ("sum", "mean", "adagrad") for f in ("dense", "sparse", "overlap")]
+                + [("adagrad", f, c) for f in ("sparse", "overlap") for c in ("feat", "generic")])
+
+
+@pytest.mark.parametrize("mode,flavour,case", _MERGE_CASES)
+def test_local_merge_matches_numpy(mode, flavour, case):
+    """lfm_sessions_merge_local / _merge_local_sparse over K = 3 sessions == the numpy restatement of the
+    merge the RCCL path performs (csrc/session.hip: merge_group, merge_group_sparse).  flavour: the dense
+    all-reduce of whole tables; "sparse" = only the rows the epoch kernels marked dirty travel (a touched
+    row that was not marked would lose its delta here); "overlap" = the sparse merge with its application
+    deferred to the flush (the overlapped multi-GPU exchange).  case: which kernel family trains and marks --
+    the lane-group tile kernel (WARP, identity), the row-stream kernels (BPR over [identity | tags]: shared
+    rows), the generic kernels (d = 10)."""
     from lightfm_amd import LightFM, _native as N
     from lightfm_amd._lightfm_fast import make_opts
     from lightfm_amd.distributed import local_shard
     from lightfm_amd.lightfm import _Session
-    K, nu, ni, d = 3, 240, 160, 32
+    K, nu, ni = 3, 240, 160
+    d = 10 if case == "generic" else 32
+    loss = "bpr" if case == "feat" else "warp"
+    item_f = H.tag_features(ni, 12, 3, seed=1) if case == "feat" else None
+    n_feat = item_f.shape[1] if item_f is not None else ni
     coo = H.make_interactions(nu, ni, 9000, seed=12)
     models, sessions, structs = [], [], []
-    base = LightFM(no_components=d, loss="warp", random_state=2)
-    base._initialize(d, ni, nu)
+    base = LightFM(no_components=d, loss=loss, random_state=2)
+    base._initialize(d, n_feat, nu)
     start = {n: getattr(base, n).copy() for n in ("item_embeddings", "item_embedding_gradients", "item_biases",
                                                   "item_bias_gradients")}
     try:
         for r in range(K):
             shard, _ = local_shard(coo, r, K)
-            m = LightFM(no_components=d, loss="warp", random_state=2)
-            m._initialize(d, ni, nu)
-            s, st = _session(m, ni, nu, shard)
+            m = LightFM(no_components=d, loss=loss, random_state=2)
+            m._initialize(d, n_feat, nu)
+            s, st = _session(m, ni, nu, shard, item_f=item_f)
             s.merge_begin(1)
             s.device_shuffle(10 + r, 20 + r)
             o, _ = make_opts()
             o.history = 1 << 30
-            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([5 + r], np.uint32), o)
+            s.epoch(loss, 0.0, 0.0, 5, 10, np.array([5 + r], np.uint32), o)
+            assert int(o.kernel_used) == {"tile": 1, "feat": 2, "generic": 0}[case]
             s.sync_to_host(st)
             models.append({n: getattr(m, n).copy() for n in start})
             sessions.append(s)
             structs.append((m, st))
-        _Session.merge_local(sessions, 1, N.MERGE_MODES[mode])
+        if flavour == "dense":
+            _Session.merge_local(sessions, 1, N.MERGE_MODES[mode])
+        else:
+            _Session.merge_local_sparse(sessions, 1, N.MERGE_MODES[mode], overlap=(flavour == "overlap"))
+            if flavour == "overlap":  # nothing has landed yet: every replica still holds its own tables
+                for (m, st), s, mm in zip(structs, sessions, models):
+                    s.sync_to_host(st)
+                    np.testing.assert_array_equal(m.item_embeddings, mm["item_embeddings"])
+                _Session.merge_local_flush(sessions)
         for (m, st), s in zip(structs, sessions):
             s.sync_to_host(st)
     finally:
@@ -315,11 +337,76 @@ def test_local_merge_matches_numpy(mode):
         W = start["item_embeddings"] + rescaled(dW, dG, start["item_embedding_gradients"])
         b = start["item_biases"] + rescaled(db, dbG, start["item_bias_gradients"])
     assert any(np.abs(x).max() > 0 for x in dW)
+    touched = np.zeros(n_feat, bool)
+    for x in dG:
+        touched |= np.abs(x).max(axis=1) > 0
+    assert 0 < touched.sum()
     for m, _ in structs:  # every replica holds the merged item tables; user tables are untouched
         np.testing.assert_allclose(m.item_embeddings, W, rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(m.item_embedding_gradients, G, rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(m.item_biases, b, rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(m.item_bias_gradients, bG, rtol=2e-5, atol=1e-7)
+        # rows nobody touched are bit-for-bit what they were
+        np.testing.assert_array_equal(m.item_embeddings[~touched], start["item_embeddings"][~touched])
+    if flavour != "overlap":  # a merge that has landed leaves all replicas bit-identical
+        for m, _ in structs[1:]:
+            np.testing.assert_array_equal(m.item_embeddings, structs[0][0].item_embeddings)
+            np.testing.assert_array_equal(m.item_embedding_gradients, structs[0][0].item_embedding_gradients)
+
+
+def test_sparse_merge_carries_what_training_adds_while_the_exchange_is_in_flight():
+    """The overlapped exchange: a second segment trains between the merge call and the flush.  What it adds to
+    the local tables must survive the late application (table += sum - local delta) and travel with the NEXT
+    merge: after two merges and the final flush every replica holds start + all deltas of both segments."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import make_opts
+    from lightfm_amd.distributed import local_shard
+    from lightfm_amd.lightfm import _Session
+    K, nu, ni, d = 2, 200, 120, 16
+    coo = H.make_interactions(nu, ni, 6000, seed=7)
+    sessions, structs = [], []
+    base = LightFM(no_components=d, loss="warp", random_state=2)
+    base._initialize(d, ni, nu)
+    G0 = base.item_embedding_gradients.copy()
+    per_segment = []
+    try:
+        for r in range(K):
+            shard, _ = local_shard(coo, r, K)
+            m = LightFM(no_components=d, loss="warp", random_state=2)
+            m._initialize(d, ni, nu)
+            s, st = _session(m, ni, nu, shard)
+            s.merge_begin(1)
+            s.device_shuffle(3 + r, 4 + r)
+            sessions.append(s)
+            structs.append((m, st, shard.nnz))
+        seen = [G0.copy() for _ in range(K)]
+        for seg in range(2):
+            dG = []
+            for r, ((m, st, n), s) in enumerate(zip(structs, sessions)):
+                o, _ = make_opts()
+                o.history = 1 << 30
+                o.pos_begin, o.pos_end = (0, n // 2) if seg == 0 else (n // 2, n)
+                s.epoch("warp", 0.0, 0.0, 5, 10, np.array([9 + r], np.uint32), o)
+                s.sync_to_host(st)
+                # what THIS segment added locally (accumulators only grow; SUM mode keeps them additive)
+                dG.append(m.item_embedding_gradients - seen[r])
+            per_segment.append(dG)
+            _Session.merge_local_sparse(sessions, 1, N.MERGE_MODES["sum"], overlap=True)
+            for r, ((m, st, n), s) in enumerate(zip(structs, sessions)):
+                s.sync_to_host(st)
+                seen[r] = m.item_embedding_gradients.copy()  # segment 0's exchange lands inside the next merge call
+        _Session.merge_local_flush(sessions)
+        for (m, st, n), s in zip(structs, sessions):
+            s.sync_to_host(st)
+    finally:
+        for s in sessions:
+            s.close()
+    # accumulators: start + every rank's growth of both segments.  `seen` bookkeeping: after merge call 1 nothing
+    # has landed (seen = own table); after merge call 2 segment 0's sum has landed.
+    total = G0 + sum(per_segment[0]) + per_segment[1][0] + per_segment[1][1]
+    # per_segment[1][r] was measured against a table that did not yet hold the other rank's segment-0 growth
+    for m, _, _ in structs:
+        np.testing.assert_allclose(m.item_embedding_gradients, total, rtol=2e-5, atol=1e-6)
 
 
 def test_load_model_roundtrip():

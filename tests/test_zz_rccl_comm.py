@@ -45,6 +45,22 @@ def test_single_rank_communicator_roundtrip():
             s.sync_to_host(struct)
             np.testing.assert_allclose(m.item_embeddings, items, rtol=1e-6, atol=1e-7)
             items = m.item_embeddings.copy()
+        # the sparse merge through RCCL (byte-map all-reduce MAX, packed all-reduces on the communication stream):
+        # over ONE rank it is the identity too, synchronous or overlapped
+        for e, (mode, overlap) in enumerate([(N.MERGE_SUM, False), (N.MERGE_ADAGRAD, False), (N.MERGE_ADAGRAD, True),
+                                             (N.MERGE_MEAN, True)]):
+            s.device_shuffle(50 + e, 9)
+            opts, _ = make_opts()
+            opts.history = 1 << 30
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([40 + e], np.uint32), opts)
+            s.sync_to_host(struct)
+            items, acc = m.item_embeddings.copy(), m.item_embedding_gradients.copy()
+            nbytes = s.comm_merge_sparse(1, mode, overlap)
+            assert nbytes >= 200  # the byte map at least
+            s.comm_merge_flush()
+            s.sync_to_host(struct)
+            np.testing.assert_allclose(m.item_embeddings, items, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(m.item_embedding_gradients, acc, rtol=1e-6, atol=1e-7)
         assert s.comm_any(False) is False and s.comm_any(True) is True
     finally:
         s.close()

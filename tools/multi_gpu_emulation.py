@@ -1,13 +1,19 @@
 """Measures the N-GPU training semantics on ONE GPU: K device-resident sessions (one per emulated
 rank, each with its row shard of the interactions, its own user rows and a replica of the item
 tables) run the very schedule lightfm_amd/distributed.py runs on K GPUs -- segments of the epoch
-with a merge of the item tables after each -- with the merge done by lfm_sessions_merge_local
-(the arithmetic of the RCCL path, csrc/session.hip: merge_group, without RCCL).  Reports
-precision@10 of the merged model against one replica (K = 1) on ML-20M-shaped data.
+with a merge of the item tables after each -- with the merge done by lfm_sessions_merge_local /
+lfm_sessions_merge_local_sparse (the arithmetic of the RCCL path, csrc/session.hip: merge_group /
+merge_group_sparse, without RCCL; "overlap" applies every exchange one merge late, as the overlapped
+multi-GPU exchange does).  Reports precision@10 of the merged model against one replica (K = 1).
 
     python tools/multi_gpu_emulation.py CONFIG [CONFIG ...]
-      CONFIG = K:mode:merge_k:merge_min:merge_max      e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0
-    env: EMU_EPOCHS (5), EMU_SEEDS (1,2,3), EMU_EVAL_USERS (4000), EMU_SCALE (1.0)
+      CONFIG = K:mode:merge_k:merge_min:merge_max[:flavour]   flavour = dense | sparse | overlap (default)
+                e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0:dense
+    env: EMU_SHAPE  c2 (ML-20M shape, WARP d=64, identity; default) | c3 (ML-20M shape, BPR d=128, item
+                    features [identity | 8 tags of 1128]: shared rows in the replicated tables) |
+                    c4s (a 1/8-scale C4: 156 k users x 625 k items x 62.5 M interactions with latent
+                    structure, WARP d=64: the table-scaled merge intervals of MergePolicy.rows_k)
+         EMU_EPOCHS (5), EMU_SEEDS (1,2,3), EMU_EVAL_USERS (4000), EMU_SCALE (1.0)
 """
 import os
 import sys
@@ -27,10 +33,15 @@ epochs = int(os.environ.get("EMU_EPOCHS", "5"))
 seeds = [int(x) for x in os.environ.get("EMU_SEEDS", "1,2,3").split(",")]
 n_eval = int(os.environ.get("EMU_EVAL_USERS", "4000"))
 scale = float(os.environ.get("EMU_SCALE", "1.0"))
-D = 64
+shape = os.environ.get("EMU_SHAPE", "c2")
+D, LOSS = (128, "bpr") if shape == "c3" else (64, "warp")
 
 t0 = time.time()
-data = synthetic.named("ml-20m", scale=scale)
+if shape == "c4s":
+    data = synthetic.make_interactions(156_250, 625_000, int(62_500_000 * scale), seed=42, n_clusters=256)
+else:
+    data = synthetic.named("ml-20m", scale=scale)
+feats = synthetic.tag_item_features(data.shape[1]) if shape == "c3" else None
 train, test = synthetic.train_test_split(data, 0.1, seed=1)
 users = np.sort(np.random.RandomState(0).choice(data.shape[0], size=n_eval, replace=False))
 mask = np.zeros(data.shape[0], bool)
@@ -43,11 +54,14 @@ n_users, n_items = data.shape
 print("data %s train %d (%.0fs)" % (data.shape, train.nnz, time.time() - t0), flush=True)
 
 
-def run(K, policy, seed):
+n_item_feat = feats.shape[1] if feats is not None else n_items
+
+
+def run(K, policy, seed, flavour):
     rng = np.random.RandomState(seed)
-    model = LightFM(no_components=D, loss="warp", random_state=seed)
-    model._initialize(D, n_items, n_users)
-    item_f = CSRMatrix(sp.identity(n_items, dtype=np.float32, format="csr"))
+    model = LightFM(no_components=D, loss=LOSS, random_state=seed)
+    model._initialize(D, n_item_feat, n_users)
+    item_f = CSRMatrix(feats if feats is not None else sp.identity(n_items, dtype=np.float32, format="csr"))
     sessions, structs, shards = [], [], []
     bounds = None
     for r in range(K):
@@ -73,7 +87,7 @@ def run(K, policy, seed):
             for s in sessions:
                 s.device_shuffle(int(rng.randint(1 << 30)), int(rng.randint(1 << 30)))
             sd = [np.array([rng.randint(1 << 30)], np.uint32) for _ in sessions]
-            fr = merge_schedule(history, train.nnz, K, policy)
+            fr = merge_schedule(history, train.nnz, K, policy, n_item_feat)
             pos = [segment_positions(fr, sh.nnz) for sh in shards]
             for j in range(len(fr) - 1):
                 seg_ms = 0.0
@@ -82,12 +96,17 @@ def run(K, policy, seed):
                     opts.history = (history + int(round(train.nnz * fr[j]))) // K
                     opts.pos_begin, opts.pos_end = int(pos[r][j]), int(pos[r][j + 1])
                     if pos[r][j + 1] > pos[r][j]:
-                        s.epoch("warp", 0.0, 0.0, 5, 10, sd[r], opts)
+                        s.epoch(LOSS, 0.0, 0.0, 5, 10, sd[r], opts)
                         seg_ms = max(seg_ms, float(opts.kernel_ms))
                 kernel_ms += seg_ms  # ranks run concurrently on real hardware
                 if K > 1:
-                    _Session.merge_local(sessions, 1, policy.mode_id())
+                    if flavour == "dense":
+                        _Session.merge_local(sessions, 1, policy.mode_id())
+                    else:
+                        _Session.merge_local_sparse(sessions, 1, policy.mode_id(), overlap=(flavour == "overlap"))
                 merges += 1
+            if K > 1 and flavour != "dense":
+                _Session.merge_local_flush(sessions)  # as DistributedFit.run_epoch does at the end of an epoch
             history += train.nnz
         for r, s in enumerate(sessions):
             s.sync_to_host(structs[r])
@@ -97,19 +116,21 @@ def run(K, policy, seed):
     finally:
         for s in sessions:
             s.close()
-    p = precision_at_k(model, test_sub, train_interactions=train_csr, k=10).mean()
+    p = precision_at_k(model, test_sub, train_interactions=train_csr, k=10, item_features=feats).mean()
     return p, merges / float(epochs), kernel_ms / epochs
 
 
 for spec in sys.argv[1:]:
-    K, mode, mk, mmin, mmax = spec.split(":")
+    parts = spec.split(":")
+    K, mode, mk, mmin, mmax = parts[:5]
+    flavour = parts[5] if len(parts) > 5 else "overlap"
     policy = MergePolicy(merge_k=int(mk), merge_min=int(mmin), merge_max=int(mmax), mode=mode)
     res = []
     t = time.time()
     for seed in seeds:
-        p, mpe, kms = run(int(K), policy, seed)
+        p, mpe, kms = run(int(K), policy, seed, flavour)
         res.append(p)
         print("  %s seed %d: p@10 test %.4f  (%.1f merges/epoch, max-over-ranks kernel %.1f ms/epoch)"
               % (spec, seed, p, mpe, kms), flush=True)
-    print("K=%s mode=%s merge_k=%s min=%s max=%s: p@10 test %.4f (std %.4f)  %.1f merges/epoch  [%.0fs]"
-          % (K, mode, mk, mmin, mmax, np.mean(res), np.std(res), mpe, time.time() - t), flush=True)
+    print("%s K=%s mode=%s merge_k=%s min=%s max=%s %s: p@10 test %.4f (std %.4f)  %.1f merges/epoch  [%.0fs]"
+          % (shape, K, mode, mk, mmin, mmax, flavour, np.mean(res), np.std(res), mpe, time.time() - t), flush=True)
