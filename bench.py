@@ -197,7 +197,7 @@ def committed_traffic(config_name, kernel_name):
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         e = table.get(config_name)
-        if e and e.get("kernel") == kernel_name:
+        if e and kernel_name in e.get("kernel", ""):
             return float(e["hbm_bytes_per_launch"]), e.get("source")
         if e:
             return None, "profiles/traffic.json holds %s for this config, this run's kernel is %s" % (e.get("kernel"), kernel_name)
@@ -422,7 +422,8 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
             "true" if reg else "false")
     elif used == 2:
-        kernel_name = "fit_feat_kernel<%s, %d, false, %s>" % (loss, 1 if d <= 64 else 2, "true" if reg else "false")
+        kernel_name = "fit_feat_kernel<%d, %d, false, %s>" % (N.LOSS_IDS[loss], 1 if d <= 64 else 2,
+                                                              "true" if reg else "false")  # <loss id, NC, TIMED, REG>
     else:
         kernel_name = "fit_%s_kernel (generic)" % loss.replace("-", "_")
     achieved = alg / kernel_s / 1e9

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "liblfm_hip.so")
+# LIGHTFM_AMD_LIB: another build of the library (A/B measurements of kernel variants, tools/ab_build.sh)
+LIB_PATH = os.environ.get("LIGHTFM_AMD_LIB") or os.path.join(HERE, "_lib", "liblfm_hip.so")
 
 F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)

@@ -23,6 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 if os.environ.get("LFM_BUILD_DEBUG"):  # line tables + symbols for rocgdb (same code generation)
     FLAGS.append("-g")
+# A/B builds: LFM_BUILD_DEFINES="-DX -DY" LFM_BUILD_DIR=<dir under lightfm_amd/> python -m lightfm_amd.build
+FLAGS += os.environ.get("LFM_BUILD_DEFINES", "").split()
+if os.environ.get("LFM_BUILD_DIR"):
+    OUT_DIR = os.path.join(HERE, os.environ["LFM_BUILD_DIR"])
+    LIB = os.path.join(OUT_DIR, "liblfm_hip.so")
 
 
 def _stale(target, deps):

@@ -43,15 +43,7 @@ struct DModel {
     float lr, rho, eps;
     int32_t max_sampled;
     double *scales;  // device [2]: item_scale, user_scale (PYX:214-215)
-    unsigned char *dirty[2];  // multi-GPU: byte per feature row of a side, set to 1 by every update of the row
-                              // (the rows the next merge exchanges, session.hip: merge_group_sparse); or nullptr
 };
-
-// Multi-GPU dirty-row tracking: plain byte stores of the same value race benignly.
-__device__ __forceinline__ void mark_dirty(const DModel &m, int side, int row)
-{
-    if (m.dirty[side]) m.dirty[side][row] = 1;
-}
 
 struct FitArgs {
     DCsr itf, usf, pos;
@@ -453,11 +445,9 @@ __device__ __forceinline__ void update_row(const DCsr &f, int row, int side, con
         int feat = f.identity ? k : uni(f.indices[k]);
         double w = f.identity ? 1.0 : (double)unif(f.data[k]);
         double lr = 0.0;
-        if (lane == 0) {
+        if (lane == 0)
             lr = cell_update(m.b[side] + feat, m.bG[side] + feat, m.bM[side] + feat, w, gbias, h,
                              alpha, atomic);
-            mark_dirty(m, side, feat);
-        }
         lr_bias += read_laned(lr, 0);
     }
     // then every coordinate (PYX:602-638); lane owns its coordinates
@@ -506,11 +496,9 @@ __device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int s
         }
         // biases (PYX:571-599): lane j owns entry j
         double lrb = 0.0;
-        if (lane < cnt) {
+        if (lane < cnt)
             lrb = cell_update(m.b[side] + myfeat, m.bG[side] + myfeat, m.bM[side] + myfeat, (double)myw,
                               gbias, h, alpha, atomic);
-            mark_dirty(m, side, myfeat);
-        }
         if (alpha != 0.0) lr_bias += wave_sum(lrb);
         // coordinates (PYX:602-638): lane owns its coordinates, 4 entries in flight
         for (int j0 = 0; j0 < cnt; j0 += 4) {
@@ -664,7 +652,6 @@ __device__ __forceinline__ double rows_update_parallel(const DModel &m, const Ro
                 put(m.b[s] + ft, nW[r], oW[r]);
                 put(m.bG[s] + ft, nG[r], oG[r]);
                 if (h.adadelta) put(m.bM[s] + ft, nM[r], oM[r]);
-                mark_dirty(m, s, ft);
             }
         }
     }
@@ -1059,7 +1046,6 @@ __device__ __forceinline__ void warp_update_identity(double loss, const FitArgs 
         const double gb = lane == 0 ? -loss : loss;
         cell_math(obW, obG, obM, 1.0, gb, h, 0.0, nW, nG, nM, lr);
         publish_cell(bW, bG, bM, obW, obG, obM, nW, nG, nM, 1.0, gb, h, 0.0, um);
-        mark_dirty(a.m, side, brow);
     }
 }
 

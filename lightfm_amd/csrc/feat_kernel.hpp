@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if constexpr (REG) lr_sum += lr;
                     publish(bp, nW, obW, um);
                     publish(bgp, nG, obG, um);
-                    mark_dirty(a.m, e.eside, e.feat);
                 }
             }
             stamp(6);

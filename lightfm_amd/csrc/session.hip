@@ -376,10 +376,9 @@ struct lfm_session {
     DBuf<float> snap[2][6];     // the tables at the start of the current merge interval
     int snap_sides = 0;         // bit 0 item, bit 1 user: which sides have a valid snapshot
     DBuf<float> scratch[2];     // merge temporaries (ADAGRAD mode: this rank's dG; local reduce: sums)
-    // sparse merge (merge_group_sparse): rows touched since the last merge, two byte maps per side (the
-    // kernels of the segment after a merge mark the other one), and the exchange that may still be in flight
-    DBuf<unsigned char> dirty[2][2];
-    int dirty_cur[2] = {0, 0};
+    // sparse merge (merge_group_sparse): the rows that differ from the interval's snapshot (a byte map per
+    // side, filled at merge time), and the exchange that may still be in flight
+    DBuf<unsigned char> dirty[2];
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     struct PendingMerge {
@@ -433,7 +432,6 @@ struct lfm_session {
         m.eps = eps;
         m.max_sampled = max_sampled;
         m.scales = scales.p;
-        for (int s = 0; s < 2; ++s) m.dirty[s] = dirty[s][dirty_cur[s]].p;  // nullptr unless a merge interval is open
         return m;
     }
 };
@@ -816,7 +814,6 @@ static int snapshot_side(lfm_session *s, int side)
     return LFM_OK;
 }
 
-static int enable_dirty_tracking(lfm_session *s, int side);
 static int complete_pending(lfm_session *s, bool exact = false);
 
 extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
@@ -827,7 +824,7 @@ extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
     for (int side = 0; side < 2; ++side)
         if ((sides >> side) & 1) {
             LFM_TRY(snapshot_side(s, side));
-            if (!s->adadelta) LFM_TRY(enable_dirty_tracking(s, side));
+            if (!s->adadelta) LFM_TRY(s->dirty[side].alloc((size_t)s->n_feat[side]));
         }
     if (!s->comm_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
@@ -857,10 +854,6 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
     for (int i = 0; i < k; ++i) {  // a sparse exchange still in flight lands first; the dense merge covers every row
         LFM_TRY(complete_pending(ss[i]));
         HIP_TRY(hipStreamSynchronize(ss[i]->stream));
-        for (int side = 0; side < 2; ++side)
-            for (int m = 0; m < 2; ++m)
-                if (((sides >> side) & 1) && ss[i]->dirty[side][m].p)
-                    HIP_TRY(hipMemsetAsync(ss[i]->dirty[side][m].p, 0, ss[i]->dirty[side][m].n, st));
     }
     auto reduce_kinds = [&](int side, std::initializer_list<int> kinds) -> int {
         if (use_rccl) {
@@ -940,7 +933,10 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
 // The dense merge above moves every replicated table through the fabric six times and through xGMI once per
 // merge, whatever the interval touched: 2.6 GB for the 5 M-row item tables of BASELINE config C4, against
 // ~1 ms of training per 2^20 interactions.  This one is proportional to what changed:
-//   1. every update marks its rows in a byte map (device.hpp: mark_dirty; two maps per side, ping-pong);
+//   1. the rows whose W, G, b or bG differ from the interval's snapshot are flagged in a byte map (one streaming
+//      read of the tables at merge time.  Marking the rows from inside the epoch kernels was measured first: one
+//      predicated byte store per updated row cost the C2 tile kernel 6 %, 0.99 against 1.05 G interactions/s in
+//      an A/B of two builds on one box -- on single-GPU runs that never merge);
 //   2. the ranks' maps are OR-ed (all-reduce MAX over bytes: n_feat bytes) -- every rank then holds the same
 //      union U of touched rows -- and compacted to an ascending id list (csr_build.hip: compact_flagged_rows);
 //   3. each rank packs its deltas (table - snapshot) of the rows of U into dense [|U|, d] buffers;
@@ -952,6 +948,21 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
 // (or lfm_session_comm_merge_flush): the exchange of segment j overlaps the kernels of segment j + 1, at the
 // price of the other ranks' updates arriving one segment late.  The arithmetic does not depend on it: whatever
 // the local table gained between pack and apply stays in (table - snapshot) for the next merge.
+// flags[r] = 1 if row r of (W, G) or its (b, bG) cell differs from the snapshot; one wavefront per row
+__global__ void detect_dirty_kernel(const float *W, const float *sW, const float *G, const float *sG, const float *b, const float *sb,
+                                    const float *bG, const float *sbG, int64_t rows, int d, unsigned char *flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = w0; r < rows; r += nw) {
+        bool diff = false;
+        const size_t base = (size_t)r * d;
+        for (int c = lane; c < d; c += 64) diff |= (W[base + c] != sW[base + c]) | (G[base + c] != sG[base + c]);
+        if (lane == 0) diff |= (b[r] != sb[r]) | (bG[r] != sbG[r]);
+        const unsigned long long any = __ballot(diff);
+        if (lane == 0) flags[r] = any ? 1 : 0;
+    }
+}
 __global__ void pack_delta_kernel(const float *tab, const float *snap, const int32_t *ids, int64_t n_u, int d, float *loc, float *sum)
 {
     const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
@@ -1006,16 +1017,6 @@ __global__ void local_or_kernel(BytePack xs, int k, int64_t n)
 
 static const int SPARSE_KINDS[4] = {0, 1, 3, 4};  // W, G, b, bG (adagrad models)
 
-static int enable_dirty_tracking(lfm_session *s, int side)
-{
-    for (int m = 0; m < 2; ++m) {
-        if (s->dirty[side][m].p && s->dirty[side][m].n == (size_t)s->n_feat[side]) continue;
-        LFM_TRY(s->dirty[side][m].alloc((size_t)s->n_feat[side]));
-        if (s->n_feat[side]) HIP_TRY(hipMemsetAsync(s->dirty[side][m].p, 0, (size_t)s->n_feat[side], s->stream));
-    }
-    return LFM_OK;
-}
-
 // step 5 of a merge whose exchange may still be in flight
 static int complete_pending(lfm_session *s, bool exact)
 {
@@ -1065,32 +1066,36 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         if (!((sides >> side) & 1)) continue;
         const int64_t nf = s0->n_feat[side];
         for (int i = 0; i < k; ++i) {
-            if (!((ss[i]->snap_sides >> side) & 1) || !ss[i]->dirty[side][0].p)
+            if (!((ss[i]->snap_sides >> side) & 1) || !ss[i]->dirty[side].p)
                 return fail(LFM_EINVAL, "sparse merge without lfm_session_merge_begin");
             if (ss[i]->n_feat[side] != nf || ss[i]->d != s0->d) return fail(LFM_EINVAL, "sessions differ in shape");
         }
         if (nf == 0) continue;
+        // 1. rows that differ from the snapshot
+        for (int i = 0; i < k; ++i) {
+            lfm_session *s = ss[i];
+            const int dgrid = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (nf + 3) / 4));
+            detect_dirty_kernel<<<dgrid, 256, 0, st>>>(s->tab[side][0].p, s->snap[side][0].p, s->tab[side][1].p, s->snap[side][1].p,
+                                                       s->tab[side][3].p, s->snap[side][3].p, s->tab[side][4].p, s->snap[side][4].p,
+                                                       nf, s->d, s->dirty[side].p);
+        }
         // 2. union of the maps
-        const int cur = s0->dirty_cur[side];
         if (use_rccl) {
-            NCCL_TRY(r->AllReduce(s0->dirty[side][cur].p, s0->dirty[side][cur].p, (size_t)nf, ncclUint8, ncclMax, s0->comm, st));
+            NCCL_TRY(r->AllReduce(s0->dirty[side].p, s0->dirty[side].p, (size_t)nf, ncclUint8, ncclMax, s0->comm, st));
             bytes += nf;
         } else if (k > 1) {
             BytePack pk;
-            for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->dirty[side][ss[i]->dirty_cur[side]].p;
+            for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->dirty[side].p;
             local_or_kernel<<<grid_for(nf), 256, 0, st>>>(pk, k, nf);
         }
         // ... compacted (identical on every rank: same map, ascending order)
         for (int i = 0; i < k; ++i) {
             lfm_session *s = ss[i];
-            const int c = s->dirty_cur[side];
             LFM_TRY(s->pend.ids[side].reserve((size_t)nf));
             int64_t n_u = 0;
-            hipError_t e = compact_flagged_rows(s->dirty[side][c].p, nf, s->pend.ids[side].p, &n_u, st);
+            hipError_t e = compact_flagged_rows(s->dirty[side].p, nf, s->pend.ids[side].p, &n_u, st);
             if (e != hipSuccess) return fail(LFM_ENODEV, std::string("compact_flagged_rows: ") + hipGetErrorString(e));
             s->pend.n_u[side] = n_u;
-            HIP_TRY(hipMemsetAsync(s->dirty[side][c].p, 0, (size_t)nf, st));  // ready for the interval after next
-            s->dirty_cur[side] = c ^ 1;                                       // the next segment marks the other map
             // 3. pack
             for (int q = 0; q < 4 && n_u; ++q) {
                 const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;

@@ -681,7 +681,6 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
                             publish_cell(bWp + brow, bGp + brow, bMp + brow, obW[gg], obG[gg], ooM, bnW, bnG, bnM, 1.0,
                                          lane == 0 ? -loss : loss, h, balpha, um);
-                            mark_dirty(a.m, lane == 2 ? 1 : 0, brow);
                         }
                     }
                 }

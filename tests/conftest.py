@@ -19,3 +19,17 @@ def ref_strict():
     if not oracle.ref_available("strict"):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     return oracle.ref_module("strict")
+
+
+@pytest.fixture(autouse=True)
+def _restore_backend_options():
+    """Backend options a test sets (mode, kernel selectors, ...) never leak into the next test."""
+    try:
+        from lightfm_amd.options import options
+    except Exception:
+        yield
+        return
+    saved = dict(options.__dict__)
+    yield
+    options.__dict__.clear()
+    options.__dict__.update(saved)

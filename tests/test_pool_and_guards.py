@@ -57,7 +57,7 @@ def test_shuffle_entry_out_of_range_is_an_error_not_a_gpu_fault(family):
     coo = H.make_interactions(nu, ni, 9000, seed=6)
     loss = "bpr" if family == "row-stream" else "warp"
     if family == "generic":
-        options.set(warp_kernel=1)
+        options.set(warp_kernel=1, feat_kernel=1)
     if family == "serial":
         options.set(mode="serial")
     m = LightFM(no_components=32, loss=loss, random_state=1)

@@ -7,8 +7,10 @@ merge_group_sparse, without RCCL; "overlap" applies every exchange one merge lat
 multi-GPU exchange does).  Reports precision@10 of the merged model against one replica (K = 1).
 
     python tools/multi_gpu_emulation.py CONFIG [CONFIG ...]
-      CONFIG = K:mode:merge_k:merge_min:merge_max[:flavour]   flavour = dense | sparse | overlap (default)
-                e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0:dense
+      CONFIG = K:mode:merge_k:merge_min:merge_max[:flavour[:rows_k]]
+                flavour = dense | sparse | overlap (default) | late<E> (sparse, overlapped only once the model has
+                seen E epochs: late1, late0.5)        rows_k = MergePolicy.rows_k (default 64)
+                e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0:dense   8:adagrad:4:16384:0:late1:16
     env: EMU_SHAPE  c2 (ML-20M shape, WARP d=64, identity; default) | c3 (ML-20M shape, BPR d=128, item
                     features [identity | 8 tags of 1128]: shared rows in the replicated tables) |
                     c4s (a 1/8-scale C4: 156 k users x 625 k items x 62.5 M interactions with latent
@@ -103,7 +105,9 @@ def run(K, policy, seed, flavour):
                     if flavour == "dense":
                         _Session.merge_local(sessions, 1, policy.mode_id())
                     else:
-                        _Session.merge_local_sparse(sessions, 1, policy.mode_id(), overlap=(flavour == "overlap"))
+                        seen = history + train.nnz * fr[j + 1]
+                        ov = flavour == "overlap" or (flavour.startswith("late") and seen >= float(flavour[4:]) * train.nnz)
+                        _Session.merge_local_sparse(sessions, 1, policy.mode_id(), overlap=ov)
                 merges += 1
             if K > 1 and flavour != "dense":
                 _Session.merge_local_flush(sessions)  # as DistributedFit.run_epoch does at the end of an epoch
@@ -125,6 +129,8 @@ for spec in sys.argv[1:]:
     K, mode, mk, mmin, mmax = parts[:5]
     flavour = parts[5] if len(parts) > 5 else "overlap"
     policy = MergePolicy(merge_k=int(mk), merge_min=int(mmin), merge_max=int(mmax), mode=mode)
+    if len(parts) > 6:
+        policy.rows_k = int(parts[6])
     res = []
     t = time.time()
     for seed in seeds:
@@ -132,5 +138,5 @@ for spec in sys.argv[1:]:
         res.append(p)
         print("  %s seed %d: p@10 test %.4f  (%.1f merges/epoch, max-over-ranks kernel %.1f ms/epoch)"
               % (spec, seed, p, mpe, kms), flush=True)
-    print("%s K=%s mode=%s merge_k=%s min=%s max=%s %s: p@10 test %.4f (std %.4f)  %.1f merges/epoch  [%.0fs]"
-          % (shape, K, mode, mk, mmin, mmax, flavour, np.mean(res), np.std(res), mpe, time.time() - t), flush=True)
+    print("%s K=%s mode=%s merge_k=%s min=%s max=%s %s rows_k=%d: p@10 test %.4f (std %.4f)  %.1f merges/epoch  [%.0fs]"
+          % (shape, K, mode, mk, mmin, mmax, flavour, policy.rows_k, np.mean(res), np.std(res), mpe, time.time() - t), flush=True)

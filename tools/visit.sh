@@ -117,6 +117,61 @@ except Exception as e:
 PY
   done
   ;;
+r3c)
+  # suite, the driver's default bench line (with the extra_configs legs), rocprofv3 trace + PMC of c2 / c3 / c4shard
+  timeout -k 5 1200 $PYT tests -m gpu -x -q -s > $OUT/suite_1.log 2>&1
+  echo "suite: exit $?  $(grep -aE ' passed| failed' $OUT/suite_1.log | tail -1)"; summ $OUT/suite_1.log 12
+  grep -a "per side, fixed" $OUT/suite_1.log | cut -c1-200
+  ( time timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2>&1 | grep real; echo "bench default exit $?"
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_default.json"))
+    def show(n, v, r):
+        print("  %-8s %8.1f M/s  frac %.3f  atomic %.3f  launch %.3f ms  U %.3f  %s" % (n, v / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r["kernel"]))
+    show("c2", d["value"], d["roofline"])
+    for e in d.get("extra_configs", []):
+        if "error" in e: print("  ", e)
+        else: show(e["name"], e["value"], e["roofline"])
+    print("  quality", d.get("quality"))
+    print("  cpu", (d.get("cpu_baseline") or {}).get("value"), "fit", (d.get("end_to_end_fit") or {}).get("value"))
+except Exception as e:
+    print("  no result:", e)
+PY
+  tail -5 $OUT/bench_default.err | cut -c1-300
+  for cfg in c2 c3 c4shard; do bash tools/profile2.sh r03_$cfg --config $cfg; done
+  cp $R/profiles/r03_* $OUT/ 2>/dev/null
+  ;;
+emu)
+  # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
+  SH=$1; EP=$2; SD=$3; shift 3
+  EMU_SHAPE=$SH EMU_EPOCHS=$EP EMU_SEEDS=$SD timeout 1500 python tools/multi_gpu_emulation.py "$@" > $OUT/emu_${SH}_$$.txt 2>&1
+  grep -a "K=" $OUT/emu_${SH}_$$.txt; tail -2 $OUT/emu_${SH}_$$.txt | grep -av "K=" | cut -c1-300
+  ;;
+ab)
+  # A/B of two builds of the library on the same box: tools/visit.sh ab <dir under lightfm_amd/> [bench args]
+  ALT=$1; shift
+  S="--no-cpu-baseline --no-quality --no-fit --steps 10 --warmup 2 ${*:---config c2}"
+  for i in 1 2; do for lib in _lib $ALT; do
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 300 python bench.py $S > $OUT/bench_${lib}_$i.json 2> $OUT/bench_${lib}_$i.err
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_${lib}_$i.json")); r = d["roofline"]
+    print("  %-14s run $i: %8.1f M/s  frac %.3f  launch %.3f ms  U %.3f" % ("$lib", d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"]))
+except Exception as e:
+    print("  $lib run $i: no result:", e)
+PY
+  done; done
+  ;;
+r3d)
+  # N-GPU semantics on one GPU: the sparse overlapped merge at the shipped intervals (C2, C3, scaled C4)
+  export EMU_SEEDS=${EMU_SEEDS:-1,2,3}
+  EMU_SHAPE=c2 timeout 900 python tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:overlap 8:adagrad:4:16384:0:sparse > $OUT/emu_c2.txt 2>&1; grep -a "K=" $OUT/emu_c2.txt
+  EMU_SHAPE=c3 EMU_EPOCHS=3 timeout 900 python tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:overlap > $OUT/emu_c3.txt 2>&1; grep -a "K=" $OUT/emu_c3.txt
+  EMU_SHAPE=c4s EMU_EPOCHS=3 EMU_SEEDS=1,2 timeout 1200 python tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:overlap > $OUT/emu_c4s.txt 2>&1; grep -a "K=" $OUT/emu_c4s.txt
+  tail -3 $OUT/emu_c4s.txt | cut -c1-300
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
