@@ -55,6 +55,7 @@ def test_single_rank_communicator_roundtrip():
             s.epoch("warp", 0.0, 0.0, 5, 10, np.array([40 + e], np.uint32), opts)
             s.sync_to_host(struct)
             items, acc = m.item_embeddings.copy(), m.item_embedding_gradients.copy()
+            trained = m.user_embeddings.copy()
             nbytes = s.comm_merge_sparse(1, mode, overlap)
             assert nbytes >= 200  # the byte map at least
             s.comm_merge_flush()
