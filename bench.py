@@ -229,6 +229,8 @@ def parse_args():
     ap.add_argument("--merge-k", type=int, default=None)
     ap.add_argument("--merge-max", type=int, default=None)
     ap.add_argument("--merge-dense", action="store_true", help="N > 1: the dense synchronous merge of round 2")
+    ap.add_argument("--merge-overlap", action="store_true",
+                    help="N > 1: sparse merges overlap the next segment (land one merge late; costs precision@10)")
     for knob in KNOBS:
         ap.add_argument("--" + knob.replace("_", "-"), type=int, default=None, help="backend option (tuning)")
     return ap.parse_args()
@@ -257,7 +259,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     (contract fields + roofline of this config, the pieces the reporting-only legs need)."""
     from lightfm_amd import _native as N
     from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
-    from lightfm_amd.distributed import MergePolicy, merge_schedule, segment_positions
+    from lightfm_amd.distributed import MergePolicy, hot_rows, merge_plan, segment_positions
     from lightfm_amd.lightfm import LightFM, _Session
     from lightfm_amd.options import options
     args, rank, world, dist, log = env.args, env.rank, env.world, env.dist, env.log
@@ -272,6 +274,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         policy.merge_k = args.merge_k
     if args.merge_max:
         policy.merge_max = args.merge_max
+    policy.overlap = bool(args.merge_overlap)
     dev_name, cus, hbm = N.device_info(env.local_rank)
 
     t0 = time.time()
@@ -320,6 +323,9 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
         dist.broadcast(t, src=0)
         session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()), N.UNIQUE_ID_BYTES), rank, world)
+    hot = hot_rows(feats, policy.hot_nnz) if world > 1 else []
+    if len(hot):  # shared feature rows (C3's tags): merged at the short cadence between the full merges
+        session.set_hot_rows(0, hot)
     log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))
 
     n_local = train.nnz
@@ -339,7 +345,8 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
             session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
             all_stats.append(opts)
         else:
-            pos = segment_positions(merge_schedule(state["history"], global_n, world, policy, n_repl_rows), n_local)
+            fr, kinds = merge_plan(state["history"], global_n, world, policy, n_repl_rows, len(hot) > 0)
+            pos = segment_positions(fr, n_local)
             for j in range(len(pos) - 1):
                 opts, _ = make_opts()
                 opts.history = (state["history"] + int(round(global_n * pos[j] / max(1, n_local)))) // world
@@ -348,9 +355,12 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
                     session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
                     all_stats.append(opts)
                 if args.merge_dense:
-                    session.comm_merge(1, policy.mode_id())
+                    if kinds[j] == "full":
+                        session.comm_merge(1, policy.mode_id())
+                elif kinds[j] == "hot":
+                    state["merge_bytes"] += session.comm_merge_hot(1, policy.mode_id(), policy.overlap)
                 else:
-                    state["merge_bytes"] += session.comm_merge_sparse(1, policy.mode_id(), overlap=True)
+                    state["merge_bytes"] += session.comm_merge_sparse(1, policy.mode_id(), policy.overlap)
                 state["merges"] += 1
             if not args.merge_dense:
                 session.comm_merge_flush()
@@ -471,8 +481,10 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
            % (scaling, world,
               "one COO row-sharded by user" if scaling == "strong" else "every rank its own full-size row shard",
               policy.mode, "dense all-reduce, synchronous" if args.merge_dense else
-              "all-reduce over the compacted union of the rows touched since the last merge, overlapped with the "
-              "next segment", (state["merges"] - merges0) / float(n_epochs),
+              "all-reduce over the compacted union of the rows touched since the last merge%s%s"
+              % (", overlapped with the next segment" if policy.overlap else ", synchronous",
+                 "; %d hot rows merged every %d interactions" % (len(hot), world << 17) if len(hot) else ""),
+              (state["merges"] - merges0) / float(n_epochs),
               (state["merge_bytes"] - mbytes0) / 1e6 / max(1, state["merges"] - merges0)))
     result = {
         "value": total_pos / elapsed, "unit": "interactions/s", "steps": steps, "warmup": warmup,

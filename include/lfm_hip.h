@@ -302,6 +302,15 @@ int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode);
  * for adadelta: use lfm_session_comm_merge).  Same modes and the same arithmetic as the dense merge. */
 int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes);
 int lfm_session_comm_merge_flush(lfm_session *s);
+/* HOT rows: feature rows that many interactions of every rank update (the tag / genre rows of a hybrid model:
+ * 16 of the 19 rows an interaction of BASELINE config C3 touches are among its 1 128 tag rows) tolerate far
+ * shorter merge intervals than rows one interaction in thousands touches (measured on one GPU with 8 emulated
+ * ranks: C3 loses 0.027 precision@10 at the 8 Mi-interaction interval that suits ML-20M's identity rows, nothing
+ * at 1 Mi).  lfm_session_set_hot_rows names them once (ascending feature rows of `side`, the same list on every
+ * rank); lfm_session_comm_merge_hot then merges exactly these rows -- no detection, no union: one packed
+ * all-reduce of n_rows x (2 d + 2) floats -- between the full merges, which include them anyway. */
+int lfm_session_set_hot_rows(lfm_session *s, int32_t side, const int32_t *rows, int64_t n_rows);
+int lfm_session_comm_merge_hot(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes);
 /* Marks the current tables of `sides` as the start of a merge interval (lfm_session_comm_init
  * does it for the replicated sides; sessions merged with lfm_sessions_merge_local call it once
  * before training). */
@@ -316,6 +325,7 @@ int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32_t sides, i
  * (or to lfm_sessions_merge_local_flush): the one-segment delay of the overlapped multi-GPU exchange. */
 int lfm_sessions_merge_local_sparse(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap);
 int lfm_sessions_merge_local_flush(lfm_session **sessions, int32_t k);
+int lfm_sessions_merge_local_hot(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,7 @@ EXPORTS = (
     "lfm_device_trim", "lfm_device_pool_stats",
     "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
+    "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
     "lfm_session_comm_any", "lfm_session_comm_barrier", "lfm_sessions_merge_local",
 )
 MERGE_SUM, MERGE_MEAN, MERGE_ADAGRAD = 0, 1, 2

@@ -379,6 +379,7 @@ struct lfm_session {
     // sparse merge (merge_group_sparse): the rows that differ from the interval's snapshot (a byte map per
     // side, filled at merge time), and the exchange that may still be in flight
     DBuf<unsigned char> dirty[2];
+    DBuf<int32_t> hot_ids[2];   // rows merged at the short cadence (lfm_session_set_hot_rows), ascending
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     struct PendingMerge {
@@ -1039,7 +1040,8 @@ static int complete_pending(lfm_session *s, bool exact)
     return LFM_OK;
 }
 
-static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sides, int mode, bool overlap, int64_t *bytes_out)
+static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sides, int mode, bool overlap, int64_t *bytes_out,
+                              bool hot_only = false)
 {
     lfm_session *s0 = ss[0];
     const bool use_rccl = (k == 1 && s0->comm != nullptr);
@@ -1071,6 +1073,19 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
             if (ss[i]->n_feat[side] != nf || ss[i]->d != s0->d) return fail(LFM_EINVAL, "sessions differ in shape");
         }
         if (nf == 0) continue;
+        if (hot_only) {
+            // the given rows (identical on every rank by contract): no detection, no union, no compaction
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                const size_t nh = s->hot_ids[side].n;
+                if (nh != s0->hot_ids[side].n) return fail(LFM_EINVAL, "sessions differ in their hot rows");
+                s->pend.n_u[side] = (int64_t)nh;
+                if (nh) {
+                    LFM_TRY(s->pend.ids[side].reserve(nh));
+                    HIP_TRY(hipMemcpyAsync(s->pend.ids[side].p, s->hot_ids[side].p, nh * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                }
+            }
+        } else {
         // 1. rows that differ from the snapshot
         for (int i = 0; i < k; ++i) {
             lfm_session *s = ss[i];
@@ -1096,6 +1111,11 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
             hipError_t e = compact_flagged_rows(s->dirty[side].p, nf, s->pend.ids[side].p, &n_u, st);
             if (e != hipSuccess) return fail(LFM_ENODEV, std::string("compact_flagged_rows: ") + hipGetErrorString(e));
             s->pend.n_u[side] = n_u;
+        }
+        }
+        for (int i = 0; i < k; ++i) {
+            lfm_session *s = ss[i];
+            const int64_t n_u = s->pend.n_u[side];
             // 3. pack
             for (int q = 0; q < 4 && n_u; ++q) {
                 const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;
@@ -1188,6 +1208,41 @@ extern "C" int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int3
     HIP_TRY(hipSetDevice(s->device));
     lfm_session *g[1] = {s};
     return merge_group_sparse(g, 1, s->nranks, sides, mode, overlap != 0, bytes);
+}
+
+extern "C" int lfm_session_set_hot_rows(lfm_session *s, int32_t side, const int32_t *rows, int64_t n_rows)
+{
+    if (!s || (side != 0 && side != 1) || n_rows < 0 || (n_rows && !rows)) return fail(LFM_EINVAL, "bad hot-row arguments");
+    for (int64_t j = 0; j < n_rows; ++j)
+        if (rows[j] < 0 || rows[j] >= s->n_feat[side] || (j && rows[j] <= rows[j - 1]))
+            return fail(LFM_EINVAL, "hot rows must be ascending feature rows of the side");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (n_rows == 0) {
+        s->hot_ids[side].release();
+        return LFM_OK;
+    }
+    return s->hot_ids[side].upload(rows, (size_t)n_rows);
+}
+
+extern "C" int lfm_session_comm_merge_hot(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes)
+{
+    if (bytes) *bytes = 0;
+    if (!s || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    if (!s->comm || sides == 0) return LFM_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    lfm_session *g[1] = {s};
+    return merge_group_sparse(g, 1, s->nranks, sides, mode, overlap != 0, bytes, true);
+}
+
+extern "C" int lfm_sessions_merge_local_hot(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap)
+{
+    if (!sessions || k < 1 || sides < 0 || sides > 3) return fail(LFM_EINVAL, "bad merge arguments");
+    for (int i = 0; i < k; ++i)
+        if (!sessions[i] || sessions[i]->device != sessions[0]->device || sessions[i]->comm)
+            return fail(LFM_EINVAL, "local merge needs sessions of one device without a communicator");
+    HIP_TRY(hipSetDevice(sessions[0]->device));
+    return merge_group_sparse(sessions, k, k, sides, mode, overlap != 0, nullptr, true);
 }
 
 extern "C" int lfm_session_comm_merge_flush(lfm_session *s)

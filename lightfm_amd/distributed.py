@@ -15,9 +15,9 @@ overlaps the kernels of segment j + 1 and lands at the next merge):
   interactions in flight inside one GPU (DESIGN.md "Hogwild at GPU width"), replicas that
   have not exchanged their updates are harmless once the model has left its initial state and
   ruinous before -- from `merge_min` interactions up to `merge_max` (all ranks together);
-* both bounds scale with the replicated table: what matters is how many un-exchanged updates
-  a ROW collects, so a 5 M-row item table merges every 64 updates per row (320 M
-  interactions), not every 8 Mi interactions like ML-20M's 27 k rows.
+* HOT rows -- feature rows shared by many items (the tag rows of a hybrid model) -- are merged at
+  a short cadence of their own between the full merges (`MergePolicy.hot_nnz / hot_max`,
+  `hot_rows`): they are few (a megabyte) and every interaction of every rank updates some.
 
 `torch.distributed` (any backend, gloo is enough) is used ONLY for the rendezvous: broadcasting
 the RCCL unique id and the initial tables, and gathering the user rows at the end.  The data
@@ -30,8 +30,8 @@ import scipy.sparse as sp
 
 from . import _native as N
 
-__all__ = ["plan_row_shards", "local_shard", "rank_seed", "merge_deltas", "merge_schedule",
-           "MergePolicy", "DistributedFit"]
+__all__ = ["plan_row_shards", "local_shard", "rank_seed", "merge_deltas", "merge_schedule", "merge_plan",
+           "hot_rows", "MergePolicy", "DistributedFit"]
 
 
 def plan_row_shards(row_counts, world):
@@ -85,20 +85,27 @@ class MergePolicy(object):
                / merge_k, clamped to [lo, cap]
     merge_min  lo = max(merge_min, rows_lo * replicated rows) interactions of ALL ranks together
     merge_max  cap; 0 = max(world * 2**20 (one full-size launch per rank), rows_k * replicated rows)
-    rows_lo, rows_k  un-exchanged updates per replicated ROW the shortest / longest interval may
-               collect (an interaction updates 1.4 item rows on the BASELINE shapes): the measured
-               ML-20M policy (8 Mi interactions over 26 744 item rows at 8 ranks = ~450 per row,
-               precision@10 within the gate) bounds rows_k from above
+    rows_lo, rows_k  optional: scale the bounds with the replicated table (interactions per ROW the
+               shortest / longest interval may span).  0 (default) = off: a 1/8-scale C4 emulated at 8
+               ranks lost 0.004 precision@10 with rows_k = 64 (two merges per epoch) against 0.002 at
+               the plain world * 2**20 cap -- a trade of quality for exchange volume the caller makes
     mode       "sum" | "mean" | "adagrad" (include/lfm_hip.h: LFM_MERGE_*)
     sparse     exchange only the rows touched since the last merge (default); False = the dense
                all-reduce of whole tables
-    overlap    sparse merges: the exchange overlaps the next segment and lands one merge later
+    overlap    sparse merges: the exchange overlaps the next segment and lands one merge later.
+               Off by default: measured with 8 emulated ranks it costs precision@10 (C2 -0.007 at the
+               8 Mi cap, -0.002 at half of it), and what it hides is small next to the kernels wherever
+               the quality-preserving cadence is affordable at all (DESIGN.md "Multi-GPU")
+    hot_nnz    a feature column of the replicated side with at least this many entries in the feature
+               matrix is a HOT row (tag / genre rows shared by many items): merged between the full
+               merges at the short cadence hot_max (0 = world * 2**17 interactions)
     """
 
-    def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad", rows_lo=1, rows_k=64,
-                 sparse=True, overlap=True):
+    def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad", rows_lo=0, rows_k=0,
+                 sparse=True, overlap=False, hot_nnz=16, hot_max=0):
         self.merge_k, self.merge_min, self.merge_max, self.mode = merge_k, merge_min, merge_max, mode
         self.rows_lo, self.rows_k, self.sparse, self.overlap = rows_lo, rows_k, sparse, overlap
+        self.hot_nnz, self.hot_max = hot_nnz, hot_max
 
     def mode_id(self):
         return N.MERGE_MODES[self.mode]
@@ -121,6 +128,36 @@ def merge_schedule(global_history, global_n, world, policy=None, n_rows=0):
         fr.append(g / float(global_n))
     fr[-1] = 1.0
     return np.asarray(fr)
+
+
+def hot_rows(features, hot_nnz):
+    """Ascending feature columns of a (replicated side's) feature matrix with >= hot_nnz entries; none for
+    an identity matrix."""
+    if features is None or hot_nnz <= 0:
+        return np.zeros(0, np.int32)
+    f = sp.csc_matrix(features)
+    counts = np.diff(f.indptr)
+    return np.flatnonzero(counts >= hot_nnz).astype(np.int32)
+
+
+def merge_plan(global_history, global_n, world, policy=None, n_rows=0, has_hot=False):
+    """(fractions, kinds): the full-merge schedule of `merge_schedule`, its segments cut further into pieces
+    of at most policy.hot_max interactions when there are hot rows; kinds[j] = "full" | "hot" names the merge
+    after segment j.  Identical on every rank."""
+    policy = policy or MergePolicy()
+    full = merge_schedule(global_history, global_n, world, policy, n_rows)
+    if not has_hot or global_n <= 0:
+        return full, ["full"] * (len(full) - 1)
+    hot_cap = policy.hot_max if policy.hot_max > 0 else world * (1 << 17)
+    fr, kinds = [0.0], []
+    for j in range(len(full) - 1):
+        a, b = full[j], full[j + 1]
+        pieces = max(1, int(np.ceil((b - a) * global_n / float(hot_cap))))
+        for q in range(1, pieces + 1):
+            fr.append(a + (b - a) * q / pieces)
+            kinds.append("hot" if q < pieces else "full")
+    fr[-1] = 1.0
+    return np.asarray(fr), kinds
 
 
 def segment_positions(fractions, n_local):
@@ -180,6 +217,7 @@ class DistributedFit(object):
         self.session.build_positives(b1 - b0, n_items)
         self.n_replicated_rows = n_items
         self.merges, self.merge_bytes = 0, 0
+        self.hot = hot_rows(None, self.policy.hot_nnz)  # identity item features: no shared rows
         if world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
@@ -189,6 +227,8 @@ class DistributedFit(object):
             dist.broadcast(t, src=0)
             self.session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()),
                                                           N.UNIQUE_ID_BYTES), rank, world)
+            if len(self.hot):
+                self.session.set_hot_rows(0, self.hot)
 
     def run_epoch(self, seeds, slot=0):
         """One epoch of this rank: segments + merges.  Returns the per-segment lfm_opts."""
@@ -196,8 +236,9 @@ class DistributedFit(object):
         m = self.model
         n = self.shard.nnz
         history = int(getattr(m, "_trained_interactions", 0))  # interactions of ALL ranks so far
-        pos = segment_positions(merge_schedule(history, self.global_n, self.world, self.policy,
-                                               self.n_replicated_rows), n)
+        fr, kinds = merge_plan(history, self.global_n, self.world, self.policy, self.n_replicated_rows,
+                               len(self.hot) > 0)
+        pos = segment_positions(fr, n)
         sparse = self.policy.sparse and m.learning_schedule == "adagrad"
         stats = []
         for j in range(len(pos) - 1):
@@ -207,10 +248,13 @@ class DistributedFit(object):
             opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
             if pos[j + 1] > pos[j]:
                 self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts, slot=slot)
-            if sparse:
-                self.merge_bytes += self.session.comm_merge_sparse(1, self.policy.mode_id(), self.policy.overlap)
+            if not sparse:
+                if kinds[j] == "full":
+                    self.session.comm_merge(1, self.policy.mode_id())
+            elif kinds[j] == "hot":
+                self.merge_bytes += self.session.comm_merge_hot(1, self.policy.mode_id(), self.policy.overlap)
             else:
-                self.session.comm_merge(1, self.policy.mode_id())
+                self.merge_bytes += self.session.comm_merge_sparse(1, self.policy.mode_id(), self.policy.overlap)
             self.merges += 1
             stats.append(opts)
         if sparse:

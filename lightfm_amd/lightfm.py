@@ -129,6 +129,16 @@ class _Session(object):
     def comm_merge_flush(self):
         N.check(N.lib().lfm_session_comm_merge_flush(self.handle))
 
+    def set_hot_rows(self, side, rows):
+        """The feature rows of `side` merged at the short cadence (ascending int32; lfm_session_set_hot_rows)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        N.check(N.lib().lfm_session_set_hot_rows(self.handle, side, N.i32p(rows), C.c_int64(len(rows))))
+
+    def comm_merge_hot(self, sides=1, mode=0, overlap=False):
+        nbytes = C.c_int64()
+        N.check(N.lib().lfm_session_comm_merge_hot(self.handle, sides, mode, int(bool(overlap)), C.byref(nbytes)))
+        return nbytes.value
+
     def merge_begin(self, sides=1):
         N.check(N.lib().lfm_session_merge_begin(self.handle, sides))
 
@@ -142,6 +152,11 @@ class _Session(object):
     def merge_local_sparse(sessions, sides=1, mode=0, overlap=False):
         arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
         N.check(N.lib().lfm_sessions_merge_local_sparse(arr, len(sessions), sides, mode, int(bool(overlap))))
+
+    @staticmethod
+    def merge_local_hot(sessions, sides=1, mode=0, overlap=False):
+        arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
+        N.check(N.lib().lfm_sessions_merge_local_hot(arr, len(sessions), sides, mode, int(bool(overlap))))
 
     @staticmethod
     def merge_local_flush(sessions):

@@ -81,6 +81,12 @@ def _worker(rank, world, port, out, argv):
             dist.barrier()
             return 1000
 
+        def comm_merge_hot(self, sides, mode, overlap=True):
+            return self.comm_merge_sparse(sides, mode, overlap)
+
+        def set_hot_rows(self, side, rows):
+            calls["hot"] = len(rows)
+
         def comm_merge_flush(self):
             self.pending = False
 

@@ -354,6 +354,65 @@ def test_local_merge_matches_numpy(mode, flavour, case):
             np.testing.assert_array_equal(m.item_embedding_gradients, structs[0][0].item_embedding_gradients)
 
 
+def test_hot_rows_merge_between_full_merges():
+    """lfm_session_set_hot_rows / lfm_sessions_merge_local_hot: the shared tag rows of a hybrid model are merged
+    on their own (every replica then agrees on them, and holds its own values everywhere else); the next full
+    merge exchanges the rest and leaves the hot rows where they are.  SUM mode against numpy."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import make_opts
+    from lightfm_amd.distributed import hot_rows, local_shard
+    from lightfm_amd.lightfm import _Session
+    K, nu, ni, d = 3, 240, 160, 32
+    item_f = H.tag_features(ni, 12, 3, seed=1)
+    n_feat = item_f.shape[1]
+    hot = hot_rows(item_f, 16)
+    assert 0 < len(hot) <= 12 and hot.min() >= ni  # the tag columns, not the identity block
+    cold = np.setdiff1d(np.arange(n_feat), hot)
+    coo = H.make_interactions(nu, ni, 9000, seed=12)
+    base = LightFM(no_components=d, loss="bpr", random_state=2)
+    base._initialize(d, n_feat, nu)
+    W0, G0 = base.item_embeddings.copy(), base.item_embedding_gradients.copy()
+    own, sessions, structs = [], [], []
+    try:
+        for r in range(K):
+            shard, _ = local_shard(coo, r, K)
+            m = LightFM(no_components=d, loss="bpr", random_state=2)
+            m._initialize(d, n_feat, nu)
+            s, st = _session(m, ni, nu, shard, item_f=item_f)
+            s.merge_begin(1)
+            s.set_hot_rows(0, hot)
+            s.device_shuffle(10 + r, 20 + r)
+            o, _ = make_opts()
+            o.history = 1 << 30
+            s.epoch("bpr", 0.0, 0.0, 5, 10, np.array([5 + r], np.uint32), o)
+            s.sync_to_host(st)
+            own.append((m.item_embeddings.copy(), m.item_embedding_gradients.copy()))
+            sessions.append(s)
+            structs.append((m, st))
+        W = W0 + sum(w - W0 for w, _ in own)
+        G = G0 + sum(g - G0 for _, g in own)
+        _Session.merge_local_hot(sessions, 1, N.MERGE_MODES["sum"])
+        for ((m, st), s), (w, g) in zip(zip(structs, sessions), own):
+            s.sync_to_host(st)
+            np.testing.assert_allclose(m.item_embeddings[hot], W[hot], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(m.item_embedding_gradients[hot], G[hot], rtol=2e-5, atol=1e-7)
+            np.testing.assert_array_equal(m.item_embeddings[cold], w[cold])  # untouched by the hot merge
+        hot_after = structs[0][0].item_embeddings[hot].copy()
+        _Session.merge_local_sparse(sessions, 1, N.MERGE_MODES["sum"])
+        for (m, st), s in zip(structs, sessions):
+            s.sync_to_host(st)
+            np.testing.assert_allclose(m.item_embeddings, W, rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(m.item_embedding_gradients, G, rtol=2e-5, atol=1e-7)
+            np.testing.assert_array_equal(m.item_embeddings[hot], hot_after)  # already exchanged: nothing to add
+        with pytest.raises(ValueError):
+            sessions[0].set_hot_rows(0, np.array([3, 2], np.int32))  # not ascending
+        with pytest.raises(ValueError):
+            sessions[0].set_hot_rows(0, np.array([n_feat], np.int32))  # not a feature row
+    finally:
+        for s in sessions:
+            s.close()
+
+
 def test_sparse_merge_carries_what_training_adds_while_the_exchange_is_in_flight():
     """The overlapped exchange: a second segment trains between the merge call and the flush.  What it adds to
     the local tables must survive the late application (table += sum - local delta) and travel with the NEXT

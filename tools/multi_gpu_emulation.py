@@ -9,7 +9,8 @@ multi-GPU exchange does).  Reports precision@10 of the merged model against one 
     python tools/multi_gpu_emulation.py CONFIG [CONFIG ...]
       CONFIG = K:mode:merge_k:merge_min:merge_max[:flavour[:rows_k]]
                 flavour = dense | sparse | overlap (default) | late<E> (sparse, overlapped only once the model has
-                seen E epochs: late1, late0.5)        rows_k = MergePolicy.rows_k (default 64)
+                seen E epochs: late1, late0.5); a "+hot" suffix merges the hot rows (MergePolicy.hot_nnz) every
+                K * 2**17 interactions between the full merges      rows_k = MergePolicy.rows_k (default 0 = off)
                 e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0:dense   8:adagrad:4:16384:0:late1:16
     env: EMU_SHAPE  c2 (ML-20M shape, WARP d=64, identity; default) | c3 (ML-20M shape, BPR d=128, item
                     features [identity | 8 tags of 1128]: shared rows in the replicated tables) |
@@ -27,7 +28,7 @@ import scipy.sparse as sp
 
 from lightfm_amd import LightFM, synthetic
 from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
-from lightfm_amd.distributed import MergePolicy, local_shard, merge_schedule, segment_positions
+from lightfm_amd.distributed import MergePolicy, hot_rows, local_shard, merge_plan, segment_positions
 from lightfm_amd.evaluation import precision_at_k
 from lightfm_amd.lightfm import _Session, _WEIGHTS
 
@@ -60,6 +61,9 @@ n_item_feat = feats.shape[1] if feats is not None else n_items
 
 
 def run(K, policy, seed, flavour):
+    use_hot = flavour.endswith("+hot")
+    flavour = flavour[:-4] if use_hot else flavour
+    hot = hot_rows(feats, policy.hot_nnz) if use_hot else []
     rng = np.random.RandomState(seed)
     model = LightFM(no_components=D, loss=LOSS, random_state=seed)
     model._initialize(D, n_item_feat, n_users)
@@ -80,6 +84,8 @@ def run(K, policy, seed, flavour):
                            shard.data, shard.data)
         s.build_positives(b1 - b0, n_items)
         s.merge_begin(1)
+        if len(hot):
+            s.set_hot_rows(0, hot)
         sessions.append(s)
         structs.append(st)
         shards.append(shard)
@@ -89,7 +95,7 @@ def run(K, policy, seed, flavour):
             for s in sessions:
                 s.device_shuffle(int(rng.randint(1 << 30)), int(rng.randint(1 << 30)))
             sd = [np.array([rng.randint(1 << 30)], np.uint32) for _ in sessions]
-            fr = merge_schedule(history, train.nnz, K, policy, n_item_feat)
+            fr, kinds = merge_plan(history, train.nnz, K, policy, n_item_feat, len(hot) > 0)
             pos = [segment_positions(fr, sh.nnz) for sh in shards]
             for j in range(len(fr) - 1):
                 seg_ms = 0.0
@@ -102,11 +108,13 @@ def run(K, policy, seed, flavour):
                         seg_ms = max(seg_ms, float(opts.kernel_ms))
                 kernel_ms += seg_ms  # ranks run concurrently on real hardware
                 if K > 1:
+                    seen = history + train.nnz * fr[j + 1]
+                    ov = flavour == "overlap" or (flavour.startswith("late") and seen >= float(flavour[4:]) * train.nnz)
                     if flavour == "dense":
                         _Session.merge_local(sessions, 1, policy.mode_id())
+                    elif kinds[j] == "hot":
+                        _Session.merge_local_hot(sessions, 1, policy.mode_id(), overlap=ov)
                     else:
-                        seen = history + train.nnz * fr[j + 1]
-                        ov = flavour == "overlap" or (flavour.startswith("late") and seen >= float(flavour[4:]) * train.nnz)
                         _Session.merge_local_sparse(sessions, 1, policy.mode_id(), overlap=ov)
                 merges += 1
             if K > 1 and flavour != "dense":
