@@ -323,7 +323,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
         dist.broadcast(t, src=0)
         session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()), N.UNIQUE_ID_BYTES), rank, world)
-    hot = hot_rows(feats, policy.hot_nnz) if world > 1 else []
+    hot = hot_rows(feats, policy.hot_share) if world > 1 else []
     if len(hot):  # shared feature rows (C3's tags): merged at the short cadence between the full merges
         session.set_hot_rows(0, hot)
     log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))

@@ -16,7 +16,7 @@ overlaps the kernels of segment j + 1 and lands at the next merge):
   have not exchanged their updates are harmless once the model has left its initial state and
   ruinous before -- from `merge_min` interactions up to `merge_max` (all ranks together);
 * HOT rows -- feature rows shared by many items (the tag rows of a hybrid model) -- are merged at
-  a short cadence of their own between the full merges (`MergePolicy.hot_nnz / hot_max`,
+  a short cadence of their own between the full merges (`MergePolicy.hot_share / hot_max`,
   `hot_rows`): they are few (a megabyte) and every interaction of every rank updates some.
 
 `torch.distributed` (any backend, gloo is enough) is used ONLY for the rendezvous: broadcasting
@@ -96,16 +96,19 @@ class MergePolicy(object):
                Off by default: measured with 8 emulated ranks it costs precision@10 (C2 -0.007 at the
                8 Mi cap, -0.002 at half of it), and what it hides is small next to the kernels wherever
                the quality-preserving cadence is affordable at all (DESIGN.md "Multi-GPU")
-    hot_nnz    a feature column of the replicated side with at least this many entries in the feature
-               matrix is a HOT row (tag / genre rows shared by many items): merged between the full
-               merges at the short cadence hot_max (0 = world * 2**17 interactions)
+    hot_share  a feature column of the replicated side that an interaction touches with at least this
+               probability -- 2 nnz(column) / rows of the feature matrix (the positive and the negative
+               item), columns with a single entry (identity blocks) never -- is a HOT row: the tag / genre
+               rows shared by many items (C3: 0.014; ML-20M identity rows: 0.00007; C5's hashed rows:
+               0.000016).  Hot rows are merged between the full merges at the short cadence hot_max
+               (0 = world * 2**17 interactions)
     """
 
     def __init__(self, merge_k=4, merge_min=16384, merge_max=0, mode="adagrad", rows_lo=0, rows_k=0,
-                 sparse=True, overlap=False, hot_nnz=16, hot_max=0):
+                 sparse=True, overlap=False, hot_share=1.0 / 512, hot_max=0):
         self.merge_k, self.merge_min, self.merge_max, self.mode = merge_k, merge_min, merge_max, mode
         self.rows_lo, self.rows_k, self.sparse, self.overlap = rows_lo, rows_k, sparse, overlap
-        self.hot_nnz, self.hot_max = hot_nnz, hot_max
+        self.hot_share, self.hot_max = hot_share, hot_max
 
     def mode_id(self):
         return N.MERGE_MODES[self.mode]
@@ -130,14 +133,14 @@ def merge_schedule(global_history, global_n, world, policy=None, n_rows=0):
     return np.asarray(fr)
 
 
-def hot_rows(features, hot_nnz):
-    """Ascending feature columns of a (replicated side's) feature matrix with >= hot_nnz entries; none for
-    an identity matrix."""
-    if features is None or hot_nnz <= 0:
+def hot_rows(features, hot_share):
+    """Ascending feature columns of a (replicated side's) feature matrix that an interaction touches with
+    probability >= hot_share (MergePolicy.hot_share); none for an identity matrix."""
+    if features is None or hot_share <= 0 or features.shape[0] == 0:
         return np.zeros(0, np.int32)
     f = sp.csc_matrix(features)
     counts = np.diff(f.indptr)
-    return np.flatnonzero(counts >= hot_nnz).astype(np.int32)
+    return np.flatnonzero((counts >= 2) & (2.0 * counts / float(features.shape[0]) >= hot_share)).astype(np.int32)
 
 
 def merge_plan(global_history, global_n, world, policy=None, n_rows=0, has_hot=False):
@@ -217,7 +220,7 @@ class DistributedFit(object):
         self.session.build_positives(b1 - b0, n_items)
         self.n_replicated_rows = n_items
         self.merges, self.merge_bytes = 0, 0
-        self.hot = hot_rows(None, self.policy.hot_nnz)  # identity item features: no shared rows
+        self.hot = hot_rows(None, self.policy.hot_share)  # identity item features: no shared rows
         if world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)

@@ -365,7 +365,7 @@ def test_hot_rows_merge_between_full_merges():
     K, nu, ni, d = 3, 240, 160, 32
     item_f = H.tag_features(ni, 12, 3, seed=1)
     n_feat = item_f.shape[1]
-    hot = hot_rows(item_f, 16)
+    hot = hot_rows(item_f, 1.0 / 512)
     assert 0 < len(hot) <= 12 and hot.min() >= ni  # the tag columns, not the identity block
     cold = np.setdiff1d(np.arange(n_feat), hot)
     coo = H.make_interactions(nu, ni, 9000, seed=12)

@@ -151,3 +151,35 @@ def test_local_shard_rebased_ids():
     assert np.array_equal(bounds, b2)
     assert reb.shape == (bounds[2] - bounds[1], 90) and reb.nnz == full.nnz
     assert np.array_equal(reb.row + bounds[1], full.row) and np.array_equal(reb.col, full.col)
+
+
+def test_merge_plan_hot_rows_and_full_merges():
+    """merge_plan: the full-merge schedule cut into pieces of at most hot_max interactions when the replicated
+    side has hot (shared) feature rows; hot_rows: the feature columns an interaction touches with probability >= hot_share."""
+    import scipy.sparse as sp
+    from lightfm_amd import synthetic
+    from lightfm_amd.distributed import MergePolicy, hot_rows, merge_plan, merge_schedule
+    pol = MergePolicy()
+    n, world = 20_000_000, 8
+    full = merge_schedule(3 * n, n, world, pol)
+    fr, kinds = merge_plan(3 * n, n, world, pol, 0, has_hot=False)
+    assert np.array_equal(fr, full) and set(kinds) == {"full"}
+    fr, kinds = merge_plan(3 * n, n, world, pol, 0, has_hot=True)
+    assert fr[0] == 0.0 and fr[-1] == 1.0 and np.all(np.diff(fr) > 0) and len(kinds) == len(fr) - 1
+    assert np.max(np.diff(fr)) * n <= world * (1 << 17) + 1  # no piece longer than the hot cadence
+    full_ends = [f for f, k in zip(fr[1:], kinds) if k == "full"]
+    np.testing.assert_allclose(full_ends, full[1:])            # the full merges are where they were
+    assert kinds[-1] == "full" and kinds.count("hot") > kinds.count("full")
+    # a fresh model: the ramp's short segments are already below the hot cadence
+    fr0, kinds0 = merge_plan(0, n, world, pol, 0, has_hot=True)
+    assert kinds0[0] == "full" and np.diff(fr0)[0] * n <= 16384 + 1
+    # identical on every rank by construction: depends on global numbers only
+    assert np.array_equal(merge_plan(3 * n, n, world, pol, 0, True)[0], fr)
+
+    feats = synthetic.tag_item_features(2000, n_tags=50, per_item=4)
+    hot = hot_rows(feats, pol.hot_share)
+    assert np.array_equal(hot, np.arange(2000, 2050))           # the tag block, ascending; never the identity block
+    assert len(hot_rows(None, pol.hot_share)) == 0 and len(hot_rows(sp.identity(30, format="csr"), pol.hot_share)) == 0
+    # BASELINE shapes: C3's 1 128 tag rows are hot, C5's hashed feature rows (80 items each of 10 M) are not
+    assert len(hot_rows(synthetic.tag_item_features(26744), pol.hot_share)) == 1128
+    assert len(hot_rows(synthetic.hashed_item_features(200_000, n_cols=20_000), pol.hot_share)) == 0

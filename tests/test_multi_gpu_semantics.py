@@ -71,6 +71,28 @@ def _merge(mode, start, local_list_or_none, local, allsum, world):
     return out
 
 
+def _dirty_union(start, local, allmax):
+    """Rows whose W, G, b or bG differ from the interval's snapshot on ANY rank (csrc/session.hip:
+    detect_dirty_kernel + the all-reduce MAX of the byte maps + compact_flagged_rows), ascending."""
+    flags = np.zeros(len(start["item_biases"]), np.uint8)
+    for n in start:
+        diff = local[n] != start[n]
+        flags |= (diff.any(axis=1) if diff.ndim == 2 else diff).astype(np.uint8)
+    return np.flatnonzero(allmax(flags))
+
+
+def _merge_sparse(mode, start, local, allsum, allmax, world):
+    """numpy restatement of merge_group_sparse, one rank's view: (rows of the union, the merged deltas of those
+    rows summed over ranks, this rank's own deltas) -- what complete_pending later applies."""
+    rows = _dirty_union(start, local, allmax)
+    sub_start = {n: start[n][rows] for n in start}
+    sub_local = {n: local[n][rows] for n in start}
+    merged = _merge(mode, sub_start, None, sub_local, allsum, world)
+    total = {n: (merged[n] - sub_start[n]).astype(np.float32) for n in start}   # sum over ranks (rescaled)
+    own = {n: (sub_local[n] - sub_start[n]).astype(np.float32) for n in start}  # unscaled
+    return rows, total, own
+
+
 ITEM_NAMES = ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients")
 USER_NAMES = ("user_embeddings", "user_embedding_gradients", "user_biases", "user_bias_gradients")
 
@@ -80,9 +102,12 @@ def _policy():
     return MergePolicy(merge_k=2, merge_min=150, merge_max=900, mode="adagrad")
 
 
-def _rank_epochs(rank, world, coo, st, allsum, epochs=2):
+def _rank_epochs(rank, world, coo, st, allsum, epochs=2, flavour="dense", allmax=None):
     """What DistributedFit.run does on one rank, with the CPU oracle as the epoch engine: segments of
-    the rank's shuffled shard from the GLOBAL schedule, a merge of the item tables after each."""
+    the rank's shuffled shard from the GLOBAL schedule, a merge of the item tables after each.
+    flavour: "dense" (whole tables), "sparse" (the union of the rows that changed, applied at once) or
+    "overlap" (the sparse merge applied at the NEXT merge / at the end of the epoch, while the rank has
+    trained on: table += sum - own delta, snapshot += sum)."""
     from lightfm_amd.distributed import local_shard, merge_schedule, rank_seed, segment_positions
     from oracle import oracle
     from tests import helpers as H
@@ -93,24 +118,47 @@ def _rank_epochs(rank, world, coo, st, allsum, epochs=2):
     pol = _policy()
     history, merges = 0, 0
     pos_csr = H.positives_csr(shard)
+    snap = {n: getattr(st, n).copy() for n in ITEM_NAMES}  # the tables at the start of the merge interval
+    pending = None
+
+    def land(exact):
+        rows, total, own = pending
+        for n in ITEM_NAMES:
+            tab = getattr(st, n)
+            new_snap = (snap[n][rows] + total[n]).astype(np.float32)
+            tab[rows] = new_snap if exact else (tab[rows] + (total[n] - own[n])).astype(np.float32)
+            snap[n][rows] = new_snap
+
     for _ in range(epochs):
         shuffle, seeds = H.epoch_inputs(shard, rng)
         pos = segment_positions(merge_schedule(history, coo.nnz, world, pol), shard.nnz)
         for j in range(len(pos) - 1):
-            start = {n: getattr(st, n).copy() for n in ITEM_NAMES}
             sub = np.ascontiguousarray(shuffle[pos[j]:pos[j + 1]])
             if len(sub):
                 oracle.fit_warp(item_f, user_f, pos_csr, shard.row, shard.col, shard.data, shard.data, sub, st,
                                 0.0, 0.0, seeds)
-            merged = _merge(pol.mode, start, None, {n: getattr(st, n) for n in ITEM_NAMES}, allsum, world)
-            for n in ITEM_NAMES:
-                getattr(st, n)[...] = merged[n]
+            local = {n: getattr(st, n) for n in ITEM_NAMES}
+            if flavour == "dense":
+                merged = _merge(pol.mode, snap, None, local, allsum, world)
+                for n in ITEM_NAMES:
+                    getattr(st, n)[...] = merged[n]
+                    snap[n][...] = merged[n]
+            else:
+                if pending is not None:  # the previous exchange lands before this one's deltas are formed
+                    land(False)
+                pending = _merge_sparse(pol.mode, snap, local, allsum, allmax, world)
+                if flavour == "sparse":
+                    land(True)
+                    pending = None
             merges += 1
+        if pending is not None:  # lfm_session_comm_merge_flush at the end of the epoch
+            land(False)
+            pending = None
         history += coo.nnz
     return bounds, merges
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, flavour="dense"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -128,7 +176,12 @@ def _worker(rank, world, port, out):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return t.numpy()
 
-        bounds, merges = _rank_epochs(rank, world, coo, st, allsum)
+        def allmax(x):
+            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint8).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.numpy()
+
+        bounds, merges = _rank_epochs(rank, world, coo, st, allsum, flavour=flavour, allmax=allmax)
         # the user rows of the other rank arrive once at the end (host plane): DistributedFit.gather_users
         for n in USER_NAMES:
             a = getattr(st, n)
@@ -143,18 +196,21 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_schedule_matches_single_process_emulation(tmp_path):
+@pytest.mark.parametrize("flavour", ["dense", "sparse", "overlap"])
+def test_two_rank_gloo_schedule_matches_single_process_emulation(tmp_path, flavour):
     """World size 2 over gloo == the same algorithm emulated in one process: both replicas start
     from the same tables, train the segments of the global merge schedule on their shard, the item
     tables are merged after every segment (LFM_MERGE_ADAGRAD arithmetic), user rows are a disjoint
-    union.  Both ranks must make the same number of collective calls (else this test hangs)."""
+    union.  Both ranks must make the same number of collective calls (else this test hangs).
+    flavour: the dense merge, the sparse merge over the union of changed rows (same result as the dense
+    one, checked), and the overlapped sparse merge that lands one merge late."""
     import torch.multiprocessing as mp
     from lightfm_amd.distributed import local_shard
     from oracle import oracle
     from tests import helpers as H
     world, port = 2, _free_port()
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, flavour), nprocs=world, join=True)
     got = [np.load(out % r) for r in range(world)]
     assert int(got[0]["merges"]) == int(got[1]["merges"]) > 4
 
@@ -167,24 +223,33 @@ def test_two_rank_gloo_schedule_matches_single_process_emulation(tmp_path):
     pending, results = {}, {}
     lock = threading.Lock()
 
-    def make_allsum(rank):
+    def make_collectives(rank):
         calls = [0]
 
-        def allsum(x):
+        def collective(x, dtype, reduce):
             key = calls[0]
             calls[0] += 1
             with lock:
-                pending.setdefault(key, []).append(np.asarray(x, np.float32).copy())
+                pending.setdefault(key, []).append(np.asarray(x, dtype).copy())
             barrier.wait()
             with lock:
                 if key not in results:
-                    results[key] = np.sum(pending[key], axis=0, dtype=np.float32)
+                    results[key] = reduce(pending[key])
             barrier.wait()
             return results[key].copy()
-        return allsum
 
-    threads = [threading.Thread(target=_rank_epochs, args=(r, world, coo, states[r], make_allsum(r)))
-               for r in range(world)]
+        def allsum(x):
+            return collective(x, np.float32, lambda xs: np.sum(xs, axis=0, dtype=np.float32))
+
+        def allmax(x):
+            return collective(x, np.uint8, lambda xs: np.max(xs, axis=0))
+        return allsum, allmax
+
+    def run_rank(r):
+        allsum, allmax = make_collectives(r)
+        _rank_epochs(r, world, coo, states[r], allsum, flavour=flavour, allmax=allmax)
+
+    threads = [threading.Thread(target=run_rank, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -200,6 +265,22 @@ def test_two_rank_gloo_schedule_matches_single_process_emulation(tmp_path):
                 b0, b1 = int(bounds[q]), int(bounds[q + 1])
                 np.testing.assert_allclose(got[r][n][b0:b1], getattr(states[q], n)[b0:b1], rtol=1e-6, atol=1e-7,
                                            err_msg=n)
+    if flavour == "sparse":
+        # the union of changed rows carries everything the dense merge does: same tables, bit for bit
+        dense = [oracle.State(ni, nu, d, np.random.RandomState(3)) for _ in range(world)]
+        pending.clear()
+        results.clear()
+
+        def run_dense(r):
+            allsum, allmax = make_collectives(r)
+            _rank_epochs(r, world, coo, dense[r], allsum, flavour="dense", allmax=allmax)
+        threads = [threading.Thread(target=run_dense, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for n in ITEM_NAMES:
+            np.testing.assert_array_equal(getattr(states[0], n), getattr(dense[0], n), err_msg=n)
     # every user row was trained by exactly one rank: the union changed rows of both shards
     fresh = oracle.State(ni, nu, d, np.random.RandomState(3)).user_embeddings
     moved = np.any(got[0]["user_embeddings"] != fresh, axis=1)

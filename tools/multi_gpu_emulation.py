@@ -9,7 +9,7 @@ multi-GPU exchange does).  Reports precision@10 of the merged model against one 
     python tools/multi_gpu_emulation.py CONFIG [CONFIG ...]
       CONFIG = K:mode:merge_k:merge_min:merge_max[:flavour[:rows_k]]
                 flavour = dense | sparse | overlap (default) | late<E> (sparse, overlapped only once the model has
-                seen E epochs: late1, late0.5); a "+hot" suffix merges the hot rows (MergePolicy.hot_nnz) every
+                seen E epochs: late1, late0.5); a "+hot" suffix merges the hot rows (MergePolicy.hot_share) every
                 K * 2**17 interactions between the full merges      rows_k = MergePolicy.rows_k (default 0 = off)
                 e.g. 8:adagrad:4:16384:0   1:sum:4:16384:0:dense   8:adagrad:4:16384:0:late1:16
     env: EMU_SHAPE  c2 (ML-20M shape, WARP d=64, identity; default) | c3 (ML-20M shape, BPR d=128, item
@@ -63,7 +63,7 @@ n_item_feat = feats.shape[1] if feats is not None else n_items
 def run(K, policy, seed, flavour):
     use_hot = flavour.endswith("+hot")
     flavour = flavour[:-4] if use_hot else flavour
-    hot = hot_rows(feats, policy.hot_nnz) if use_hot else []
+    hot = hot_rows(feats, policy.hot_share) if use_hot else []
     rng = np.random.RandomState(seed)
     model = LightFM(no_components=D, loss=LOSS, random_state=seed)
     model._initialize(D, n_item_feat, n_users)
