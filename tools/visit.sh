@@ -117,6 +117,33 @@ except Exception as e:
 PY
   done
   ;;
+final)
+  # the driver's sequence: suite (twice), smoke, default bench; then rocprofv3 trace + PMC of c2 / c3 / c4shard
+  for i in 1 2; do
+    timeout -k 5 1200 $PYT tests -m gpu -x -q > $OUT/suite_$i.log 2>&1
+    echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 8
+  done
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ( time timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2>&1 | grep real
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_default.json"))
+    def show(n, v, r):
+        print("  %-8s %8.1f M/s  frac %.3f  atomic %.3f  launch %.3f ms  U %.3f  traffic %s  %s" % (n, v / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r.get("traffic_over_algorithmic"), r["kernel"]))
+    show("c2", d["value"], d["roofline"])
+    for e in d.get("extra_configs", []):
+        if "error" in e: print("  ", e)
+        else: show(e["name"], e["value"], e["roofline"])
+    q = d.get("quality") or {}
+    print("  quality", q.get("precision_at_10"), q.get("precision_at_10_ref"), q.get("delta"))
+    print("  cpu", (d.get("cpu_baseline") or {}).get("value"), "fit", (d.get("end_to_end_fit") or {}).get("value"))
+except Exception as e:
+    print("  no result:", e)
+PY
+  for cfg in c2 c3 c4shard; do bash tools/profile2.sh r03_$cfg --config $cfg; done
+  cp $R/profiles/r03_c*_kernel_stats.txt $R/profiles/r03_c*_pmc_summary.json $OUT/ 2>/dev/null
+  ;;
 r3c)
   # suite, the driver's default bench line (with the extra_configs legs), rocprofv3 trace + PMC of c2 / c3 / c4shard
   timeout -k 5 1200 $PYT tests -m gpu -x -q -s > $OUT/suite_1.log 2>&1
