@@ -211,41 +211,27 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
-                // four staged rows are read from LDS together, then accumulated one after the other in CSR
-                // order (the reference's summation order): the loop used to expose one LDS round trip per row
-                // (240 cycles per row of C5's 168 rows per interaction, profiles/r02_ablations.txt)
-                constexpr int RB = 4;
-                for (int t0 = ce; t0 < ce + nc; t0 += RB) {
-                    float xr[RB][NC];
+                for (int t = ce; t < ce + nc; ++t) {
+                    const int jt = read_lane(e.job, t);
+                    if (jt != cur) {
+                        if (cur >= 0) flush();
+                        cur = jt;
 #pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const float *sr = stage + (size_t)(min(t0 + u, ce + nc - 1) - ce) * d;
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            const int c = lane + WAVE * q;
-                            xr[u][q] = c < d ? sr[c] : 0.0f;
-                        }
+                        for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+                        accb = 0.0f;
                     }
+                    float wt = read_lanef(e.w, t);
+                    const float bt = read_lanef(bx, t);
+                    if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
+                        wt = (float)((double)wt * (double)(read_lane(e.eside, t) ? wsc_u : wsc_i));
+                    const float *sr = stage + (size_t)(t - ce) * d;
 #pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int t = t0 + u;
-                        if (t >= ce + nc) break;
-                        const int jt = read_lane(e.job, t);
-                        if (jt != cur) {
-                            if (cur >= 0) flush();
-                            cur = jt;
-#pragma unroll
-                            for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
-                            accb = 0.0f;
-                        }
-                        float wt = read_lanef(e.w, t);
-                        const float bt = read_lanef(bx, t);
-                        if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
-                            wt = (float)((double)wt * (double)(read_lane(e.eside, t) ? wsc_u : wsc_i));
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xr[u][q]));
-                        accb = __fadd_rn(accb, __fmul_rn(wt, bt));
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        const float xv = c < d ? sr[c] : 0.0f;
+                        acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xv));
                     }
+                    accb = __fadd_rn(accb, __fmul_rn(wt, bt));
                 }
                 wave_sync();  // the stage is rewritten by the next chunk
                 stamp(3);
