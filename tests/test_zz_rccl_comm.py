@@ -68,3 +68,64 @@ def test_single_rank_communicator_roundtrip():
     assert not np.array_equal(before, trained)
     assert np.array_equal(m.user_embeddings, trained)  # identity user features: never communicated
     assert np.isfinite(m.item_embeddings).all()
+
+
+def test_deterministic_device_inputs_after_rccl_in_process():
+    """every dying process of round 2 had initialised RCCL earlier in its life, and two of them first
+    failed deterministic tests that read freshly built index arrays.  With librccl loaded and a communicator
+    alive in this process: the device-built positives lookup must equal tocsr() + sorted_indices(), long-row
+    in_positives lookups must be right, and a loop of segments + sparse merges must leave a finite model and the
+    same lookup behind (the root cause -- recycled device memory, DESIGN.md -- is fixed by the pool; this test
+    keeps the sequence under watch)."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
+    import lightfm_amd._lightfm_fast as fast
+    from lightfm_amd.lightfm import _Session
+    from tests import helpers as H
+    nu, ni = 500, 2000
+    coo = H.make_interactions(nu, ni, 60000, seed=9)
+    want = coo.tocsr()
+    want.sum_duplicates()
+    want.sort_indices()
+    m = LightFM(no_components=32, loss="warp", random_state=4)
+    m._initialize(32, ni, nu)
+    struct = m._get_lightfm_data()
+    s = _Session(struct, CSRMatrix(H.identity_features(ni)), CSRMatrix(H.identity_features(nu)))
+    try:
+        s.set_interactions(None, np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col), coo.data, coo.data)
+        uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
+        N.check(N.lib().lfm_comm_unique_id(uid))
+        s.comm_init(uid, 0, 1)
+
+        def check_lookup():
+            s.build_positives(nu, ni)
+            indptr, indices = s.download_positives(nu)
+            assert np.array_equal(indptr, want.indptr) and np.array_equal(indices, want.indices)
+
+        check_lookup()
+        n = coo.nnz
+        for e in range(12):
+            s.device_shuffle(70 + e, 3)
+            for b, end in ((0, n // 3), (n // 3, 2 * n // 3), (2 * n // 3, n)):
+                opts, _ = make_opts()
+                opts.history = n * (e + 1)
+                opts.pos_begin, opts.pos_end = b, end
+                s.epoch("warp", 0.0, 0.0, 5, 10, np.array([90 + e], np.uint32), opts)
+                s.comm_merge_sparse(1, N.MERGE_ADAGRAD, overlap=(e % 2 == 1))
+            s.comm_merge_flush()
+            assert s.check_finite()
+            if e % 4 == 3:
+                check_lookup()
+        s.sync_to_host(struct)
+        assert np.isfinite(m.item_embeddings).all() and np.isfinite(m.user_embeddings).all()
+    finally:
+        s.close()
+    # long rows: every member of the longest row is found, its neighbours' gaps are not
+    pos = CSRMatrix(want.astype(np.float32))
+    u = int(np.argmax(np.diff(want.indptr)))
+    row = want.indices[want.indptr[u]:want.indptr[u + 1]]
+    for col in (int(row[0]), int(row[len(row) // 2]), int(row[-1])):
+        assert fast.__dict__["__test_in_positives"](u, col, pos)
+    missing = np.setdiff1d(np.arange(ni), row)
+    for col in (int(missing[0]), int(missing[len(missing) // 2]), int(missing[-1])):
+        assert not fast.__dict__["__test_in_positives"](u, col, pos)
