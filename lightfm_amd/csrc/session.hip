@@ -1672,7 +1672,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         // release/acquire) of at most `slice` positions; while the ramp is still below the chip's
         // residency a launch covers 64 passes of its wavefronts, so the ramp costs milliseconds.
         int L = opts->launches_per_epoch;
-        if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 20) - 1) >> 20));
+        // 2 Mi positions per launch: a launch costs ~75 us beyond its passes (its wavefronts start in lockstep
+        // and drain unevenly) -- C2 at 20 launches of 1 Mi per epoch ran 1.04 G interactions/s, at 10 launches
+        // 1.14 G/s, at 5 launches 1.17 G/s (round 3; precision@10 of 3 seeds unchanged at 10).  What a boundary
+        // still gives: fresh bias snapshots for the tile kernel's scoring and the regularisation folds.
+        if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 21) - 1) >> 21));
         const int64_t slice = std::max<int64_t>(1, (s->n + L - 1) / L);
         const size_t generic_smem = smem;
         const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);
@@ -1949,6 +1953,16 @@ extern "C" int lfm_session_predict(lfm_session *s, const int32_t *user_ids, cons
     return dout.download(predictions);
 }
 
+// flag := 1 if a row of the CSR has a column index below its predecessor
+__global__ void rows_sorted_kernel(const int32_t *indptr, const int32_t *indices, int32_t rows, int *flag)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t r = t; r < rows; r += st)
+        for (int32_t j = indptr[r] + 1; j < indptr[r + 1]; ++j) bad |= indices[j] < indices[j - 1];
+    if (bad) atomicOr(flag, 1);
+}
+
 extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, const lfm_csr *train, float *ranks)
 {
     if (!s || !ranks) return fail(LFM_EINVAL, "null argument");
@@ -1999,13 +2013,16 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
     // the MFMA sweeps mask train positives by walking each user's train row alongside the item tiles: they
     // need ascending column indices (tocsr() of a COO gives them; a CSR handed in by the caller may not).
-    // Unsorted rows run the scalar kernel, whose lookup does not care.
-    if (mfma_mode != 0) {
-        bool sorted = true;
-        for (int32_t u = 0; u < train->rows && sorted; ++u)
-            for (int32_t j = train->indptr[u] + 1; j < train->indptr[u + 1]; ++j)
-                if (train->indices[j] < train->indices[j - 1]) { sorted = false; break; }
-        if (!sorted) mfma_mode = 0;
+    // Unsorted rows run the scalar kernel, whose lookup is the reference's binary search.  Checked on the
+    // device (the host loop over ML-20M's 18 M train entries cost 15 ms per call).
+    if (mfma_mode != 0 && train->nnz > 1) {
+        int unsorted = 0;
+        HIP_TRY(hipMemsetAsync(s->flag.p, 0, sizeof(int), s->stream));
+        rows_sorted_kernel<<<(int)std::min<int64_t>(4096, ((int64_t)train->rows + 255) / 256), 256, 0, s->stream>>>(
+            dtrain.indptr.p, dtrain.indices.p, train->rows, s->flag.p);
+        HIP_TRY(hipMemcpyAsync(&unsorted, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (unsorted) mfma_mode = 0;
     }
     a.work = nullptr;
     a.n_work = 0;
