@@ -103,7 +103,9 @@ typedef struct lfm_opts {
                                    the register-staged variant of the 4-per-pass tile kernel instead of
                                    the LDS-DMA one (global_load_lds_dwordx4); bit 0 with the profiling
                                    builds: drain the memory counters at every phase stamp; bit 5 (32):
-                                   no bias snapshots */
+                                   no bias snapshots; bit 7 (128): consecutive full-size launches on ONE stream
+                                   (default: two streams alternately, so that a launch's draining tail is
+                                   filled by the next launch's workgroups) */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 / feat_kernel = 2 (profiling builds): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator

@@ -363,7 +363,9 @@ struct lfm_session {
     DBuf<int32_t> user_ids, item_ids;
     DBuf<float> Y, weight;
     bool weight_aliases_Y = false;
-    DBuf<float> bias_snap[2];  // per-launch cached copies of the bias tables (tile kernel scoring)
+    DBuf<float> bias_snap[2][2];  // per-launch cached copies of the bias tables (tile kernel scoring): [side][launch parity]
+    hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
     bool recs_valid = false;
     int64_t n = 0;
@@ -404,6 +406,12 @@ struct lfm_session {
         // the buffers go back to the pool without any implicit synchronisation (hipFree had one)
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto *s : shuffles) delete s;
+        if (stream2) {
+            (void)hipStreamSynchronize(stream2);
+            (void)hipStreamDestroy(stream2);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (comm_stream) (void)hipStreamSynchronize(comm_stream);
         if (comm && rccl()) rccl()->CommDestroy(comm);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -1681,7 +1689,18 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         const size_t generic_smem = smem;
         const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);
         if (snap_biases)
-            for (int side = 0; side < 2; ++side) LFM_TRY(s->bias_snap[side].alloc(tab_count(s, side, 3)));
+            for (int side = 0; side < 2; ++side)
+                for (int par = 0; par < 2; ++par) LFM_TRY(s->bias_snap[side][par].alloc(tab_count(s, side, 3)));
+        // Consecutive full-residency launches go to two streams alternately: the wavefronts of a launch finish
+        // unevenly (same number of passes each, passes of different length: a tail of ~100 us in which the chip
+        // drains), and the next launch's workgroups, already queued on the other stream, take the slots as they
+        // free up.  Residency -- hence the interactions in flight -- is what it was.  Not with lazy regularisation
+        // (its boundary kernels order the launches) and not below residency (the ramp).  debug bit 7 (128) disables it.
+        // (nor when the caller fixed the launch plan or asked for plain stores: the bit-exactness tests rely on
+        // one launch seeing the previous one's stores)
+        const bool two_streams = !reg && !(opts->debug & 128) && opts->launches_per_epoch <= 0 && a.update_mode == 0;
+        bool forked = false;
+        int n_full = 0;
         FitArgs base = a;
         // [pos_begin, pos_end): one segment of the epoch (multi-GPU driver), default the whole epoch
         const int64_t seg_begin = std::max<int64_t>(0, std::min<int64_t>(opts->pos_begin, s->n));
@@ -1747,6 +1766,24 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         (const void *)a.user_ids, (const void *)a.item_ids, (const void *)a.Y, (const void *)a.weight,
                         (const void *)a.pos.indptr, (const void *)a.pos.indices, (void *)a.m.W[0], (void *)a.m.W[1]);
             int grid_used = grid;
+            hipStream_t lst = s->stream;
+            int par = 0;
+            if (two_streams && !below_residency && !fixed_cap) {
+                par = n_full++ & 1;
+                if (par) {
+                    if (!s->stream2) {
+                        HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+                    }
+                    if (!forked) {  // everything queued so far (shuffle, record packing, the ramp) precedes the second stream
+                        HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+                        HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+                        forked = true;
+                    }
+                    lst = s->stream2;
+                }
+            }
             if (ng) {
                 // Scoring reads twelve 4-byte biases per interaction.  With uncached tables each
                 // is a fabric request; a cached snapshot taken at the launch boundary (the tables
@@ -1759,17 +1796,17 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         const int64_t cnt = (int64_t)tab_count(s, side, 3);
                         if (cnt) {
                             const int cgrid = (int)std::min<int64_t>(1024, (cnt + 255) / 256);
-                            copy_kernel<<<cgrid, 256, 0, s->stream>>>(s->bias_snap[side].p, s->tab[side][3].p, cnt);
+                            copy_kernel<<<cgrid, 256, 0, lst>>>(s->bias_snap[side][par].p, s->tab[side][3].p, cnt);
                         }
-                        a.b_read[side] = s->bias_snap[side].p;
+                        a.b_read[side] = s->bias_snap[side][par].p;
                     }
                 }
-                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, s->stream, s->cus, opts->warp_kernel == 2,
+                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                              &grid_used, tile[ng].dma4));
             }
-            else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, s->stream, s->cus, &grid_used,
+            else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));
-            else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, s->stream, s->cus, &grid_used));
+            else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, lst, s->cus, &grid_used));
             // Lazy L2 regularisation (device.hpp: RegScale): the scales live in s->reg_log while the
             // launch runs; between launches they are folded into the weights when one has passed
             // MAX_REG_SCALE (locked_regularize, PYX:678-691) -- decided on the device, no host round trip.
@@ -1781,6 +1818,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             ++n_launches;
         }
         tile_ng_used = ng_used;
+        if (forked) {  // the second stream joins before anything else of this session runs
+            HIP_TRY(hipEventRecord(s->ev_join, s->stream2));
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+        }
     }
     if (reg) HIP_TRY(launch_regularize(a.m, serial ? nullptr : s->reg_log.p, serial ? nullptr : s->reg_live.p, 1, s->stream));  // PYX:910-912
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
