@@ -443,6 +443,10 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
                 "algorithmic_bytes_per_interaction": alg / max(1.0, counters[0]),
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches / n_epochs,
+                "avg_launch_note": "HIP events around each epoch's launches on the session's stream / launches.  Consecutive "
+                                   "full-size launches alternate between two streams and overlap by the earlier one's draining "
+                                   "tail: rocprofv3's per-kernel durations include that wait; the union of their intervals / "
+                                   "launches (profiles/*_kernel_stats.txt) is the comparable figure",
                 "kernel_time_fraction_of_step": kernel_s / elapsed,
                 "interactions_per_wavefront_pass": ng, "interactions_in_flight": int(stats[-1].in_flight),
                 "draws_per_interaction": counters[1] / max(1.0, counters[0]),

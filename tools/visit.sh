@@ -118,8 +118,10 @@ PY
   done
   ;;
 final)
-  # the driver's sequence: suite (twice), smoke, default bench; then rocprofv3 trace + PMC of c2 / c3 / c4shard
-  for i in 1 2; do
+  # the driver's sequence: suite (N times, default 2), smoke, default bench; then rocprofv3 trace + PMC of the
+  # configs named after N (default c2 c3 c4shard):   tools/visit.sh final [N [cfg ...]]
+  NS=${1:-2}; shift; CFGS=${*:-c2 c3 c4shard}
+  for i in $(seq 1 $NS); do
     timeout -k 5 1200 $PYT tests -m gpu -x -q > $OUT/suite_$i.log 2>&1
     echo "suite run $i: exit $?  $(grep -aE ' passed| failed' $OUT/suite_$i.log | tail -1)"; summ $OUT/suite_$i.log 8
   done
@@ -141,7 +143,7 @@ try:
 except Exception as e:
     print("  no result:", e)
 PY
-  for cfg in c2 c3 c4shard; do bash tools/profile2.sh r03_$cfg --config $cfg; done
+  for cfg in $CFGS; do bash tools/profile2.sh r03_$cfg --config $cfg; done
   cp $R/profiles/r03_c*_kernel_stats.txt $R/profiles/r03_c*_pmc_summary.json $OUT/ 2>/dev/null
   ;;
 r3c)
