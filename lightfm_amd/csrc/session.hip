@@ -1768,7 +1768,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             int grid_used = grid;
             hipStream_t lst = s->stream;
             int par = 0;
-            if (two_streams && !below_residency && !fixed_cap) {
+            // (tile kernel only: its grid IS the hardware's residency.  The row-stream and generic kernels are launched
+            // with fewer workgroups than would fit -- 8 wavefronts per CU publish fastest -- and two of their launches
+            // side by side would double the interactions in flight: C3 fell from 42.5 to 37.6 M interactions/s)
+            if (two_streams && ng && !below_residency && !fixed_cap) {
                 par = n_full++ & 1;
                 if (par) {
                     if (!s->stream2) {
