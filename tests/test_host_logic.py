@@ -183,3 +183,52 @@ def test_merge_plan_hot_rows_and_full_merges():
     # BASELINE shapes: C3's 1 128 tag rows are hot, C5's hashed feature rows (80 items each of 10 M) are not
     assert len(hot_rows(synthetic.tag_item_features(26744), pol.hot_share)) == 1128
     assert len(hot_rows(synthetic.hashed_item_features(200_000, n_cols=20_000), pol.hot_share)) == 0
+
+
+def test_weight_array_signature_sees_edits_moves_and_reassignment():
+    """LightFM._array_signature guards the device-resident scoring session: a single-cell edit, a swap of two
+    rows (same multiset of values), a swap of two columns and a re-assigned array must all change it; an
+    untouched array must not."""
+    from lightfm_amd import LightFM
+    rng = np.random.RandomState(0)
+    a = rng.randn(500, 32).astype(np.float32)
+    sig = LightFM._array_signature(a)
+    assert LightFM._array_signature(a) == sig
+    b = a.copy()
+    assert LightFM._array_signature(b) != sig            # another object, even with equal content
+    assert LightFM._array_signature(b)[3:] == sig[3:]    # ... whose content part agrees
+    a[17, 5] = np.nextafter(a[17, 5], np.float32(9))     # one ulp, in place
+    assert LightFM._array_signature(a)[3:] != sig[3:]
+    a[17, 5] = b[17, 5]
+    assert LightFM._array_signature(a) == sig
+    a[[3, 4]] = a[[4, 3]]                                # rows swapped in place
+    assert LightFM._array_signature(a)[3:] != sig[3:]
+    a[[3, 4]] = a[[4, 3]]
+    a[:, [0, 1]] = a[:, [1, 0]]                          # columns swapped in place
+    assert LightFM._array_signature(a)[3:] != sig[3:]
+    v = rng.randn(777).astype(np.float32)                # odd length, one-dimensional (biases)
+    sv = LightFM._array_signature(v)
+    v[-1] += 1.0
+    assert LightFM._array_signature(v)[3:] != sv[3:]
+    assert LightFM._array_signature(np.zeros((0, 8), np.float32))[2:] == (0, 0.0)
+
+
+def test_committed_traffic_feeds_the_roofline():
+    """bench.py copies roofline.traffic from profiles/traffic.json when the run's dominant kernel is the profiled
+    one: the committed file must name the kernels the default configurations actually launch."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_traffic", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    names = {"c2": "fit_warp_tile_kernel<16, 4, false, false, true, false>",
+             "c4shard": "fit_warp_tile_kernel<16, 4, false, false, true, false>",
+             "c3": "fit_feat_kernel<2, 2, false, false>"}
+    for cfg, kernel in names.items():
+        assert os.path.exists(os.path.join(root, table[cfg]["source"]))
+        value, source = bench.committed_traffic(cfg, kernel)
+        assert value is not None and value > 1e9 and source == table[cfg]["source"], (cfg, value, source)
+    value, why = bench.committed_traffic("c2", "fit_warp_kernel (generic)")
+    assert value is None and "this run's kernel" in why
+    assert bench.committed_traffic("c5shard", "fit_feat_kernel<3, 2, false, false>")[0] is None
