@@ -183,7 +183,12 @@ class DistributedFit(object):
     """
 
     def __init__(self, model, interactions, rank, world, device=0, dist=None, policy=None,
-                 host_shuffle=False):
+                 host_shuffle=False, bounds=None, global_n=None):
+        """interactions: the WHOLE interaction matrix (every rank cuts its own user range from it,
+        boundaries planned from the row counts) -- or, with `bounds` and `global_n`, only THIS rank's
+        rows of it: a matrix of the full shape whose entries all lie in users [bounds[rank],
+        bounds[rank + 1]) (a rank of a large job loads its range from its own data source; bounds =
+        the user boundaries of all ranks, global_n = interactions of all ranks together)."""
         from ._lightfm_fast import CSRMatrix, FastLightFM
         from .lightfm import _Session, _WEIGHTS
         self.model, self.rank, self.world, self.dist = model, rank, world, dist
@@ -193,9 +198,20 @@ class DistributedFit(object):
         coo = sp.coo_matrix((np.ascontiguousarray(coo.data, dtype=np.float32),
                              (np.ascontiguousarray(coo.row, dtype=np.int32),
                               np.ascontiguousarray(coo.col, dtype=np.int32))), shape=coo.shape)
-        shard, self.bounds = local_shard(coo, rank, world, rebase=True)
+        if bounds is not None:
+            if global_n is None:
+                raise ValueError("a pre-cut shard needs global_n (interactions of all ranks together)")
+            bounds = np.asarray(bounds, dtype=np.int64)
+            if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != coo.shape[0] or np.any(np.diff(bounds) < 0):
+                raise ValueError("bounds must be the %d user boundaries 0 = b[0] <= ... <= b[world] = n_users" % (world + 1))
+            if coo.nnz and (coo.row.min() < bounds[rank] or coo.row.max() >= bounds[rank + 1]):
+                raise ValueError("a pre-cut shard may only hold users of this rank's range")
+            shard, self.bounds = local_shard(coo, rank, world, bounds=bounds, rebase=True)
+            self.global_n = int(global_n)
+        else:
+            shard, self.bounds = local_shard(coo, rank, world, rebase=True)
+            self.global_n = int(coo.nnz)
         self.shard = shard
-        self.global_n = int(coo.nnz)
         n_users, n_items = coo.shape
         if model.item_embeddings is None:
             model._initialize(model.no_components, n_items, n_users)

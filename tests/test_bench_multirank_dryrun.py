@@ -149,7 +149,7 @@ def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling):
     assert "GPUs" in line["config"]["parallelism"] and "rows touched" in line["config"]["parallelism"]
 
 
-def _fit_worker(rank, world, port, out):
+def _fit_worker(rank, world, port, out, precut=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -215,7 +215,16 @@ def _fit_worker(rank, world, port, out):
         N.check = lambda rc: rc
         data = synthetic.make_interactions(400, 300, 20000, seed=3).astype(np.float64)  # wrong dtype on purpose
         model = LightFM(no_components=8, loss="warp", random_state=5)
-        fit = DistributedFit(model, data, rank, world, device=rank, dist=dist)
+        if precut:
+            # a rank that only holds its own users' rows (its range of a large job's data source)
+            from lightfm_amd.distributed import local_shard, plan_row_shards
+            coo = data.tocoo()
+            bounds = plan_row_shards(np.bincount(coo.row, minlength=coo.shape[0]), world)
+            mine, _ = local_shard(coo, rank, world, bounds=bounds)
+            assert 0 < mine.nnz < coo.nnz
+            fit = DistributedFit(model, mine, rank, world, device=rank, dist=dist, bounds=bounds, global_n=coo.nnz)
+        else:
+            fit = DistributedFit(model, data, rank, world, device=rank, dist=dist)
         before = model.user_embeddings.copy()
         fit.run(epochs=2)
         fit.gather_users()
@@ -228,14 +237,15 @@ def _fit_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_distributed_fit_control_flow_two_ranks(tmp_path):
+@pytest.mark.parametrize("precut", [False, True])
+def test_distributed_fit_control_flow_two_ranks(tmp_path, precut):
     """DistributedFit (the class a multi-GPU user drives) with a stand-in session: dtype coercion of the
     interactions, disjoint contiguous user ranges covering every user, every local position trained once per
     epoch, the same number of merges on both ranks, and gather_users() delivering the other rank's rows."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     out = str(tmp_path / "fit%d.json")
-    mp.spawn(_fit_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_fit_worker, args=(world, port, out, precut), nprocs=world, join=True)
     got = [json.load(open(out % r)) for r in range(world)]
     assert got[0]["log"]["merge"] == got[1]["log"]["merge"] > 2
     assert got[0]["range"][0] == 0 and got[0]["range"][1] == got[1]["range"][0] and got[1]["range"][1] == 400
