@@ -1855,7 +1855,6 @@ extern "C" int lfm_session_check_finite(lfm_session *s)
 {
     if (!s) return fail(LFM_EINVAL, "null session");
     HIP_TRY(hipSetDevice(s->device));
-    LFM_TRY(complete_pending(s));  // an overlapped merge still in flight lands before the tables are read
     HIP_TRY(hipMemsetAsync(s->flag.p, 0, sizeof(int), s->stream));
     for (int side = 0; side < 2; ++side) {
         HIP_TRY(launch_nonfinite(s->tab[side][0].p, (int64_t)tab_count(s, side, 0), s->flag.p, s->stream));
@@ -1873,7 +1872,6 @@ extern "C" int lfm_session_sync_to_host(lfm_session *s, lfm_model *model)
     if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
         return fail(LFM_EINVAL, "model shape differs from the session's");
     HIP_TRY(hipSetDevice(s->device));
-    LFM_TRY(complete_pending(s));  // an overlapped merge still in flight lands first
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int side = 0; side < 2; ++side)
         for (int k = 0; k < 6; ++k)
