@@ -90,11 +90,11 @@ typedef struct lfm_opts {
                                        is lost (DESIGN.md "Hogwild at GPU width")              */
     int32_t feat_kernel;        /* parallel mode, models the lane-group tile kernel does not cover
                                    (feature CSRs, BPR, k-OS, logistic): 0 = auto (the pipelined
-                                   row-stream kernels, csrc/feat_kernel.hpp, when d <= 128 and
-                                   alpha == 0), 1 = force the generic kernels, 2 = row-stream kernels
+                                   row-stream kernels, csrc/feat_kernel.hpp, for adagrad models with
+                                   d <= 128, d % 4 == 0, any alpha), 1 = force the generic kernels, 2 = row-stream kernels
                                    instrumented with per-phase cycle counters (BPR / k-OS, d > 64) */
-    int32_t warp_kernel;        /* parallel-mode WARP with identity features and no
-                                   regularisation: 0 = auto (the lane-group tile kernel,
+    int32_t warp_kernel;        /* parallel-mode WARP with identity features (any alpha; adadelta only
+                                   without regularisation): 0 = auto (the lane-group tile kernel,
                                    csrc/warp_tile.hip, when d % 4 == 0 and d <= 128),
                                    1 = do not use the tile kernel (the row-stream or generic kernels run),
                                    2 = tile kernel instrumented with per-phase cycle counters */
