@@ -232,3 +232,55 @@ def test_committed_traffic_feeds_the_roofline():
     value, why = bench.committed_traffic("c2", "fit_warp_kernel (generic)")
     assert value is None and "this run's kernel" in why
     assert bench.committed_traffic("c5shard", "fit_feat_kernel<3, 2, false, false>")[0] is None
+
+
+def test_evaluation_reductions_match_the_sparse_matrix_formulation():
+    """lightfm_amd.evaluation reduces the rank CSR's value array with segmented ufunc reductions; the reference
+    (lightfm/evaluation.py:14-327) does the same with sparse-matrix operations.  Same values and dtypes, with
+    and without preserve_rows, with a user without test interactions -- on a stand-in model (no device)."""
+    import scipy.sparse as sp
+    from lightfm_amd import evaluation as E
+    rng = np.random.RandomState(0)
+    test = sp.random(60, 40, density=0.1, format="lil", random_state=1, dtype=np.float32)
+    test[7] = 0
+    test[59] = 0
+    test = test.tocsr()
+    test.eliminate_zeros()
+    test.data[:] = 1
+    rank_values = rng.randint(0, 40, size=test.nnz).astype(np.float32)
+
+    class Model(object):
+        def predict_rank(self, t, **kw):
+            return sp.csr_matrix((rank_values.copy(), t.indices, t.indptr), shape=t.shape)
+
+    m, has = Model(), test.getnnz(axis=1) > 0
+
+    def precision(k, preserve):
+        r = m.predict_rank(test)
+        r.data = np.less(r.data, k, r.data)
+        p = np.squeeze(np.array(r.sum(axis=1))) / k
+        return p if preserve else p[has]
+
+    def recall(k, preserve):
+        r = m.predict_rank(test)
+        r.data = np.less(r.data, k, r.data)
+        hit, relevant = np.squeeze(np.array(r.sum(axis=1))), np.squeeze(test.getnnz(axis=1))
+        if not preserve:
+            hit, relevant = hit[has], relevant[has]
+        with np.errstate(all="ignore"):
+            return hit / relevant
+
+    def reciprocal(preserve):
+        r = m.predict_rank(test)
+        r.data = 1.0 / (r.data + 1.0)
+        x = np.squeeze(np.array(r.max(axis=1).todense()))
+        return x if preserve else x[has]
+
+    for preserve in (False, True):
+        for got, want in ((E.precision_at_k(m, test, k=5, preserve_rows=preserve), precision(5, preserve)),
+                          (E.recall_at_k(m, test, k=5, preserve_rows=preserve), recall(5, preserve)),
+                          (E.reciprocal_rank(m, test, preserve_rows=preserve), reciprocal(preserve))):
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True)
+    with pytest.raises(ValueError):
+        E.precision_at_k(m, test, num_threads=0)
