@@ -129,6 +129,10 @@ typedef struct lfm_opts {
                                    an epoch as segments with a merge of the replicated tables
                                    between them (lfm_session_comm_merge); `history` must then count
                                    the positions of earlier segments too                        */
+    int32_t streams_used;       /* out: HIP streams the epoch's launches were spread over: 2 when consecutive
+                                   full-residency launches of the tile kernel alternated between the session's
+                                   two streams (see `debug` bit 7), else 1                                      */
+    int32_t reserved0;          /* (keeps the struct's size a multiple of 8 explicit) */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -102,6 +102,7 @@ def _record(o, logs):
     options.last_kernel_ms = float(o.kernel_ms)
     options.last_kernel_used = int(o.kernel_used)
     options.last_launches = int(o.launches)
+    options.last_streams_used = int(o.streams_used)
     options.last_phase_cycles = list(o.phase_cycles)
     options.last_logs = logs
 

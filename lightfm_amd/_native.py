@@ -51,7 +51,8 @@ class LfmOpts(C.Structure):
                 ("phase_cycles", C.c_int64 * 8), ("tile_ng", C.c_int32), ("in_flight", C.c_int32),
                 ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32),
                 ("kernel_used", C.c_int32), ("shared_cap", C.c_int32),
-                ("pos_begin", C.c_int64), ("pos_end", C.c_int64)]
+                ("pos_begin", C.c_int64), ("pos_end", C.c_int64),
+                ("streams_used", C.c_int32), ("reserved0", C.c_int32)]
 
 
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)

@@ -1668,6 +1668,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const int64_t reg_len_cap = !reg ? INT64_MAX : (int64_t)std::max(256.0, std::max(
         std::min(1e12, 0.5 / std::max(reg_step, 1e-300)), std::min(65536.0, 55.0 / std::max(reg_step, 1e-300))));
     int in_flight = 1, tile_ng_used = 0, n_launches = 0;
+    bool used_second_stream = false;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
         int T = needs_rng ? n_seeds : 1;
@@ -1786,6 +1787,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         forked = true;
                     }
                     lst = s->stream2;
+                    used_second_stream = true;
                 }
             }
             if (ng) {
@@ -1841,6 +1843,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     opts->kernel_used = tile_ng_used ? 1 : (use_feat ? 2 : 0);
     opts->in_flight = in_flight;
     opts->launches = n_launches;
+    opts->streams_used = used_second_stream ? 2 : 1;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));

@@ -61,6 +61,7 @@ class _Options(object):
         self.last_kernel_ms = None
         self.last_kernel_used = None  # 0 generic kernels, 1 lane-group tile kernel, 2 row-stream kernels
         self.last_launches = None
+        self.last_streams_used = None
         self.last_phase_cycles = None
         self.last_logs = None
 

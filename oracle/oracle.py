@@ -47,6 +47,7 @@ def build(force=False):
         subprocess.check_call(["make", "-C", HERE, "liblfm_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.exists(REF_SRC):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", HERE, "pysuite"], stdout=subprocess.DEVNULL)
 
 
 _lib = None

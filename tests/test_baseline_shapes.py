@@ -1,0 +1,182 @@
+"""Exact parity AT THE BASELINE SHAPES (BASELINE.json configs[0] / configs[1]), under the launch plan
+that ships -- the holes the small-shape suites leave (round-3 verdict):
+
+  * C2 shape (138,493 users x 26,744 items, d = 64, max_sampled = 10, 5 M interactions): the tile
+    kernel with the DEFAULT launch plan -- launches_per_epoch = 0 (2 Mi positions per launch), the
+    concurrency ramp off (`ramp_k = -1`: the first launch already runs at full residency, 12 288
+    interactions in flight), consecutive launches on the session's two streams, bias snapshots of
+    both parities, the epoch's order built by the DEVICE shuffle.  Weights are frozen with
+    sample_weight = 0 (the reference's own trick, tests/test_movielens.py:517-533 of the
+    reference): every position's (negative, sampled) then depends only on its own PRNG stream, so
+    the chosen negatives ("WARP rank indices") and sample counts of all 5 M positions and the four
+    device counters must EQUAL the CPU oracle's (PYX:855-899), whatever the concurrency.
+  * predict_ranks at 6,000 users x 26,744 items, d = 64: the default MFMA pre-filter + sequential
+    re-check against the CPU ORACLE (PYX:1232-1323), not against another HIP kernel.
+  * C1 (ML-100k shape, d = 32, 10 epochs, WARP): serial mode through the public LightFM API against
+    the reference's own compiled extension (oracle/_ref/strict) driven by the same host class: all
+    12 arrays bit for bit (north star: 1e-4 relative), and precision@10 of the two models equal.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ML20M_USERS, ML20M_ITEMS = 138493, 26744
+
+
+def _need_gpu():
+    from lightfm_amd import _native
+    assert _native.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+
+
+def _spread(st, rng):
+    """Scores with a standard deviation of ~3 and non-trivial biases: the margin test (PYX:875)
+    sees both outcomes and the sample counts cover 1..max_sampled."""
+    a = 3.0 / st.d ** 0.25
+    st.item_embeddings *= 2 * st.d * a
+    st.user_embeddings *= 2 * st.d * a
+    st.item_biases[:] = rng.randn(len(st.item_biases)).astype(np.float32) * 0.3
+    st.user_biases[:] = rng.randn(len(st.user_biases)).astype(np.float32) * 0.3
+
+
+def test_c2_shape_default_launch_plan_samples_exact():
+    _need_gpu()
+    from lightfm_amd import synthetic
+    from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
+    from lightfm_amd.lightfm import _Session
+    from lightfm_amd.options import options
+    nu, ni, d = ML20M_USERS, ML20M_ITEMS, 64
+    coo = synthetic.make_interactions(nu, ni, 5_000_000, seed=42)
+    n = coo.nnz
+    assert n >= 4_900_000
+    rng = np.random.RandomState(9)
+    st = oracle.State(ni, nu, d, rng, max_sampled=10)
+    _spread(st, rng)
+    a, b = st.copy(), st.copy()
+    zeros = np.zeros_like(coo.data)  # frozen weights
+    seeds = rng.randint(0, np.iinfo(np.int32).max, size=1).astype(np.uint32)
+    item_f, user_f = H.identity_features(ni), H.identity_features(nu)
+
+    options.set(mode="parallel", launches_per_epoch=0, ramp_k=-1, max_waves=0, first_batch=0, warp_kernel=0,
+                update_mode=0, debug=0)
+    fl = FastLightFM(*a.arrays(), d, 0, a.lr, a.rho, a.eps, a.max_sampled)
+    session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f))
+    try:
+        rows, cols = np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col)
+        session.set_interactions(None, rows, cols, coo.data, zeros)
+        session.build_positives(nu, ni)  # the device-built lookup, as LightFM.fit_partial uses it
+        session.device_shuffle(1234567, 7654321)
+        shuffle = session.download_shuffle(n)
+        opts, logs = make_opts(n, want_log=True)
+        session.epoch("warp", 0.0, 0.0, 5, 10, seeds, opts)
+        session.sync_to_host(fl)
+    finally:
+        session.close()
+    neg, sampled = logs
+    # the plan that ran is the one bench.py times
+    assert opts.kernel_used == 1 and opts.tile_ng == 4, (opts.kernel_used, opts.tile_ng)
+    assert opts.launches >= 3, opts.launches
+    assert opts.streams_used == 2, "the second stream was not used"
+    assert opts.in_flight >= 256 * 3 * 4 * 4, opts.in_flight  # >= 3 workgroups per CU at full residency
+
+    assert np.array_equal(np.sort(shuffle), np.arange(n, dtype=np.int32))
+    o = oracle.Opts(n, rng_mode=1, log=True)
+    oracle.fit_warp(item_f, user_f, H.positives_csr(coo), coo.row, coo.col, coo.data, zeros, shuffle, b, 0.0, 0.0,
+                    seeds, o)
+    assert np.array_equal(sampled, o.sampled), "sample counts differ at %d positions" % int((sampled != o.sampled).sum())
+    assert np.array_equal(neg, o.neg), "negative (rank) indices differ at %d positions" % int((neg != o.neg).sum())
+    assert list(opts.counters) == o.counters, (list(opts.counters), o.counters)
+    counts = np.bincount(o.sampled, minlength=11)
+    assert counts[1:].min() > 1000, "the case does not exercise every sample count"
+    assert 0.2 * n < o.counters[2] < n, "the case should mix violators and exhausted budgets"
+    H.assert_states_equal(a, st, exact=True)  # loss 0: the atomics added exact zeros
+
+
+def test_predict_ranks_vs_oracle_at_ml20m_items():
+    """The default (MFMA pre-filtered) ranks kernel against the CPU oracle at 26,744 items, d = 64 -- the
+    rounding-band re-check decides ~a few pairs per thousand here."""
+    _need_gpu()
+    from lightfm_amd import synthetic
+    import lightfm_amd._lightfm_fast as fast
+    nu, ni, d = 6000, ML20M_ITEMS, 64
+    full = synthetic.make_interactions(nu, ni, 900_000, seed=43)
+    train, test = synthetic.split_off_test(full, 840_000, seed=2)
+    train = H.positives_csr(train).astype(np.float32)
+    test = test.tocsr().astype(np.float32)
+    test.sort_indices()
+    assert test.multiply(train).nnz == 0
+    rng = np.random.RandomState(21)
+    st = oracle.State(ni, nu, d, rng)
+    _spread(st, rng)
+    item_f, user_f = H.identity_features(ni), H.identity_features(nu)
+    got = np.zeros_like(test.data)
+    Cm = fast.CSRMatrix
+    fl = fast.FastLightFM(*st.arrays(), d, 0, st.lr, st.rho, st.eps, st.max_sampled)
+    fast.predict_ranks(Cm(item_f), Cm(user_f), Cm(test), Cm(train), got, fl, 1)
+    want = np.zeros_like(test.data)
+    oracle.predict_ranks(item_f, user_f, test, train, want, st)
+    assert want.max() > ni // 2 and want.min() < 50
+    assert np.array_equal(got, want), "%d of %d ranks differ" % (int((got != want).sum()), len(want))
+
+    # a FRESH model (all scores within a few ulp of each other: every pair falls inside the rounding band)
+    nu0 = 400
+    st0 = oracle.State(ni, nu0, d, np.random.RandomState(3))
+    sub, sub_train = test[:nu0], train[:nu0]
+    got0, want0 = np.zeros_like(sub.data), np.zeros_like(sub.data)
+    fl0 = fast.FastLightFM(*st0.arrays(), d, 0, st0.lr, st0.rho, st0.eps, st0.max_sampled)
+    fast.predict_ranks(Cm(item_f), Cm(H.identity_features(nu0)), Cm(sub), Cm(sub_train), got0, fl0, 1)
+    oracle.predict_ranks(item_f, H.identity_features(nu0), sub, sub_train, want0, st0)
+    assert np.array_equal(got0, want0)
+
+
+def _ml100k():
+    """Synthetic data of the ML-100k shape (tests/test_datasets.py:18-19 of the reference: 943 x 1,682,
+    90,570 train + 9,430 test interactions; no MovieLens file is reachable offline), ratings 1..5."""
+    from lightfm_amd import synthetic
+    full = synthetic.make_interactions(943, 1682, 100_000, seed=0, min_per_user=20)
+    rng = np.random.RandomState(0)
+    full.data[:] = rng.choice([1, 2, 3, 4, 5], size=full.nnz, p=[0.06, 0.11, 0.27, 0.34, 0.22]).astype(np.float32)
+    return synthetic.split_off_test(full, full.nnz - 9430, seed=0)
+
+
+def test_c1_ml100k_serial_ten_epochs_bit_exact_vs_reference():
+    """BASELINE configs[0]: ML-100k shape, loss = 'warp', no_components = 32, identity features, 10 epochs.
+    The HIP backend in serial mode and the reference's compiled extension, both driven through the
+    LightFM host class with the same seed, one thread: 12 arrays bit for bit after 10 epochs."""
+    _need_gpu()
+    if not oracle.ref_available("strict"):
+        pytest.skip("oracle/_ref not built")
+    from lightfm_amd import LightFM
+    from lightfm_amd.evaluation import precision_at_k
+    from lightfm_amd.options import options
+    from oracle.ref_model import RefLightFM
+    train, test = _ml100k()
+    assert train.shape == (943, 1682) and test.nnz == 9430 and train.nnz > 80_000
+
+    class Strict(RefLightFM):
+        kind = "strict"
+
+    ref = Strict(no_components=32, loss="warp", random_state=5)
+    ref.fit(train, epochs=10, num_threads=1)
+
+    options.set(mode="serial")
+    hip = LightFM(no_components=32, loss="warp", random_state=5)
+    hip.fit(train, epochs=10, num_threads=1)
+    options.set(mode="parallel")
+
+    for name in oracle.ARRAYS:
+        x, y = getattr(hip, name), getattr(ref, name)
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=0, err_msg=name)  # the north star's bar
+        assert np.array_equal(x, y), "%s: not bit-exact (max abs %g)" % (name, np.abs(x - y).max())
+    assert not np.array_equal(hip.item_embedding_gradients, np.ones_like(hip.item_embedding_gradients))
+
+    # the accuracy the reference's own test pins at this shape (tests/test_movielens.py:127-141 of the
+    # reference: train/test precision@k of a 10-epoch WARP fit): the same number from both models
+    p_hip = precision_at_k(hip, test, train_interactions=train, k=10).mean()
+    p_ref = precision_at_k(ref, test, train_interactions=train, k=10).mean()
+    assert p_hip == p_ref
+    assert p_hip > 0.03  # well above the 10 / 1,682 of random ranking: the model learned
