@@ -14,8 +14,9 @@
 // process.  Blocks that are never returned to the runtime keep their mapping and their memory type
 // for the life of the process: the cached and the uncached pool never exchange memory.
 //
-// A block is reused only for requests of its own (size class, allocation flags).  Size classes are
-// eighths of powers of two (at most 12.5 % of slack), 4 KiB at least.  Releasing a block does NOT
+// A block is reused only for requests of its own allocation flags (memory type) and of its size class or a
+// smaller one down to half its size.  Size classes are eighths of powers of two (at most 12.5 % of slack), 4 KiB
+// at least.  Releasing a block does NOT
 // synchronise anything (hipFree did): owners release after the work that uses the block has been
 // waited for (lfm_session's destructor and every entry point with per-call buffers drain their
 // stream first).
@@ -66,12 +67,16 @@ public:
         const size_t cls = size_class(bytes);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            auto it = free_.find(Key{dev, flags, cls});
-            if (it != free_.end() && !it->second.empty()) {
+            // the smallest cached block of this device and memory type that fits, up to twice the request (calls
+            // of varying size -- predict, predict_rank -- then share blocks instead of leaving one per class behind)
+            for (auto it = free_.lower_bound(Key{dev, flags, cls}); it != free_.end(); ++it) {
+                const Key &k = it->first;
+                if (k.dev != dev || k.flags != flags || k.cls > 2 * cls) break;
+                if (it->second.empty()) continue;
                 *out = it->second.back();
                 it->second.pop_back();
-                cached_bytes_ -= cls;
-                live_[*out] = Key{dev, flags, cls};
+                cached_bytes_ -= k.cls;
+                live_[*out] = k;  // the block keeps its own class
                 return hipSuccess;
             }
         }

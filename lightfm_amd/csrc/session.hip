@@ -353,6 +353,7 @@ struct lfm_session {
     bool scoring_only = false;  // lfm_session_create_scoring: only W and b of both sides are resident
     DBuf<double> scales;      // [2]
     DBuf<double> reg_log;     // [2] parallel mode: log of the regularisation scales at the last launch boundary
+    bool reg_rate_known = false;  // a regularised launch of this session has measured the scales' growth per position
     DBuf<float> reg_live;     // [RegScale::FLOATS] ... and their live state (device.hpp: RegScale), uncached memory
     DBuf<unsigned long long> counters;
     DBuf<uint32_t> seeds;
@@ -1661,7 +1662,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 0, recs_in_use));
     const bool reg = item_alpha != 0.0 || user_alpha != 0.0;
     if (reg && !serial) HIP_TRY(launch_reg_log_init(s->scales.p, s->reg_log.p, s->reg_live.p, s->stream));
-    const double reg_step = log1p(std::max(item_alpha, user_alpha) * (double)std::max(s->lr, 1e-6f));
+    // bound of a position's growth of a log-scale: log1p(alpha * lr_max).  Adagrad rates never exceed the
+    // learning rate (G >= 1); adadelta's sqrt(M + eps) / sqrt(G + eps) is not bounded by it: 1.0 there
+    const double lr_max = s->adadelta ? 1.0 : (double)std::max(s->lr, 1e-6f);
+    const double reg_step = log1p(std::max(item_alpha, user_alpha) * lr_max);
     // accuracy: a growth of <= 0.5 per launch; never below 64 Ki positions for that -- but never so long that
     // the scale could grow by more than e^55 (four virtual folds) either: cells an interaction touches are
     // multiplied by (1 + alpha lr) in place (PYX:433, 446), and only a boundary divides them again
@@ -1758,6 +1762,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // around a per cent -- but not below 64 Ki positions for accuracy's sake: past that alpha the model is
             // flattened whatever the scale's third digit is ("excessive regularisation"; see reg_len_cap).
             if (reg) len = std::min<int64_t>(len, reg_len_cap);
+            // ... and the FIRST regularised launch of a session has no measured rate to extrapolate with (reg_live is
+            // created zeroed; LightFM.fit_partial opens a session per call): its readers see the launch-start scale
+            // throughout, so it is kept to a growth of <= 0.02 -- the launch after it extrapolates from its rate
+            if (reg && !s->reg_rate_known)
+                len = std::min<int64_t>(len, (int64_t)std::max(256.0, std::min(1e12, 0.02 / std::max(reg_step, 1e-300))));
             a.begin = begin;
             a.end = begin + len;
             const int64_t waves = (len + per_wave - 1) / per_wave;
@@ -1816,7 +1825,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // Lazy L2 regularisation (device.hpp: RegScale): the scales live in s->reg_log while the
             // launch runs; between launches they are folded into the weights when one has passed
             // MAX_REG_SCALE (locked_regularize, PYX:678-691) -- decided on the device, no host round trip.
-            if (reg) HIP_TRY(launch_regularize(a.m, s->reg_log.p, s->reg_live.p, 0, s->stream, len));
+            if (reg) {
+                HIP_TRY(launch_regularize(a.m, s->reg_log.p, s->reg_live.p, 0, s->stream, len));
+                s->reg_rate_known = true;
+            }
             begin += len;
             // of the last (largest) launch, after the launcher's residency clamp
             in_flight = (int)std::min<int64_t>((int64_t)grid_used * wpb * per_wave, INT32_MAX);

@@ -4,10 +4,11 @@ One process per GPU.  The interaction matrix is sharded by USER into contiguous 
 balanced by interaction count.  With identity user features a rank holds ONLY its own users'
 rows of the user tables (ids rebased to the range; never communicated); the item tables are
 replicated.  An epoch runs as SEGMENTS of the rank's shuffled shard with a merge of the
-replicated tables after every segment (csrc/session.hip: merge_group_sparse -- the rows touched
-since the last merge, found by OR-ing the ranks' dirty-row maps, travel as packed deltas through
-an RCCL all-reduce over xGMI on a communication stream of their own; the exchange of segment j
-overlaps the kernels of segment j + 1 and lands at the next merge):
+replicated tables after every segment (csrc/session.hip: merge_group_sparse -- the rows that changed
+since the last merge, detected at merge time and OR-ed over the ranks, travel as packed deltas through
+an RCCL all-reduce over xGMI on a communication stream of their own.  The merge is SYNCHRONOUS by
+default; `MergePolicy.overlap` lets the exchange of segment j run under the kernels of segment j + 1
+and land at the next merge, which was measured to cost precision@10 and is off):
 
 * every rank derives the same segment list from global numbers only (`merge_schedule`), so all
   ranks call the collective the same number of times;

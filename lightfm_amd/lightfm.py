@@ -23,7 +23,9 @@ positives lookup on the device (lfm_session_build_positives instead of LFM:365-3
 `tocsr()`), runs every epoch on the GPU (only the keys or the shuffled index list and the seeds
 travel per epoch), checks finiteness on device and copies the weights back at the end.
 """
+import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 import scipy.sparse as sp
@@ -48,9 +50,12 @@ _NOT_FINITE = ("Not all estimated parameters are finite, your model may have div
 class _Session(object):
     """RAII wrapper of lfm_session (include/lfm_hip.h)."""
 
-    def __init__(self, model_struct, item_features, user_features, device=0, scoring=False):
+    def __init__(self, model_struct, item_features, user_features, device=None, scoring=False):
         """scoring=True: only embeddings and biases are uploaded (lfm_session_create_scoring); such a
-        session serves predict / predict_ranks / representations and cannot train."""
+        session serves predict / predict_ranks / representations and cannot train.  device=None: the
+        GPU named by options.device (LIGHTFM_AMD_DEVICE)."""
+        if device is None:
+            device = int(options.device)
         self.handle = C.c_void_p()
         self._keep = (model_struct, item_features, user_features)
         create = N.lib().lfm_session_create_scoring if scoring else N.lib().lfm_session_create
@@ -270,10 +275,17 @@ class LightFM(object):
 
     _SCORED = ("item_embeddings", "item_biases", "user_embeddings", "user_biases")
 
+    def _scoring_lock(self):
+        lock = self.__dict__.get("_scoring_mutex")
+        if lock is None:
+            lock = self.__dict__.setdefault("_scoring_mutex", threading.Lock())
+        return lock
+
     def _drop_scoring_session(self):
-        cached = self.__dict__.pop("_scoring", None)
-        if cached is not None:
-            cached[0].close()
+        with self._scoring_lock():  # never under a predict call that is using it
+            cached = self.__dict__.pop("_scoring", None)
+            if cached is not None:
+                cached[0].close()
 
     @staticmethod
     def _array_signature(a):
@@ -293,25 +305,43 @@ class LightFM(object):
                              np.sin(np.arange(1, rows + 1, dtype=np.float32) * np.float32(0.37))))
         return (id(a), a.__array_interface__["data"][0], a.shape, exact, probe)
 
+    @contextlib.contextmanager
     def _scoring_session(self, item_features, user_features):
-        """A device session holding the current embeddings and biases, with the given feature matrices."""
-        sig = tuple(self._array_signature(getattr(self, name)) for name in self._SCORED)
-        cached = self.__dict__.get("_scoring")
-        if cached is not None and (cached[1] != sig or not options.cache_scoring_session):
-            self._drop_scoring_session()
-            cached = None
+        """A device session holding the current embeddings and biases, with the given feature matrices.
+
+        The cached session is STATE (its resident feature matrices are swapped per call) and ctypes releases
+        the GIL during native calls, so its use is serialised by a per-model lock: the reference's predict is
+        read-only on the model and may be called from several threads (joblib-threaded evaluation, serving).
+        A caller that finds the session busy does not wait: it scores on a one-shot session of its own."""
         itf, usf = CSRMatrix(item_features), CSRMatrix(user_features)
-        if cached is None:
-            session = _Session(self._get_lightfm_data(), itf, usf, scoring=True)
-            if options.cache_scoring_session:
-                self.__dict__["_scoring"] = (session, sig)
-            return session, not options.cache_scoring_session
-        cached[0].set_features(itf, usf)
-        return cached[0], False
+        lock = self._scoring_lock()
+        if options.cache_scoring_session and lock.acquire(False):
+            try:
+                sig = tuple(self._array_signature(getattr(self, name)) for name in self._SCORED)
+                cached = self.__dict__.get("_scoring")
+                if cached is not None and cached[1] != sig:
+                    self.__dict__.pop("_scoring", None)
+                    cached[0].close()
+                    cached = None
+                if cached is None:
+                    cached = (_Session(self._get_lightfm_data(), itf, usf, scoring=True), sig)
+                    self.__dict__["_scoring"] = cached
+                else:
+                    cached[0].set_features(itf, usf)
+                yield cached[0]
+            finally:
+                lock.release()
+            return
+        session = _Session(self._get_lightfm_data(), itf, usf, scoring=True)
+        try:
+            yield session
+        finally:
+            session.close()
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_scoring", None)  # a device handle
+        state.pop("_scoring_mutex", None)
         return state
 
     def __del__(self):
@@ -580,12 +610,8 @@ class LightFM(object):
 
         predictions = np.empty(len(user_ids), dtype=np.float32)
         # predict_lightfm (PYX:1185-1229) on the resident scoring session
-        session, one_shot = self._scoring_session(item_features, user_features)
-        try:
+        with self._scoring_session(item_features, user_features) as session:
             session.predict(np.ascontiguousarray(user_ids), np.ascontiguousarray(item_ids), predictions)
-        finally:
-            if one_shot:
-                session.close()
         return predictions
 
     def _check_test_train_intersections(self, test_mat, train_mat):
@@ -627,12 +653,8 @@ class LightFM(object):
         ranks = sp.csr_matrix((np.zeros_like(test_interactions.data), test_interactions.indices,
                                test_interactions.indptr), shape=test_interactions.shape)
         # predict_ranks (PYX:1232-1323) on the resident scoring session
-        session, one_shot = self._scoring_session(item_features, user_features)
-        try:
+        with self._scoring_session(item_features, user_features) as session:
             session.predict_ranks(CSRMatrix(test_interactions), CSRMatrix(train_interactions), ranks.data)
-        finally:
-            if one_shot:
-                session.close()
         return ranks
 
     # -------------------------------------------------------- representations
@@ -645,12 +667,8 @@ class LightFM(object):
         if features.shape[1] != table.shape[0]:  # what scipy's `features * embeddings` raises
             raise ValueError("dimension mismatch")
         empty = sp.csr_matrix((0, 0), dtype=CYTHON_DTYPE)
-        session, one_shot = self._scoring_session(empty, empty)
-        try:
+        with self._scoring_session(empty, empty) as session:
             return session.representations(side, CSRMatrix(features))
-        finally:
-            if one_shot:
-                session.close()
 
     def get_item_representations(self, features=None):
         """(biases, embeddings) of items, optionally through a feature matrix (LFM:991-1018)."""

@@ -30,11 +30,13 @@ device_shuffle     LightFM.fit_partial, parallel mode: True (default) builds eac
 cache_scoring_session  True (default): LightFM keeps a device session with its embeddings and biases
                    between predict / predict_rank / get_*_representations calls (re-validated by checksum
                    per call, dropped by fit_partial); False: every call uploads them anew.
+device             the GPU LightFM.fit_partial / predict / predict_rank run on (LIGHTFM_AMD_DEVICE, default 0;
+                   DistributedFit and bench.py take theirs from the rank).
 host_positives     True: the positives lookup is built on the host (interactions.tocsr(), LFM:365-372)
                    and uploaded; False (default): built on the device from the uploaded COO.
 
 Environment: LIGHTFM_AMD_MODE, _LAUNCHES, _FIRST_BATCH, _MAX_WAVES, _RAMP_K, _UPDATE_MODE,
-_WARP_KERNEL, _FEAT_KERNEL, _DEBUG, _DEVICE_SHUFFLE; LIGHTFM_AMD_TABLE_ALLOC / _TABLE_ALLOC_MASK select the
+_WARP_KERNEL, _FEAT_KERNEL, _DEBUG, _DEVICE_SHUFFLE, _DEVICE; LIGHTFM_AMD_TABLE_ALLOC / _TABLE_ALLOC_MASK select the
 allocation flavour of the weight tables (csrc/session.hip).
 """
 import os
@@ -53,6 +55,7 @@ class _Options(object):
         self.ramp_k = int(os.environ.get("LIGHTFM_AMD_RAMP_K", "0"))
         self.shared_cap = int(os.environ.get("LIGHTFM_AMD_SHARED_CAP", "0"))
         self.history = 0
+        self.device = int(os.environ.get("LIGHTFM_AMD_DEVICE", "0"))
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.host_positives = os.environ.get("LIGHTFM_AMD_HOST_POSITIVES", "0") != "0"
         self.cache_scoring_session = os.environ.get("LIGHTFM_AMD_CACHE_SCORING", "1") != "0"

@@ -264,3 +264,45 @@ def test_representations_reject_out_of_range_feature_ids(fitted):
     bad.indices, bad.indptr, bad.data = np.array([n_feat + 5], np.int32), np.array([0, 1], np.int32), np.ones(1, np.float32)
     with pytest.raises(ValueError):
         model.get_item_representations(bad)
+
+
+def test_concurrent_predict_with_different_feature_matrices(fitted):
+    """The reference's predict is read-only on the model; threads may share it (joblib-threaded
+    evaluation, serving).  The cached scoring session is state (its feature matrices are swapped per
+    call, ctypes drops the GIL): a per-model lock serialises its use and a caller that finds it busy
+    scores on a one-shot session.  8 threads x 30 calls with per-thread feature matrices must give
+    exactly the single-threaded scores."""
+    import threading
+    model, train, test = fitted
+    model = _fresh_copy(model)
+    nu, ni = test.shape
+    uids = np.repeat(np.arange(nu, dtype=np.int32), ni)
+    iids = np.tile(np.arange(ni, dtype=np.int32), nu)
+    n_feat = model.item_embeddings.shape[0]
+    mats = []
+    for t in range(8):
+        m = sp.random(ni, n_feat, density=0.2, format="csr", random_state=100 + t, dtype=np.float32)
+        mats.append((m + sp.identity(ni, dtype=np.float32, format="csr")[:, :n_feat]).tocsr().astype(np.float32))
+    want = [model.predict(uids, iids, item_features=m) for m in mats]
+    ranks_want = model.predict_rank(test, train_interactions=train).toarray()
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(30):
+                got = model.predict(uids, iids, item_features=mats[t])
+                if not np.array_equal(got, want[t]):
+                    errors.append("thread %d: scores differ" % t)
+                    return
+                if t == 0 and not np.array_equal(model.predict_rank(test, train_interactions=train).toarray(), ranks_want):
+                    errors.append("ranks differ")
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]

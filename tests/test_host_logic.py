@@ -284,3 +284,31 @@ def test_evaluation_reductions_match_the_sparse_matrix_formulation():
             assert np.array_equal(got, want, equal_nan=True)
     with pytest.raises(ValueError):
         E.precision_at_k(m, test, num_threads=0)
+
+
+def test_session_opens_on_the_configured_device(monkeypatch):
+    """options.device (LIGHTFM_AMD_DEVICE) is the GPU LightFM's sessions are created on; an explicit
+    device argument (DistributedFit, bench.py: the rank's GPU) wins."""
+    import lightfm_amd.lightfm as L
+    from lightfm_amd._lightfm_fast import CSRMatrix
+    from lightfm_amd.options import options
+    seen = []
+
+    class FakeLib(object):
+        def lfm_session_create(self, handle, device, *rest):
+            seen.append(device)
+            return 0
+
+        lfm_session_create_scoring = lfm_session_create
+
+        def lfm_session_destroy(self, handle):
+            return 0
+
+    monkeypatch.setattr(L.N, "lib", lambda: FakeLib())
+    m = L.LightFM(no_components=4)
+    m._initialize(4, 3, 2)
+    eye3, eye2 = sp.identity(3, dtype=np.float32, format="csr"), sp.identity(2, dtype=np.float32, format="csr")
+    options.set(device=5)
+    L._Session(m._get_lightfm_data(), CSRMatrix(eye3), CSRMatrix(eye2))
+    L._Session(m._get_lightfm_data(), CSRMatrix(eye3), CSRMatrix(eye2), device=2, scoring=True)
+    assert seen == [5, 2]

@@ -171,6 +171,39 @@ PY
   for cfg in c2 c3 c4shard; do bash tools/profile2.sh r03_$cfg --config $cfg; done
   cp $R/profiles/r03_* $OUT/ 2>/dev/null
   ;;
+r4a)
+  # round 4, first visit: the new exact-parity tests at the BASELINE shapes, the reference's own suite through the shim,
+  # C3 A/B of the round-2 tree (tools/_bin/r2tree, built from commit b0bf975) against the current one at the same
+  # epochs, C5 shard evidence (kernel trace + FETCH/WRITE counters at --scale 0.1; per-phase split at full size)
+  timeout -k 5 900 $PYT tests/test_baseline_shapes.py tests/test_reference_suite.py -m gpu -q -s > $OUT/new_tests.log 2>&1
+  echo "new tests: exit $?  $(grep -aE ' passed| failed' $OUT/new_tests.log | tail -1)"; summ $OUT/new_tests.log 20
+  grep -aE "^E  |differ|assert" $OUT/new_tests.log | cut -c1-300 | head -40
+  S="--no-cpu-baseline --no-quality --no-fit --steps 3 --warmup 1 --epochs-per-step 2 --config c3"
+  for i in 1 2; do
+    ( cd $R/tools/_bin/r2tree && timeout 300 python bench.py $S > $OUT/c3_r2_$i.json 2> $OUT/c3_r2_$i.err )
+    timeout 300 python bench.py $S > $OUT/c3_r3_$i.json 2> $OUT/c3_r3_$i.err
+    for t in r2 r3; do python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/c3_${t}_$i.json")); r = d["roofline"]
+    print("  c3 %s run $i: %8.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  in_flight %s  %s" % ("$t", d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r.get("interactions_in_flight"), d["config"].get("timed_epochs")))
+except Exception as e:
+    print("  c3 $t run $i: no result:", e)
+PY
+    done
+  done
+  TRACE_ONLY= bash tools/profile2.sh r04_c5shard --config c5shard --scale 0.1
+  timeout 400 python bench.py --config c5shard --feat-kernel 2 --no-cpu-baseline --no-quality --no-fit --steps 2 --warmup 1 --epochs-per-step 1 > $OUT/c5_phases.json 2> $OUT/c5_phases.err
+  echo "c5 phases exit $?"; python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/c5_phases.json")); r = d["roofline"]
+    print("  c5shard timed build: %.2f M/s frac %.3f" % (d["value"] / 1e6, r["frac"]), r.get("phase_cycles_per_interaction"))
+except Exception as e:
+    print("  no result:", e)
+PY
+  cp $R/profiles/r04_* $OUT/ 2>/dev/null
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
