@@ -259,7 +259,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     (contract fields + roofline of this config, the pieces the reporting-only legs need)."""
     from lightfm_amd import _native as N
     from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
-    from lightfm_amd.distributed import MergePolicy, hot_rows, merge_plan, segment_positions
+    from lightfm_amd.distributed import DistributedFit, MergePolicy
     from lightfm_amd.lightfm import LightFM, _Session
     from lightfm_amd.options import options
     args, rank, world, dist, log = env.args, env.rank, env.world, env.dist, env.log
@@ -301,79 +301,32 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     loss, d = cfg["loss"], cfg["d"]
     n_item_feat = feats.shape[1] if feats is not None else n_items
 
-    model = LightFM(no_components=d, loss=loss, random_state=10 + rank, max_sampled=MAX_SAMPLED)
-    model._initialize(d, n_item_feat, n_users)
-    if world > 1:  # replicated item tables start identical on every rank
-        import torch
-        dist.broadcast(torch.from_numpy(model.item_embeddings), src=0)
-    item_f = feats if feats is not None else sp.identity(n_items, dtype=np.float32, format="csr")
-    user_f = sp.identity(n_users, dtype=np.float32, format="csr")
-    fl = model._get_lightfm_data()
-    session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f), device=env.local_rank)
+    # The epoch loop is the product's: lightfm_amd.distributed.DistributedFit (at N = 1 an epoch of it is exactly an
+    # epoch of LightFM.fit_partial: device shuffle, seeds, one lfm_session_epoch, the on-device finite check; at
+    # N > 1 segments + RCCL merges of the replicated tables, hot rows at their own cadence).  This rank's shard
+    # carries LOCAL user ids, and only its own users' rows exist anywhere (host or device).
+    model = LightFM(no_components=d, loss=loss, random_state=10 + rank, max_sampled=MAX_SAMPLED,
+                    item_alpha=args.item_alpha, user_alpha=args.user_alpha)
+    policy.sparse = not args.merge_dense
+    fit = DistributedFit(model, train, rank, world, device=env.local_rank, dist=dist, policy=policy,
+                         global_n=global_n, item_features=feats, local_ids=True)
+    session = fit.session
+    hot = fit.hot[0]
     rows = np.ascontiguousarray(train.row, dtype=np.int32)
-    cols = np.ascontiguousarray(train.col, dtype=np.int32)
-    vals = np.ascontiguousarray(train.data, dtype=np.float32)
-    session.set_interactions(None, rows, cols, vals, vals)
-    session.build_positives(n_users, n_items)
-    if world > 1:
-        uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
-        if rank == 0:
-            N.check(N.lib().lfm_comm_unique_id(uid))
-        import torch
-        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-        dist.broadcast(t, src=0)
-        session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()), N.UNIQUE_ID_BYTES), rank, world)
-    hot = hot_rows(feats, policy.hot_share) if world > 1 else []
-    if len(hot):  # shared feature rows (C3's tags): merged at the short cadence between the full merges
-        session.set_hot_rows(0, hot)
     log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))
 
     n_local = train.nnz
-    state = {"history": 0, "merges": 0, "merge_bytes": 0}
     all_stats = []
-    n_repl_rows = n_item_feat  # rows of the replicated (item-side) tables: sets the longest merge interval
 
     def epoch():
-        """What LightFM.fit_partial / DistributedFit.run do per epoch."""
-        keys = model.random_state.randint(0, np.iinfo(np.int32).max, size=624)
-        session.device_shuffle(int(keys[0]), int(keys[1]))
-        seeds = np.ascontiguousarray(model.random_state.randint(
-            0, np.iinfo(np.int32).max, size=1).astype(np.uint32))
-        if world == 1:
-            opts, _ = make_opts()
-            opts.history = state["history"]
-            session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
-            all_stats.append(opts)
-        else:
-            fr, kinds = merge_plan(state["history"], global_n, world, policy, n_repl_rows, len(hot) > 0)
-            pos = segment_positions(fr, n_local)
-            for j in range(len(pos) - 1):
-                opts, _ = make_opts()
-                opts.history = (state["history"] + int(round(global_n * pos[j] / max(1, n_local)))) // world
-                opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
-                if pos[j + 1] > pos[j]:
-                    session.epoch(loss, args.item_alpha, args.user_alpha, 5, 10, seeds, opts)
-                    all_stats.append(opts)
-                if args.merge_dense:
-                    if kinds[j] == "full":
-                        session.comm_merge(1, policy.mode_id())
-                elif kinds[j] == "hot":
-                    state["merge_bytes"] += session.comm_merge_hot(1, policy.mode_id(), policy.overlap)
-                else:
-                    state["merge_bytes"] += session.comm_merge_sparse(1, policy.mode_id(), policy.overlap)
-                state["merges"] += 1
-            if not args.merge_dense:
-                session.comm_merge_flush()
-        state["history"] += global_n if world > 1 else n_local
-        bad = not session.check_finite()
-        if world > 1:
-            bad = session.comm_any(bad)
-        if bad:
+        try:
+            all_stats.extend(fit.epoch())
+        except ValueError:
             raise SystemExit("model diverged")
 
     def barrier():
         if world > 1:
-            session.comm_barrier()
+            fit.barrier()
             dist.barrier()
 
     # warm-up: the first epoch ramps the concurrency up; its duration calibrates epochs_per_step
@@ -393,8 +346,8 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         epoch()
     barrier()  # lfm_session_epoch / check_finite synchronise the session's stream before returning
     all_stats.clear()
-    merges0, mbytes0 = state["merges"], state["merge_bytes"]
-    epoch0 = state["history"] // max(1, (global_n if world > 1 else n_local))
+    merges0, mbytes0 = fit.merges, fit.merge_bytes
+    epoch0 = int(getattr(model, "_trained_interactions", 0)) // max(1, global_n)
     t_start = time.perf_counter()
     for _ in range(steps * eps):
         epoch()
@@ -488,8 +441,8 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
               "all-reduce over the compacted union of the rows touched since the last merge%s%s"
               % (", overlapped with the next segment" if policy.overlap else ", synchronous",
                  "; %d hot rows merged every %d interactions" % (len(hot), world << 17) if len(hot) else ""),
-              (state["merges"] - merges0) / float(n_epochs),
-              (state["merge_bytes"] - mbytes0) / 1e6 / max(1, state["merges"] - merges0)))
+              (fit.merges - merges0) / float(n_epochs),
+              (fit.merge_bytes - mbytes0) / 1e6 / max(1, fit.merges - merges0)))
     result = {
         "value": total_pos / elapsed, "unit": "interactions/s", "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed * 1e3 / steps,

@@ -44,6 +44,30 @@ __global__ void row_pointers_kernel(const uint64_t *keys, int64_t n, uint64_t n_
     }
 }
 
+// Bloom filter over the rows of the positives lookup (device.hpp: Bloom): eight lanes walk a row.
+__global__ void bloom_build_kernel(const int32_t *indptr, const int32_t *indices, int32_t n_rows, uint32_t *bloom)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    const int sub = (int)(t & 7);
+    for (int64_t r = t >> 3; r < n_rows; r += st >> 3) {
+        const int lo = indptr[r], hi = indptr[r + 1];
+        for (int k = lo + sub; k < hi; k += 8) {
+            const uint32_t h = Bloom::mix((uint32_t)indices[k]);
+            atomicOr(bloom + Bloom::word(h, lo, hi), Bloom::mask(h));
+        }
+    }
+}
+
+hipError_t build_positives_bloom(const int32_t *indptr, const int32_t *indices, int32_t n_rows, int64_t nnz, uint32_t *bloom,
+                                 hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(bloom, 0, (size_t)Bloom::words(nnz) * sizeof(uint32_t), st);
+    if (e != hipSuccess || n_rows <= 0 || nnz <= 0) return e;
+    const int grid = (int)std::min<int64_t>(8192, ((int64_t)n_rows * 8 + 255) / 256);
+    bloom_build_kernel<<<grid, 256, 0, st>>>(indptr, indices, n_rows, bloom);
+    return hipGetLastError();
+}
+
 static int bits_for(uint64_t v)
 {
     int b = 1;

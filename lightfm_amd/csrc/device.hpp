@@ -71,6 +71,7 @@ struct FitArgs {
     int32_t cand_base;     // feat_kernel.hpp: first candidate-negative row of the representation tile
     int32_t *neg_log, *sampled_log;
     unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
+    const uint32_t *bloom;         // Bloom filter over the positives lookup (struct Bloom below), nullptr = none
     float *reg_live;               // [RegScale::FLOATS] parallel mode, lazy L2 regularisation (see RegScale): line 0 =
                                    // min(item_scale, MAX), min(user_scale, MAX) at the last launch boundary, lines 1.. =
                                    // the slots collecting the growth of log(scale) since then (float atomics)
@@ -88,6 +89,38 @@ __device__ __forceinline__ int guard_row(const FitArgs &a, int r)
     }
     return r;
 }
+
+// Bloom filter over the positives lookup: an EXACT pre-filter of in_positives (PYX:270-284).  The filter of
+// user u occupies the words [lo >> 1, lo >> 1 + n_w) of ONE array, (lo, hi) = u's row bounds in the lookup
+// and n_w = max(1, ((hi + 1) >> 1) - (lo >> 1)): 16 bits per positive, addressed from the row bounds the
+// kernels hold anyway (no table of its own; neighbouring rows may share a boundary word, which only adds
+// false positives).  An item sets / tests 3 bits of one word.  "All three set" = maybe a positive (the exact
+// search decides); anything else = certainly not a positive -- the common case of a uniformly drawn
+// negative -- decided by ONE 4-byte read whose address does not depend on the row's contents, so it can
+// travel together with the candidate's embedding row.
+struct Bloom {
+    __host__ __device__ static inline uint32_t mix(uint32_t item)
+    {
+        uint32_t h = item * 0x9E3779B1u;
+        h ^= h >> 16;
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 13;
+        return h;
+    }
+    __host__ __device__ static inline int64_t words(int64_t nnz) { return ((nnz + 1) >> 1) + 1; }
+    __host__ __device__ static inline uint32_t word(uint32_t h, int lo, int hi)
+    {
+        const uint32_t lw = (uint32_t)lo >> 1;
+        const uint32_t hw = ((uint32_t)hi + 1u) >> 1;
+        const uint32_t nw = hw > lw ? hw - lw : 1u;
+        return lw + (uint32_t)(((uint64_t)h * (uint64_t)nw) >> 32);
+    }
+    __host__ __device__ static inline uint32_t mask(uint32_t h)
+    {
+        const uint32_t g = h * 0xC2B2AE35u;
+        return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)) | (1u << ((g >> 17) & 31u));
+    }
+};
 
 // ------------------------------------------------------------------ lanes ---
 

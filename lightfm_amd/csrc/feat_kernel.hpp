@@ -185,8 +185,12 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         if (keep) keep->n = -1;
         int cur = -1;
         float acc[NC], accb = 0.0f;
+        int cc_[NC];  // this lane's components, lanes past d clamped to component 0 (never stored)
 #pragma unroll
-        for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+        for (int q = 0; q < NC; ++q) {
+            acc[q] = 0.0f;
+            cc_[q] = (lane + WAVE * q) < d ? lane + WAVE * q : 0;
+        }
         auto flush = [&]() {
             float *rp = reps + (size_t)read_lane(rrow, cur) * TS;
 #pragma unroll
@@ -211,7 +215,13 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
-                for (int t = ce; t < ce + nc; ++t) {
+                // Reduction of the staged rows, job by job.  Within a job the float32 accumulation is one
+                // sequential chain in CSR order (PYX:306-313); what is NOT sequential is everything around it, so
+                // the rows of up to four consecutive entries of the job are read from the stage together (one LDS
+                // latency per four entries instead of one per entry) and their weights are fetched by lane reads
+                // while those reads are in flight.  No per-lane predicates in the loop: lanes past d read
+                // component 0 and their accumulators are never stored (flush() writes c < d only).
+                for (int t = ce; t < ce + nc;) {
                     const int jt = read_lane(e.job, t);
                     if (jt != cur) {
                         if (cur >= 0) flush();
@@ -220,18 +230,32 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
                         accb = 0.0f;
                     }
-                    float wt = read_lanef(e.w, t);
-                    const float bt = read_lanef(bx, t);
-                    if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
-                        wt = (float)((double)wt * (double)(read_lane(e.eside, t) ? wsc_u : wsc_i));
-                    const float *sr = stage + (size_t)(t - ce) * d;
+                    // entries [t, jend) of this chunk belong to job `cur`
+                    const int jend = min(ce + nc, read_lane(off, jt) + read_lane(len, jt) - r * WAVE);
+                    for (; t < jend; t += 4) {
+                        const int m = jend - t;  // >= 1; entries t .. t + min(m, 4) - 1
+                        float xv[4][NC], wt[4], bt[4];
 #pragma unroll
-                    for (int q = 0; q < NC; ++q) {
-                        const int c = lane + WAVE * q;
-                        const float xv = c < d ? sr[c] : 0.0f;
-                        acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xv));
+                        for (int u = 0; u < 4; ++u) {
+                            const int tu = min(t + u, jend - 1);  // past the job's end: its last row again (unused)
+                            const float *sr = stage + (size_t)(tu - ce) * d;
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) xv[u][q] = sr[cc_[q]];
+                            wt[u] = read_lanef(e.w, tu);
+                            bt[u] = read_lanef(bx, tu);
+                            if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
+                                wt[u] = (float)((double)wt[u] * (double)(read_lane(e.eside, tu) ? wsc_u : wsc_i));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (u < m) {  // wave-uniform
+#pragma unroll
+                                for (int q = 0; q < NC; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(wt[u], xv[u][q]));
+                                accb = __fadd_rn(accb, __fmul_rn(wt[u], bt[u]));
+                            }
+                        }
                     }
-                    accb = __fadd_rn(accb, __fmul_rn(wt, bt));
+                    t = jend;
                 }
                 wave_sync();  // the stage is rewritten by the next chunk
                 stamp(3);

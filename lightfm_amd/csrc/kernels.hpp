@@ -63,12 +63,16 @@ hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, siz
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...
     int waves_per_block;
+    int waves_per_cu = 8;  // wavefronts the session keeps resident per CU (session.hip)
     size_t smem;  // LDS bytes per workgroup
 };
 // rows_hint: rows of a typical update list (f_user + 2 f_item), so that one chunk covers it
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used = nullptr, bool timed = false);
+// csr_build.hip: the Bloom filter over the positives lookup (device.hpp: Bloom); bloom has Bloom::words(nnz) words
+hipError_t build_positives_bloom(const int32_t *indptr, const int32_t *indices, int32_t n_rows, int64_t nnz, uint32_t *bloom,
+                                 hipStream_t st);
 hipError_t launch_pack_records(const int32_t *user_ids, const int32_t *item_ids, const float *Y,
                                const float *weight, int64_t n, void *out, hipStream_t st);
 // lazy L2 regularisation in parallel mode (device.hpp: RegScale): reg_log[2] float64 totals at the last launch

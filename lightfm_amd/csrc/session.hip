@@ -368,6 +368,8 @@ struct lfm_session {
     hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
+    DBuf<uint32_t> bloom;  // Bloom filter over the rows of `pos` (device.hpp: Bloom), built with the lookup
+    bool bloom_valid = false;
     bool recs_valid = false;
     int64_t n = 0;
     std::vector<DBuf<int32_t> *> shuffles;
@@ -635,6 +637,17 @@ extern "C" int lfm_session_destroy(lfm_session *s)
     return LFM_OK;
 }
 
+// The Bloom filter over the resident positives lookup (tile kernel: in_positives pre-filter).
+static int build_bloom(lfm_session *s)
+{
+    s->bloom_valid = false;
+    if (!s->pos.indptr.p || s->pos.rows <= 0 || s->pos.nnz <= 0) return LFM_OK;
+    LFM_TRY(s->bloom.alloc((size_t)Bloom::words(s->pos.nnz)));
+    HIP_TRY(build_positives_bloom(s->pos.indptr.p, s->pos.indices.p, s->pos.rows, s->pos.nnz, s->bloom.p, s->stream));
+    s->bloom_valid = true;
+    return LFM_OK;
+}
+
 extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *positives,
                                             const int32_t *user_ids, const int32_t *item_ids,
                                             const float *Y, const float *sample_weight, int64_t n)
@@ -666,6 +679,7 @@ extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *posit
             return fail(LFM_EINVAL, "interactions matrix has more columns than item_features has rows");
         LFM_TRY(check_id_range(s, s->pos.indices.p, s->pos.nnz, std::max<int64_t>(positives->cols, 1), "interactions.indices"));
     }
+    LFM_TRY(build_bloom(s));
     return LFM_OK;
 }
 
@@ -1538,6 +1552,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     a.n_pos = n_positives;
     a.counters = s->counters.p;
     a.reg_live = s->reg_live.p;
+    // in_positives pre-filter of the tile kernel (debug bit 8 = 256: off; bit 9 = 512: probed after the scoring pass
+    // instead of together with the candidate rows)
+    a.bloom = (s->bloom_valid && !(opts->debug & 256)) ? s->bloom.p : nullptr;
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
     // never calls log(): PYX:881 / C_OMP:7446 (WARP), PYX:1039 / C_OMP:8452 (k-OS).
@@ -1747,7 +1764,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             }
             // row-stream kernels: 8 wavefronts per CU publish fastest (C3: 43 M/s at 2 048 interactions
             // in flight against 35 M/s at 3 072 -- the float atomics queue up in the fabric)
-            const size_t cu_blocks = use_feat ? (size_t)(8 / wpb) : 8;
+            // (LIGHTFM_AMD_FEAT_WAVES_PER_CU: experiments with the row-stream kernels' residency; their LDS budget per
+            // wavefront -- LIGHTFM_AMD_FEAT_LDS_KB, feat_kernels.hip -- must allow it)
+            static const int feat_waves_env = [] { const char *e = getenv("LIGHTFM_AMD_FEAT_WAVES_PER_CU"); return e ? atoi(e) : 0; }();
+            const int feat_waves = feat_waves_env > 0 ? feat_waves_env : fplan.waves_per_cu;
+            const size_t cu_blocks = use_feat ? (size_t)std::max(1, feat_waves / wpb) : 8;
             const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
             const bool below_residency = allowed / (wpb * per_wave) < max_grid;
@@ -1939,6 +1960,7 @@ extern "C" int lfm_session_build_positives(lfm_session *s, int32_t n_users, int3
     s->pos.cols = n_items;
     s->pos.nnz = nnz;
     s->pos.identity = false;
+    LFM_TRY(build_bloom(s));
     return LFM_OK;
 }
 

@@ -246,6 +246,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     const uint32_t base_seed = a.seeds[0];
     const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
+    const uint32_t *bloom = a.bloom;              // in_positives pre-filter, nullptr = none
+    const bool bloom_early = !(a.debug & 512);   // probe with the candidate rows (default) or after the scoring pass
 
     // rand_r's LCG is affine, so k steps collapse into one multiply-add.  For the first batch of
     // every pass lane p needs the stream after min(p, nb_first) more draws: it keeps
@@ -397,6 +399,12 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
+                // in_positives pre-filter (device.hpp: Bloom): the filter word of every candidate travels with its
+                // embedding row (its address needs only the user's row bounds, prefetched a pass ahead), so the
+                // common answer -- "certainly not a positive" -- costs no round trip of its own
+                const uint32_t bh = Bloom::mix((uint32_t)myitem);
+                uint32_t bword = 0xffffffffu;  // no filter: every candidate is "maybe a positive"
+                if (bloom && bloom_early && rowlane && p > 0) bword = bloom[Bloom::word(bh, c_lo, c_hi)];
                 // up to 10 candidate rows per round, ALL requested before the first is staged
                 const bool gln = need && pc;
                 if constexpr (DMA) {
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
                 const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
                 unsigned long long vm = (__ballot(viol) >> gbase) & GM;
+                if (bloom && !bloom_early && viol) bword = bloom[Bloom::word(bh, c_lo, c_hi)];  // probed for the violators only
                 int used = nb;
                 stamp(2);  // scoring pass
                 if (done == 0) {
@@ -506,14 +515,21 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                       __builtin_amdgcn_readlane(spec_cand, gg * LPR), false);
                     }
                 }
+                // lane r's verdict on ITS candidate: all three filter bits set = maybe a positive
+                const uint32_t bmask = Bloom::mask(bh);
+                const int maybe_pos = ((bword & bmask) == bmask) ? 1 : 0;
                 while (true) {
                     const bool part = need && chosen < 0 && vm != 0ull;
                     if (__ballot(part) == 0ull) break;
                     const int r = part ? (__ffsll((long long)vm) - 1) : 0;
                     if (part) vm &= vm - 1ull;
                     const int cand = LPR == 64 ? read_lane(myitem, r) : __shfl(myitem, gbase + r, WAVE);
-                    const bool found = group_in_positives<LPR>(indices, cand, LPR == 64 ? uni(c_lo) : c_lo,
-                                                               LPR == 64 ? uni(c_hi) : c_hi, part, gbase, p);
+                    // the exact search (PYX:270-284) only where the filter cannot rule the candidate out
+                    const bool ask = part && (LPR == 64 ? read_lane(maybe_pos, r) : __shfl(maybe_pos, gbase + r, WAVE)) != 0;
+                    bool found = false;
+                    if (__ballot(ask) != 0ull)
+                        found = group_in_positives<LPR>(indices, cand, LPR == 64 ? uni(c_lo) : c_lo,
+                                                        LPR == 64 ? uni(c_hi) : c_hi, ask, gbase, p);
                     c3 += (uint32_t)__popcll(__ballot(part && p == 0));  // PYX:878-879: the draw still counts
                     if (part) {
                         if (!found) {

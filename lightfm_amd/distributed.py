@@ -134,14 +134,15 @@ def merge_schedule(global_history, global_n, world, policy=None, n_rows=0):
     return np.asarray(fr)
 
 
-def hot_rows(features, hot_share):
+def hot_rows(features, hot_share, touches=2.0):
     """Ascending feature columns of a (replicated side's) feature matrix that an interaction touches with
-    probability >= hot_share (MergePolicy.hot_share); none for an identity matrix."""
+    probability >= hot_share (MergePolicy.hot_share); none for an identity matrix.  touches = rows of the
+    matrix an interaction reads: 2 on the item side (the positive and the negative item), 1 on the user side."""
     if features is None or hot_share <= 0 or features.shape[0] == 0:
         return np.zeros(0, np.int32)
     f = sp.csc_matrix(features)
     counts = np.diff(f.indptr)
-    return np.flatnonzero((counts >= 2) & (2.0 * counts / float(features.shape[0]) >= hot_share)).astype(np.int32)
+    return np.flatnonzero((counts >= 2) & (touches * counts / float(features.shape[0]) >= hot_share)).astype(np.int32)
 
 
 def merge_plan(global_history, global_n, world, policy=None, n_rows=0, has_hot=False):
@@ -174,22 +175,37 @@ def segment_positions(fractions, n_local):
 class DistributedFit(object):
     """Drives the epochs of one rank.  Usage (inside torch.distributed.run):
 
-        fit = DistributedFit(model, interactions, rank, world, device=local_rank, dist=dist)
+        fit = DistributedFit(model, interactions, rank, world, device=local_rank, dist=dist,
+                             item_features=item_features, user_features=user_features)
         fit.run(epochs)
         fit.gather_users()       # optional: every rank's model then holds all user rows
 
-    `model` is a lightfm_amd.LightFM with identity user and item features (the BASELINE
-    multi-GPU configurations).  Its user arrays keep the FULL shape on the host; the rank's
-    session only sees (and allocates on the GPU) the slice of its own users.
+    `model` is a lightfm_amd.LightFM; `item_features` / `user_features` are what the reference's
+    `fit_partial` takes (LFM:560-666; None = identity).  What is replicated and what is partitioned:
+
+    * item side: the tables have one row per item FEATURE and every rank's negatives range over all
+      items (PYX:860-861) -- always replicated, merged over RCCL; feature columns shared by many items (a
+      hybrid model's tag rows) are HOT rows with a short merge cadence of their own (`hot_rows`);
+    * user side, identity features: a user's row is touched only by that user's interactions, i.e. by its
+      owner rank -- the tables are PARTITIONED (a rank allocates only its range; never communicated; the
+      host arrays keep the full shape and `gather_users` fills them in after training);
+    * user side with a feature matrix: feature rows are shared between users of different ranks --
+      replicated and merged like the item side (`sides` bit 1), the rank's session sees the rows of the
+      matrix that belong to its users.
     """
 
     def __init__(self, model, interactions, rank, world, device=0, dist=None, policy=None,
-                 host_shuffle=False, bounds=None, global_n=None):
+                 host_shuffle=False, bounds=None, global_n=None, item_features=None, user_features=None,
+                 local_ids=False):
         """interactions: the WHOLE interaction matrix (every rank cuts its own user range from it,
         boundaries planned from the row counts) -- or, with `bounds` and `global_n`, only THIS rank's
         rows of it: a matrix of the full shape whose entries all lie in users [bounds[rank],
         bounds[rank + 1]) (a rank of a large job loads its range from its own data source; bounds =
-        the user boundaries of all ranks, global_n = interactions of all ranks together)."""
+        the user boundaries of all ranks, global_n = interactions of all ranks together) -- or, with
+        `local_ids=True` and `global_n`, this rank's shard with user ids already relative to its range
+        (shape (users of the rank, n_items); user_features, if any, are the rank's rows; the model then
+        holds ONLY the rank's user rows on the host as well: what a 50 M-user job needs, where no process
+        can hold the full user tables; `gather_users` is not available)."""
         from ._lightfm_fast import CSRMatrix, FastLightFM
         from .lightfm import _Session, _WEIGHTS
         self.model, self.rank, self.world, self.dist = model, rank, world, dist
@@ -199,7 +215,14 @@ class DistributedFit(object):
         coo = sp.coo_matrix((np.ascontiguousarray(coo.data, dtype=np.float32),
                              (np.ascontiguousarray(coo.row, dtype=np.int32),
                               np.ascontiguousarray(coo.col, dtype=np.int32))), shape=coo.shape)
-        if bounds is not None:
+        self.local_ids = bool(local_ids)
+        if local_ids:
+            if global_n is None or bounds is not None:
+                raise ValueError("local_ids needs global_n (interactions of all ranks together) and no bounds")
+            shard = coo
+            self.bounds = None
+            self.global_n = int(global_n)
+        elif bounds is not None:
             if global_n is None:
                 raise ValueError("a pre-cut shard needs global_n (interactions of all ranks together)")
             bounds = np.asarray(bounds, dtype=np.int64)
@@ -214,30 +237,45 @@ class DistributedFit(object):
             self.global_n = int(coo.nnz)
         self.shard = shard
         n_users, n_items = coo.shape
+        # the reference's checks and coercions of the feature matrices (LFM:314-363)
+        user_f, item_f = model._construct_feature_matrices(n_users, n_items, user_features, item_features)
+        self.shared_users = user_features is not None
         if model.item_embeddings is None:
-            model._initialize(model.no_components, n_items, n_users)
-        if world > 1:  # replicas start from rank 0's tables
+            model._initialize(model.no_components, item_f.shape[1], user_f.shape[1])
+        if not item_f.shape[1] == model.item_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in item_features")
+        if not user_f.shape[1] == model.user_embeddings.shape[0]:
+            raise ValueError("Incorrect number of features in user_features")
+        if world > 1:  # replicas start from rank 0's tables (with local ids the user rows are each rank's own)
             import torch
-            for name in ("item_embeddings", "user_embeddings"):
+            for name in ("item_embeddings",) + (() if (local_ids and not self.shared_users) else ("user_embeddings",)):
                 dist.broadcast(torch.from_numpy(getattr(model, name)), src=0)
-        b0, b1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        b0, b1 = (0, n_users) if local_ids else (int(self.bounds[rank]), int(self.bounds[rank + 1]))
         self.user_range = (b0, b1)
         arrays = []
         for name in _WEIGHTS:  # views: device results land in the model's own arrays
             a = getattr(model, name)
-            arrays.append(a[b0:b1] if name.startswith("user") else a)
+            arrays.append(a[b0:b1] if (name.startswith("user") and not self.shared_users) else a)
         self.struct = FastLightFM(*arrays, model.no_components,
                                   int(model.learning_schedule == "adadelta"), model.learning_rate,
                                   model.rho, model.epsilon, model.max_sampled)
-        user_f = sp.identity(b1 - b0, dtype=np.float32, format="csr")
-        item_f = sp.identity(n_items, dtype=np.float32, format="csr")
-        self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(user_f), device=device)
+        if self.shared_users:
+            # the rank's users' rows of the matrix over ALL user-feature columns (replicated tables)
+            rank_user_f = user_f[b0:b1].tocsr()
+            rank_user_f.sort_indices()
+        else:
+            rank_user_f = sp.identity(b1 - b0, dtype=np.float32, format="csr")
+        self.item_features, self.user_features = item_f, rank_user_f
+        self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(rank_user_f), device=device)
         self.session.set_interactions(None, np.ascontiguousarray(shard.row),
                                       np.ascontiguousarray(shard.col), shard.data, shard.data)
         self.session.build_positives(b1 - b0, n_items)
-        self.n_replicated_rows = n_items
+        # what the merges cover: bit 0 = the item tables, bit 1 = user tables of shared user features
+        self.sides = 1 | (2 if self.shared_users else 0)
+        self.n_replicated_rows = max(item_f.shape[1], user_f.shape[1] if self.shared_users else 0)
         self.merges, self.merge_bytes = 0, 0
-        self.hot = hot_rows(None, self.policy.hot_share)  # identity item features: no shared rows
+        self.hot = [hot_rows(item_features, self.policy.hot_share, 2.0),
+                    hot_rows(user_features if self.shared_users else None, self.policy.hot_share, 1.0)]
         if world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
@@ -247,8 +285,13 @@ class DistributedFit(object):
             dist.broadcast(t, src=0)
             self.session.comm_init(C.create_string_buffer(bytes(t.numpy().tobytes()),
                                                           N.UNIQUE_ID_BYTES), rank, world)
-            if len(self.hot):
-                self.session.set_hot_rows(0, self.hot)
+            for side in (0, 1):
+                if len(self.hot[side]):
+                    self.session.set_hot_rows(side, self.hot[side])
+
+    @property
+    def has_hot(self):
+        return len(self.hot[0]) > 0 or len(self.hot[1]) > 0
 
     def run_epoch(self, seeds, slot=0):
         """One epoch of this rank: segments + merges.  Returns the per-segment lfm_opts."""
@@ -256,8 +299,11 @@ class DistributedFit(object):
         m = self.model
         n = self.shard.nnz
         history = int(getattr(m, "_trained_interactions", 0))  # interactions of ALL ranks so far
-        fr, kinds = merge_plan(history, self.global_n, self.world, self.policy, self.n_replicated_rows,
-                               len(self.hot) > 0)
+        if self.world == 1:  # nothing to merge: the whole epoch in one call, exactly LightFM.fit_partial's epoch
+            fr, kinds = np.array([0.0, 1.0]), ["none"]
+        else:
+            fr, kinds = merge_plan(history, self.global_n, self.world, self.policy, self.n_replicated_rows,
+                                   self.has_hot)
         pos = segment_positions(fr, n)
         sparse = self.policy.sparse and m.learning_schedule == "adagrad"
         stats = []
@@ -268,47 +314,67 @@ class DistributedFit(object):
             opts.pos_begin, opts.pos_end = int(pos[j]), int(pos[j + 1])
             if pos[j + 1] > pos[j]:
                 self.session.epoch(m.loss, m.item_alpha, m.user_alpha, m.k, m.n, seeds, opts, slot=slot)
-            if not sparse:
+            if kinds[j] == "none":
+                pass
+            elif not sparse:
                 if kinds[j] == "full":
-                    self.session.comm_merge(1, self.policy.mode_id())
+                    self.session.comm_merge(self.sides, self.policy.mode_id())
             elif kinds[j] == "hot":
-                self.merge_bytes += self.session.comm_merge_hot(1, self.policy.mode_id(), self.policy.overlap)
+                self.merge_bytes += self.session.comm_merge_hot(self.sides, self.policy.mode_id(), self.policy.overlap)
             else:
-                self.merge_bytes += self.session.comm_merge_sparse(1, self.policy.mode_id(), self.policy.overlap)
-            self.merges += 1
-            stats.append(opts)
-        if sparse:
+                self.merge_bytes += self.session.comm_merge_sparse(self.sides, self.policy.mode_id(), self.policy.overlap)
+            self.merges += int(kinds[j] != "none")
+            if pos[j + 1] > pos[j]:
+                stats.append(opts)
+        if sparse and self.world > 1:
             self.session.comm_merge_flush()  # the last exchange lands before anything reads the tables
         m._trained_interactions = history + self.global_n
         return stats
 
-    def run(self, epochs, num_threads=1):
+    def epoch(self, num_threads=1):
+        """One epoch as LightFM.fit_partial runs it (LFM:654-664): the shuffle, the kernel seeds, the
+        segments with their merges, the finite check -- all ranks raise together (a rank that stopped
+        alone would leave the others blocked in the next collective).  Returns the per-segment lfm_opts."""
         m = self.model
         n = self.shard.nnz
-        stats = []
-        for _ in range(epochs):
-            if self.host_shuffle:
-                shuffle = np.arange(n, dtype=np.int32)
-                m.random_state.shuffle(shuffle)
-                self.session.upload_shuffle(shuffle)
-            else:
-                keys = m.random_state.randint(0, np.iinfo(np.int32).max, size=624)
-                self.session.device_shuffle(int(keys[0]), int(keys[1]))
+        if self.host_shuffle:
+            shuffle = np.arange(n, dtype=np.int32)
+            m.random_state.shuffle(shuffle)
+            self.session.upload_shuffle(shuffle)
+        else:
+            keys = m.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+            self.session.device_shuffle(int(keys[0]), int(keys[1]))
+        seeds = None
+        if m.loss != "logistic":
             seeds = np.ascontiguousarray(m.random_state.randint(
                 0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
-            stats.extend(self.run_epoch(seeds))
-            # all ranks raise together (a rank that stopped alone would leave the others blocked in
-            # the next collective)
-            if self.session.comm_any(not self.session.check_finite()):
-                self.session.sync_to_host(self.struct)
-                raise ValueError("Not all estimated parameters are finite, your model may have diverged.")
+        stats = self.run_epoch(seeds)
+        bad = not self.session.check_finite()
+        if self.world > 1:
+            bad = self.session.comm_any(bad)
+        if bad:
+            self.session.sync_to_host(self.struct)
+            raise ValueError("Not all estimated parameters are finite, your model may have diverged.")
+        return stats
+
+    def run(self, epochs, num_threads=1):
+        stats = []
+        for _ in range(epochs):
+            stats.extend(self.epoch(num_threads))
         self.session.sync_to_host(self.struct)
         return stats
 
+    def barrier(self):
+        """Device work of this rank done and every rank here (bench.py's timed region)."""
+        if self.world > 1:
+            self.session.comm_barrier()
+
     def gather_users(self):
         """Every rank receives the other ranks' user rows (host plane, once, after training)."""
-        if self.world <= 1:
+        if self.world <= 1 or self.shared_users:  # shared user features: the tables are replicated anyway
             return
+        if self.local_ids:
+            raise ValueError("gather_users needs the global user ranges (not available with local_ids)")
         import torch
         from .lightfm import _WEIGHTS
         for name in _WEIGHTS:

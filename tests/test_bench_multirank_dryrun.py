@@ -127,12 +127,12 @@ def _worker(rank, world, port, out, argv):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling):
+@pytest.mark.parametrize("scaling,config", [("strong", "c2"), ("weak", "c2"), ("strong", "c3")])
+def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling, config):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     out = str(tmp_path / "rank%d.json")
-    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "1", "--config", "c2",
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--epochs-per-step", "1", "--config", config,
             "--scale", "0.004", "--scaling", scaling]
     mp.spawn(_worker, args=(world, port, out, argv), nprocs=world, join=True)
     got = [json.load(open(out % r)) for r in range(world)]
@@ -147,9 +147,12 @@ def test_bench_two_ranks_walk_the_same_schedule(tmp_path, scaling):
     assert 0 < line["value"] * line["ms_per_step"] * 1e-3 * line["steps"] <= timed
     assert "roofline" in line and line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
     assert "GPUs" in line["config"]["parallelism"] and "rows touched" in line["config"]["parallelism"]
+    if config == "c3":  # the hybrid config runs through the product driver: its tag rows are hot rows on both ranks
+        assert got[0]["calls"].get("hot", 0) == got[1]["calls"].get("hot", 0) > 1000
+        assert "hot rows" in line["config"]["parallelism"]
 
 
-def _fit_worker(rank, world, port, out, precut=False):
+def _fit_worker(rank, world, port, out, precut=False, hybrid=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -159,12 +162,14 @@ def _fit_worker(rank, world, port, out, precut=False):
         import lightfm_amd.lightfm as L
         from lightfm_amd import LightFM, synthetic
         from lightfm_amd.distributed import DistributedFit
-        log = {"epoch": 0, "merge": 0, "positions": 0}
+        log = {"epoch": 0, "merge": 0, "positions": 0, "sides": [], "hot": {}, "kinds": []}
 
         class FakeSession(object):
             def __init__(self, struct, item_f, user_f, device=0):
-                self.users = struct.user_features.shape[0]
+                self.users = user_f.rows
                 self.struct = struct
+                log["shapes"] = [item_f.rows, item_f.cols, user_f.rows, user_f.cols,
+                                 int(struct.item_features.shape[0]), int(struct.user_features.shape[0])]
 
             def set_interactions(self, positives, rows, cols, data, weight):
                 assert rows.dtype == np.int32 and data.dtype == np.float32 and rows.max() < self.users
@@ -190,9 +195,22 @@ def _fit_worker(rank, world, port, out, precut=False):
 
             def comm_merge_sparse(self, sides, mode, overlap=True):
                 log["merge"] += 1
+                log["sides"].append(sides)
+                log["kinds"].append("full")
                 self.pending = bool(overlap)
                 dist.barrier()
                 return 1000
+
+            def comm_merge_hot(self, sides, mode, overlap=True):
+                log["merge"] += 1
+                log["sides"].append(sides)
+                log["kinds"].append("hot")
+                dist.barrier()
+                return 100
+
+            def set_hot_rows(self, side, rows):
+                assert np.all(np.diff(rows) > 0)
+                log["hot"][str(side)] = [int(rows[0]), int(rows[-1]), len(rows)]
 
             def comm_merge_flush(self):
                 self.pending = False
@@ -215,7 +233,17 @@ def _fit_worker(rank, world, port, out, precut=False):
         N.check = lambda rc: rc
         data = synthetic.make_interactions(400, 300, 20000, seed=3).astype(np.float64)  # wrong dtype on purpose
         model = LightFM(no_components=8, loss="warp", random_state=5)
-        if precut:
+        if hybrid:
+            # a hybrid model through the product driver: [identity | 20 tags] item features (the tags are hot
+            # rows) and 12 shared user-feature columns (the user tables are then replicated and merged too)
+            from tests import helpers as H
+            item_f = H.tag_features(300, 20, 3, seed=1)
+            user_f = H.tag_features(400, 12, 2, seed=2, with_identity=False)
+            from lightfm_amd.distributed import MergePolicy
+            fit = DistributedFit(model, data, rank, world, device=rank, dist=dist, item_features=item_f,
+                                 user_features=user_f, policy=MergePolicy(hot_max=2048))  # (default: every world * 2**17)
+            assert model.item_embeddings.shape[0] == 320 and model.user_embeddings.shape[0] == 12
+        elif precut:
             # a rank that only holds its own users' rows (its range of a large job's data source)
             from lightfm_amd.distributed import local_shard, plan_row_shards
             coo = data.tocoo()
@@ -231,7 +259,7 @@ def _fit_worker(rank, world, port, out, precut=False):
         fit.close()
         b0, b1 = fit.user_range
         json.dump({"log": log, "n_local": int(fit.shard.nnz), "range": [b0, b1], "global_n": int(fit.global_n),
-                   "moved_all": bool(np.all(model.user_embeddings != before))}, open(out % rank, "w"))
+                   "sides": int(fit.sides), "moved_all": bool(np.all(model.user_embeddings != before))}, open(out % rank, "w"))
     finally:
         dist.destroy_process_group()
 
@@ -253,3 +281,25 @@ def test_distributed_fit_control_flow_two_ranks(tmp_path, precut):
         assert g["log"]["positions"] == 2 * g["n_local"]
         assert g["moved_all"], "after gather_users every rank holds the trained rows of every user"
     assert got[0]["n_local"] + got[1]["n_local"] == got[0]["global_n"] == got[1]["global_n"] > 15000
+
+
+@pytest.mark.timeout(600)
+def test_distributed_fit_hybrid_model_two_ranks(tmp_path):
+    """BASELINE configs C3 / C5 are hybrid: DistributedFit takes item_features / user_features like the
+    reference's fit_partial (LFM:560-666).  Item tables are replicated with the tag columns as hot rows;
+    shared user features make the user tables replicated too (sides = 3) and every rank's session sees its
+    users' rows of the matrix over ALL feature columns."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = str(tmp_path / "hyb%d.json")
+    mp.spawn(_fit_worker, args=(world, port, out, False, True), nprocs=world, join=True)
+    got = [json.load(open(out % r)) for r in range(world)]
+    for g in got:
+        assert g["sides"] == 3 and set(g["log"]["sides"]) == {3}
+        assert g["log"]["hot"]["0"] == [300, 319, 20], g["log"]["hot"]       # the 20 tag columns behind the identity block
+        assert g["log"]["hot"]["1"][2] == 12                                  # every shared user-feature column
+        assert "hot" in g["log"]["kinds"] and "full" in g["log"]["kinds"]
+        n_local_users = g["range"][1] - g["range"][0]
+        assert g["log"]["shapes"] == [300, 320, n_local_users, 12, 320, 12]
+        assert g["log"]["positions"] == 2 * g["n_local"]
+    assert got[0]["log"]["kinds"] == got[1]["log"]["kinds"]                   # the same schedule on both ranks

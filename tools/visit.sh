@@ -204,6 +204,45 @@ except Exception as e:
 PY
   cp $R/profiles/r04_* $OUT/ 2>/dev/null
   ;;
+r4b)
+  # round 4, second visit: Bloom pre-filter of in_positives in the tile kernel (default = probed with the candidate rows,
+  # --debug 512 = after the scoring pass, --debug 256 = off) and the batched representation reduce of the row-stream
+  # kernels, each against the previous commit's library (lightfm_amd/_lib_prev); exactness tests first
+  timeout -k 5 900 $PYT tests/test_hip_warp_tile.py tests/test_hip_feat.py tests/test_hip_parity.py tests/test_baseline_shapes.py tests/test_hip_round2.py -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "kernel tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  PREV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_prev/liblfm_hip.so"
+  C2="--config c2 --steps 5 --warmup 2 --epochs-per-step 16"
+  for i in 1 2; do
+    ENVV= run c2_bloom_early_$i $C2
+    ENVV= run c2_bloom_late_$i $C2 --debug 512
+    ENVV= run c2_bloom_off_$i $C2 --debug 256
+    ENVV=$PREV run c2_prev_$i $C2
+  done
+  C4="--config c4shard --steps 3 --warmup 1 --epochs-per-step 8"
+  ENVV= run c4_bloom_early $C4
+  ENVV= run c4_bloom_late $C4 --debug 512
+  ENVV= run c4_bloom_off $C4 --debug 256
+  ENVV=$PREV run c4_prev $C4
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  ENVV= run c5_new $C5
+  ENVV=$PREV run c5_prev $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=12 LIGHTFM_AMD_FEAT_LDS_KB=13" run c5_new_w12 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=10 LIGHTFM_AMD_FEAT_LDS_KB=16" run c5_new_w10 $C5
+  C3="--config c3 --steps 3 --warmup 1 --epochs-per-step 2"
+  ENVV= run c3_new $C3
+  ENVV=$PREV run c3_prev $C3
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
