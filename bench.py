@@ -159,7 +159,37 @@ def precision_at_10(model, train, test, item_features):
                                 item_features=item_features).mean())
 
 
-def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note):
+def head_users(coo, nu, n_items):
+    """The first `nu` users' interactions of a COO (a row sub-sample over the full item side)."""
+    keep = coo.row < nu
+    return sp.coo_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(nu, n_items), dtype=np.float32)
+
+
+def thread_scaling(cfg_name, sub, feats, log, counts):
+    """The reference's native epoch call at several OpenMP thread counts on one row sub-sample (SURVEY.md 8(d):
+    T = 1 and T = all host cores; 16 is what `cpu_baseline.value` uses): epoch 2 of a fresh fit each."""
+    out = {}
+    for T in counts:
+        cpu, _ = reference_leg(cfg_name, sub, None, feats, 2, log, "", threads=T)
+        if cpu:
+            out[str(T)] = cpu["value"]
+    return out
+
+
+def extra_cpu_leg(name, env, pieces):
+    """cpu_baseline of an extra_configs leg: the reference (16 threads) on a bounded row sub-sample of the leg's
+    own workload over the full item-side tables."""
+    train, feats, n_users, n_items = pieces["train"], pieces["feats"], pieces["n_users"], pieces["n_items"]
+    frac = {"c3": 16, "c4shard": 50, "c5shard": 200}.get(name, 50)
+    nu = max(1000, n_users // frac)
+    sub = head_users(train, nu, n_items)
+    cpu, _ = reference_leg(name, sub, None, feats, 2, env.log,
+                           "the first %d users' %d interactions of this workload (1/%d row sub-sample) over the full "
+                           "item-side tables" % (nu, sub.nnz, frac))
+    return cpu
+
+
+def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note, threads=None):
     """The reference's compiled Cython/OpenMP path (oracle/_ref/fast) on this box's host cores:
     throughput of its native epoch call (and with its per-epoch host prologue), and -- when a
     test set is given -- precision@10 of the model it trained."""
@@ -169,7 +199,9 @@ def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note):
         return None, None
     cfg = CONFIGS[cfg_name]
     ncpu = os.cpu_count() or 1
-    threads = min(16, ncpu)  # the reference's Hogwild stops scaling there (measured: 16 beats 64 and 256)
+    # 16: where the reference's Hogwild stops scaling on these boxes (cpu_baseline.thread_scaling of every run
+    # carries T = 1 / 16 / all cores measured side by side)
+    threads = min(16, ncpu) if threads is None else max(1, min(int(threads), ncpu))
     m = RefLightFM(no_components=cfg["d"], loss=cfg["loss"], random_state=7, max_sampled=MAX_SAMPLED)
     m.native_seconds = []
     t0 = time.time()
@@ -254,7 +286,7 @@ class Env(object):
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale, want_test):
+def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale, want_test, early_epochs=3):
     """Builds the workload `name`, makes its inputs resident, warms up, times `steps` steps and returns
     (contract fields + roofline of this config, the pieces the reporting-only legs need)."""
     from lightfm_amd import _native as N
@@ -329,12 +361,22 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
             fit.barrier()
             dist.barrier()
 
-    # warm-up: the first epoch ramps the concurrency up; its duration calibrates epochs_per_step
+    # warm-up: the first epoch ramps the concurrency up.  The epochs right after it are timed on their own
+    # (`early_epochs`: the regime of a short fit -- what the quality leg and the CPU baseline run -- where nearly
+    # every interaction still finds a violator and updates); their duration also calibrates epochs_per_step.
     eps = max(1, epochs_per_step)
     epoch()
+    barrier()
+    all_stats.clear()
     t1 = time.perf_counter()
-    epoch()
-    t_epoch = time.perf_counter() - t1
+    for _ in range(early_epochs):
+        epoch()
+    barrier()
+    t_early = time.perf_counter() - t1
+    t_epoch = t_early / early_epochs
+    early_pos = float(sum(st.counters[0] for st in all_stats))
+    early = {"epochs": "2..%d of the same run" % (1 + early_epochs), "seconds": t_early,
+             "updates_per_interaction": float(sum(st.counters[2] for st in all_stats)) / max(1.0, early_pos)}
     if epochs_per_step <= 0:
         eps = int(min(64, max(1, math.ceil(target_seconds / max(1, steps) / max(t_epoch, 1e-4)))))
         if world > 1:
@@ -342,7 +384,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
             te = torch.tensor([eps], dtype=torch.int64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             eps = int(te[0])
-    for _ in range(max(0, warmup * eps - 2)):
+    for _ in range(max(0, warmup * eps - 1 - early_epochs)):
         epoch()
     barrier()  # lfm_session_epoch / check_finite synchronise the session's stream before returning
     all_stats.clear()
@@ -363,8 +405,16 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         cnt = torch.tensor([local_pos], dtype=torch.float64)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_pos = float(cnt[0])
+        e = torch.tensor([early_pos], dtype=torch.float64)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        early_pos = float(e[0])
+        e = torch.tensor([early["seconds"]], dtype=torch.float64)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        early["seconds"] = float(e[0])
     else:
         total_pos = local_pos
+    early["value"] = early_pos / early["seconds"]
+    early["unit"] = "interactions/s"
 
     # roofline of the dominant kernel (the epoch kernel of the loss), this rank
     kernel_s = sum(s.kernel_ms for s in stats) / 1e3
@@ -450,7 +500,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
                    "name": name, "epochs_per_step": eps, "ms_per_epoch": elapsed * 1e3 / n_epochs,
                    "timed_epochs": "epochs %d..%d of one continuing training run" % (epoch0 + 1, epoch0 + n_epochs),
                    "parallelism": par, "device": dev_name},
-        "roofline": roofline, "scaling": scaling,
+        "roofline": roofline, "scaling": scaling, "early_epochs": early,
     }
     if scale != 1.0:
         result["config"]["scale"] = scale
@@ -475,11 +525,7 @@ def reporting_legs(name, env, pieces, want_quality):
     if name == "c3":
         nu = n_users // 8
 
-        def head(coo):
-            keep = coo.row < nu
-            return sp.coo_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(nu, n_items),
-                                 dtype=np.float32)
-        q_train, q_test = head(train), (head(test) if test is not None else None)
+        q_train, q_test = head_users(train, nu, n_items), (head_users(test, nu, n_items) if test is not None else None)
         q_note = ("the first %d users' %d interactions of this workload (1/8 row sub-sample), full item-side "
                   "tables" % (nu, q_train.nnz))
     if want_quality and q_test is not None:
@@ -502,6 +548,13 @@ def reporting_legs(name, env, pieces, want_quality):
                 if quality is not None and p_ref is not None:
                     quality["precision_at_10_ref"] = p_ref
                     quality["delta"] = quality["precision_at_10"] - p_ref
+                if cpu:
+                    ncpu = os.cpu_count() or 1
+                    nu = max(1000, n_users // (16 if name == "c2" else 64))
+                    sub = head_users(q_train, nu, n_items) if nu < q_train.shape[0] else q_train
+                    cpu["thread_scaling"] = thread_scaling(name, sub, feats, log, sorted({1, min(16, ncpu), ncpu}))
+                    cpu["thread_scaling_sample"] = ("epoch 2 of a fresh fit on the first %d users' %d interactions, "
+                                                    "threads -> interactions/s" % (nu, sub.nnz))
             else:
                 # C4 / C5 shards: a row sub-sample (1/50 of the users, their interactions, the
                 # full item-side tables), SURVEY.md 8(d)
@@ -554,15 +607,24 @@ def main():
     if world == 1 and args.config is None and not args.no_extra and not tuned:
         # the other BASELINE shapes, short legs timed the same way (contract: barrier + sync around K steps)
         plans = {"c3": dict(steps=3, warmup=1, target=2.5), "c4shard": dict(steps=3, warmup=1, target=1.5),
-                 "c5shard": dict(steps=2, warmup=1, target=0.0)}
+                 "c5shard": dict(steps=2, warmup=1, target=0.0, early=1)}
         for extra in [e for e in args.extra.split(",") if e in plans and e != name]:
             try:
                 pl = plans[extra]
-                r, _ = run_config(extra, env, pl["steps"], pl["warmup"], 0 if pl["target"] else 1, pl["target"], 1.0,
-                                  want_quality and CONFIGS[extra]["shape"] == "ml-20m")
-                extras.append({"name": extra, "metric": "positive interactions/sec/epoch (%s, %s)" % (CONFIGS[extra]["loss"], extra),
-                               "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
-                               "ms_per_step": r["ms_per_step"], "config": r["config"], "roofline": r["roofline"]})
+                r, pc = run_config(extra, env, pl["steps"], pl["warmup"], 0 if pl["target"] else 1, pl["target"], 1.0,
+                                   False, early_epochs=pl.get("early", 3))
+                leg = {"name": extra, "metric": "positive interactions/sec/epoch (%s, %s)" % (CONFIGS[extra]["loss"], extra),
+                       "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
+                       "ms_per_step": r["ms_per_step"], "config": r["config"], "roofline": r["roofline"],
+                       "early_epochs": r["early_epochs"]}
+                if not args.no_cpu_baseline:  # the reference on a bounded row sub-sample of THIS leg's workload
+                    try:
+                        leg["cpu_baseline"] = extra_cpu_leg(extra, env, pc)
+                        if leg["cpu_baseline"]:
+                            leg["speedup_vs_cpu_baseline"] = r["value"] / leg["cpu_baseline"]["value"]
+                    except Exception as e:  # reporting only
+                        env.log("cpu_baseline of %s failed: %r" % (extra, e))
+                extras.append(leg)
             except BaseException as e:  # an extra leg never takes the contract line down
                 env.log("extra config %s failed: %r" % (extra, e))
                 extras.append({"name": extra, "error": repr(e)})
@@ -582,6 +644,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": result["config"],
             "roofline": result["roofline"],
+            "early_epochs": result["early_epochs"],
             "cpu_baseline": cpu,
             "quality": quality,
             "end_to_end_fit": fit,

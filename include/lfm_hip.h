@@ -105,7 +105,9 @@ typedef struct lfm_opts {
                                    builds: drain the memory counters at every phase stamp; bit 5 (32):
                                    no bias snapshots; bit 7 (128): consecutive full-size launches on ONE stream
                                    (default: two streams alternately, so that a launch's draining tail is
-                                   filled by the next launch's workgroups) */
+                                   filled by the next launch's workgroups); bit 8 (256): tile kernel without the
+                                   Bloom pre-filter of in_positives; bit 9 (512): the filter probed for every
+                                   candidate with its row instead of for the violators after the scoring pass */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 / feat_kernel = 2 (profiling builds): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator

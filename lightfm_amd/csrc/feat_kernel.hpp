@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
+#ifdef LFM_FEAT_REDUCE_BATCH4  // A/B build (profiles/r04_visit_b.txt: C5 -6 %, C3 +4 %: not the bound -- kept for study)
                 // Reduction of the staged rows, job by job.  Within a job the float32 accumulation is one
                 // sequential chain in CSR order (PYX:306-313); what is NOT sequential is everything around it, so
                 // the rows of up to four consecutive entries of the job are read from the stage together (one LDS
@@ -257,6 +258,30 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     }
                     t = jend;
                 }
+#else
+                for (int t = ce; t < ce + nc; ++t) {
+                    const int jt = read_lane(e.job, t);
+                    if (jt != cur) {
+                        if (cur >= 0) flush();
+                        cur = jt;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+                        accb = 0.0f;
+                    }
+                    float wt = read_lanef(e.w, t);
+                    const float bt = read_lanef(bx, t);
+                    if constexpr (REG)  // feature_weight = data * scale, PYX:306 (C_OMP:4896: through float64)
+                        wt = (float)((double)wt * (double)(read_lane(e.eside, t) ? wsc_u : wsc_i));
+                    const float *sr = stage + (size_t)(t - ce) * d;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int c = lane + WAVE * q;
+                        const float xv = c < d ? sr[c] : 0.0f;
+                        acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xv));
+                    }
+                    accb = __fadd_rn(accb, __fmul_rn(wt, bt));
+                }
+#endif
                 wave_sync();  // the stage is rewritten by the next chunk
                 stamp(3);
             }

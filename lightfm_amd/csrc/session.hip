@@ -1552,8 +1552,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     a.n_pos = n_positives;
     a.counters = s->counters.p;
     a.reg_live = s->reg_live.p;
-    // in_positives pre-filter of the tile kernel (debug bit 8 = 256: off; bit 9 = 512: probed after the scoring pass
-    // instead of together with the candidate rows)
+    // in_positives pre-filter of the tile kernel (debug bit 8 = 256: off; bit 9 = 512: probed for every candidate
+    // together with its row instead of after the scoring pass for the violators only)
     a.bloom = (s->bloom_valid && !(opts->debug & 256)) ? s->bloom.p : nullptr;
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device

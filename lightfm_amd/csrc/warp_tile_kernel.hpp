@@ -247,7 +247,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
     const uint32_t *bloom = a.bloom;              // in_positives pre-filter, nullptr = none
-    const bool bloom_early = !(a.debug & 512);   // probe with the candidate rows (default) or after the scoring pass
+    // when the filter is probed: after the scoring pass, by the violating candidates only (default: one round trip
+    // with the speculative accumulator loads instead of the search's two; C2 +5 %, C4 shard +7 % against the
+    // plain search, A/B of one box, profiles/r04_visit_b.txt), or -- debug bit 9 (512) -- for every candidate
+    // together with its embedding row (no round trip of its own but ten times the requests: +3 % / +5 %)
+    const bool bloom_early = (a.debug & 512) != 0;
 
     // rand_r's LCG is affine, so k steps collapse into one multiply-add.  For the first batch of
     // every pass lane p needs the stream after min(p, nb_first) more draws: it keeps
@@ -399,9 +403,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
-                // in_positives pre-filter (device.hpp: Bloom): the filter word of every candidate travels with its
-                // embedding row (its address needs only the user's row bounds, prefetched a pass ahead), so the
-                // common answer -- "certainly not a positive" -- costs no round trip of its own
+                // in_positives pre-filter (device.hpp: Bloom); early variant: the filter word of every candidate
+                // travels with its embedding row (its address needs only the user's row bounds, prefetched a pass ahead)
                 const uint32_t bh = Bloom::mix((uint32_t)myitem);
                 uint32_t bword = 0xffffffffu;  // no filter: every candidate is "maybe a positive"
                 if (bloom && bloom_early && rowlane && p > 0) bword = bloom[Bloom::word(bh, c_lo, c_hi)];
