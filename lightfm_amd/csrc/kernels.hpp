@@ -59,6 +59,10 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
 size_t warp_tile_geometry(int d, int max_sampled, int ng, int *rows, int *stride, int *vec, bool dma4 = false);
 hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st,
                                 int cus, bool timed = false, int *grid_used = nullptr, bool dma4 = false);
+// warp_tile_ahead.hip: the steady-state variant of the four-per-pass LDS-DMA tile kernel with the gather of the next
+// pass issued inside the current one (warp_tile_ahead.hpp); smem = 0: outside its scope
+size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch);
+hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used = nullptr);
 // feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...

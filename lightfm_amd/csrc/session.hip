@@ -1617,7 +1617,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
     // NG = 4 is the most instruction-efficient mapping; when a launch may keep only few
     // interactions in flight, fewer per wavefront buy more wavefronts (latency hiding).
-    struct TilePlan { bool ok = false, dma4 = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
+    struct TilePlan { bool ok = false, dma4 = false, ahead = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
     TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
@@ -1638,6 +1638,16 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             t.ok = true;
             t.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
             t.first_batch = std::max(1, std::min(t.first_batch, t.rows - 1));
+            // the steady-state variant with the next pass's gather issued inside the current pass (warp_tile_ahead.hpp):
+            // adagrad, no regularisation, max_sampled = 10 in one batch; debug bit 10 (1024) keeps the plain kernel
+            if (t.dma4 && !s->adadelta && item_alpha == 0.0 && user_alpha == 0.0 && opts->warp_kernel != 2 &&
+                !(opts->debug & (1024 | 512))) {
+                const size_t ahead = warp_tile_ahead_smem(s->d, s->max_sampled, t.first_batch);
+                if (ahead) {
+                    t.ahead = true;
+                    t.smem = ahead;
+                }
+            }
             use_tile = true;
         }
         if (use_tile) {
@@ -1837,8 +1847,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         a.b_read[side] = s->bias_snap[side][par].p;
                     }
                 }
-                HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
-                                             &grid_used, tile[ng].dma4));
+                if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
+                else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
+                                                  &grid_used, tile[ng].dma4));
             }
             else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));

@@ -1,0 +1,28 @@
+// warp_tile_ahead.hip -- instantiation and launcher of the gather-ahead variant of the lane-group tile
+// kernel (warp_tile_ahead.hpp): max_sampled = 10 candidates in one batch, the shape every BASELINE
+// configuration trains with (LightFM's default max_sampled).
+#include "warp_tile_ahead.hpp"
+
+namespace lfm {
+
+// 0 if (d, max_sampled, first batch) is outside the variant's scope, else its LDS bytes per workgroup
+size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch)
+{
+    if (d < 4 || d > 64 || (d & 3) != 0 || max_sampled != 10 || first_batch != 10) return 0;
+    return tile_ahead_smem<10>();
+}
+
+hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used)
+{
+    void (*kernel)(FitArgs) = fit_warp_tile_ahead_kernel<10>;
+    const size_t smem = tile_ahead_smem<10>();
+    if (cus > 0) {
+        const int per_cu = occupancy_cached(kernel, 256, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace lfm

@@ -243,6 +243,65 @@ PY
   ENVV= run c3_new $C3
   ENVV=$PREV run c3_prev $C3
   ;;
+r4c)
+  # round 4, third visit: the gather-ahead tile kernel (default) against the plain one (--debug 1024): exactness and
+  # precision@10 gates first, then A/B on c2 / c4shard; C4 two-stage candidate fetch; C5 instruction mix (one PMC pass)
+  timeout -k 5 1200 $PYT tests/test_hip_warp_tile.py tests/test_hip_parity.py tests/test_baseline_shapes.py tests/test_hip_round2.py tests/test_precision_parity.py tests/test_lightfm_api.py -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "kernel tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  grep -a "per side, fixed\|precision" $OUT/tests.log | cut -c1-200 | head
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s  early %.1f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight"), (d.get("early_epochs") or {}).get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  C2="--config c2 --steps 5 --warmup 2 --epochs-per-step 16"
+  for i in 1 2; do
+    ENVV= run c2_ahead_$i $C2
+    ENVV= run c2_plain_$i $C2 --debug 1024
+  done
+  C4="--config c4shard --steps 3 --warmup 1 --epochs-per-step 8"
+  ENVV= run c4_ahead $C4
+  ENVV= run c4_plain $C4 --debug 1024
+  ENVV= run c4_plain_fb5 $C4 --debug 1024 --first-batch 5
+  ENVV= run c4_ahead_2 $C4
+  # quality of the pipelined kernel at the C2 shape (3 seeds, 3 epochs; the reference's number is in every default line)
+  timeout 600 python bench.py --config c2 --steps 2 --warmup 1 --epochs-per-step 4 --no-fit > $OUT/c2_quality.json 2> $OUT/c2_quality.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/c2_quality.json")); q = d.get("quality") or {}
+    print("  c2 quality (ahead kernel): p@10 %s seeds %s ref %s delta %s; cpu %s" % (q.get("precision_at_10"), q.get("precision_at_10_seeds"), q.get("precision_at_10_ref"), q.get("delta"), (d.get("cpu_baseline") or {}).get("thread_scaling")))
+except Exception as e:
+    print("  no quality result:", e)
+PY
+  # C5: instruction mix of the row-stream kernel (one PMC pass, --scale 0.1)
+  cd /tmp && export TMPDIR=/tmp
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/c5pmc -o pmc -- python $R/bench.py $S --config c5shard --scale 0.1 --steps 2 --warmup 1 --epochs-per-step 1 > $OUT/c5pmc.json 2> $OUT/c5pmc.err
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_SENDMSG -d $OUT/c5pmc2 -o pmc -- python $R/bench.py $S --config c5shard --scale 0.1 --steps 2 --warmup 1 --epochs-per-step 1 > $OUT/c5pmc2.json 2> $OUT/c5pmc2.err
+  cd $R && python - <<PY
+import sqlite3, json, glob
+for sub in ("c5pmc", "c5pmc2"):
+    try:
+        db = glob.glob("$OUT/%s/**/*results.db" % sub, recursive=True)[0]
+        con = sqlite3.connect(db)
+        rows = con.execute("select k.name, p.counter_name, count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+        b = json.load(open("$OUT/%s.json" % sub))
+        tot = {}
+        for name, c, nd, v in rows:
+            if "fit_feat" in name: tot[c] = tot.get(c, 0) + v
+        n_int = 26001838 * 5.0   # interactions of all profiled epochs (ramp + early + warm-up + timed = 5 epochs at --scale 0.1)
+        print("  %s (%.1f M/s):" % (sub, b["value"] / 1e6), {c: round(v / n_int, 1) for c, v in tot.items()}, "per interaction (5 epochs assumed)")
+    except Exception as e:
+        print("  %s: %r" % (sub, e))
+PY
+  find $OUT -name "*.db" -size +5M -delete
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
