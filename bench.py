@@ -430,7 +430,9 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     launches = sum(int(s.launches) for s in stats)
     ng, used = int(stats[-1].tile_ng), int(stats[-1].kernel_used)
     reg = bool(args.item_alpha or args.user_alpha)
-    if used == 1:
+    if used == 1 and int(getattr(stats[-1], "tile_ahead", 0)):
+        kernel_name = "fit_warp_tile_ahead_kernel<10, false>"
+    elif used == 1:
         kernel_name = "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
             "true" if reg else "false")

@@ -134,7 +134,9 @@ typedef struct lfm_opts {
     int32_t streams_used;       /* out: HIP streams the epoch's launches were spread over: 2 when consecutive
                                    full-residency launches of the tile kernel alternated between the session's
                                    two streams (see `debug` bit 7), else 1                                      */
-    int32_t reserved0;          /* (keeps the struct's size a multiple of 8 explicit) */
+    int32_t tile_ahead;         /* out: 1 when the epoch's last launch ran the steady-state variant of the tile kernel
+                                   with the next pass's gather issued inside the current pass (csrc/warp_tile_ahead.hpp;
+                                   `debug` bit 10 = 1024 keeps the plain tile kernel)                            */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0
@@ -335,6 +337,18 @@ int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32_t sides, i
 int lfm_sessions_merge_local_sparse(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap);
 int lfm_sessions_merge_local_flush(lfm_session **sessions, int32_t k);
 int lfm_sessions_merge_local_hot(lfm_session **sessions, int32_t k, int32_t sides, int32_t mode, int32_t overlap);
+
+/* OWNER-SHARDED item tables, one-device form (tests / emulation; no reference counterpart).  For an item side too
+ * large to replicate and merge -- BASELINE config C4: 2.6 GB of tables against 57 ms of kernels per epoch, every
+ * rank touches nearly every row within one merge interval (DESIGN.md "Multi-GPU") -- the tables are cut into K
+ * contiguous row ranges, range j lives with owner j, and every rank's kernels gather from and publish to the
+ * OWNER's copy (global_atomic_add_f32 into the owner's memory): no replicas, no merges, plain Hogwild across all
+ * ranks.  This call wires K training sessions of ONE device that way (session j owns rows [j * rps, (j + 1) * rps),
+ * rps = ceil(n_items / K); the other rows of a session's own tables are then unused); in the multi-GPU form the
+ * K base pointers are peer mappings of the owners' memory over xGMI.  Parallel WARP with identity features,
+ * adagrad, no regularisation, d <= 64, max_sampled = 10 (the steady-state tile kernel); lfm_session_epoch fails
+ * with LFM_EUNSUPPORTED otherwise. */
+int lfm_sessions_share_items_local(lfm_session **sessions, int32_t k);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ class LfmOpts(C.Structure):
                 ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32),
                 ("kernel_used", C.c_int32), ("shared_cap", C.c_int32),
                 ("pos_begin", C.c_int64), ("pos_end", C.c_int64),
-                ("streams_used", C.c_int32), ("reserved0", C.c_int32)]
+                ("streams_used", C.c_int32), ("tile_ahead", C.c_int32)]
 
 
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)
@@ -71,6 +71,7 @@ EXPORTS = (
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
     "lfm_session_comm_any", "lfm_session_comm_barrier", "lfm_sessions_merge_local",
+    "lfm_sessions_share_items_local",
 )
 MERGE_SUM, MERGE_MEAN, MERGE_ADAGRAD = 0, 1, 2
 MERGE_MODES = {"sum": MERGE_SUM, "mean": MERGE_MEAN, "adagrad": MERGE_ADAGRAD}

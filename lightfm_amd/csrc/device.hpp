@@ -45,6 +45,18 @@ struct DModel {
     double *scales;  // device [2]: item_scale, user_scale (PYX:214-215)
 };
 
+// Owner-sharded item tables (warp_tile_ahead.hpp, SHARDED): the item-side tables of a multi-GPU job whose item side
+// is too large to replicate and merge (BASELINE config C4: 2.6 GB of tables against 57 ms of kernels per epoch) are
+// cut into n contiguous row ranges of rows_per_shard rows; range j lives in the memory of its owner (a peer GPU
+// reached over xGMI, or -- tests / one-GPU emulation -- another session of this device) and every rank gathers from
+// and publishes to the owner's copy: no replicas, no merges, plain Hogwild.  W[j] / G[j] / b[j] / bG[j] point to
+// the FIRST ROW OF RANGE j (item row j * rows_per_shard).
+struct ItemShards {
+    float *W[8], *G[8], *b[8], *bG[8];
+    int32_t n;                       // 0: not sharded (a.m.W[0] ... are the tables)
+    uint32_t rows_per_shard, magic;  // magic = floor(2^32 / rows_per_shard) + 1 (exact division of ids < 2^31)
+};
+
 struct FitArgs {
     DCsr itf, usf, pos;
     DModel m;
@@ -72,6 +84,7 @@ struct FitArgs {
     int32_t *neg_log, *sampled_log;
     unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
     const uint32_t *bloom;         // Bloom filter over the positives lookup (struct Bloom below), nullptr = none
+    ItemShards shards;             // owner-sharded item tables (n = 0: none)
     float *reg_live;               // [RegScale::FLOATS] parallel mode, lazy L2 regularisation (see RegScale): line 0 =
                                    // min(item_scale, MAX), min(user_scale, MAX) at the last launch boundary, lines 1.. =
                                    // the slots collecting the growth of log(scale) since then (float atomics)

@@ -368,6 +368,7 @@ struct lfm_session {
     hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
+    ItemShards shards = {};  // owner-sharded item tables (lfm_sessions_share_items_local); n = 0: this session's own tables
     DBuf<uint32_t> bloom;  // Bloom filter over the rows of `pos` (device.hpp: Bloom), built with the lookup
     bool bloom_valid = false;
     bool recs_valid = false;
@@ -1345,6 +1346,41 @@ extern "C" int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32
     return merge_group(sessions, k, k, sides, mode);
 }
 
+// Owner-sharded item tables over K sessions of ONE device (device.hpp: ItemShards): session j owns the item rows
+// [j * rps, (j + 1) * rps), rps = ceil(n_items / K), and every session's epoch kernels gather from and publish to
+// the owner's tables.  The one-device form of the multi-GPU decomposition for item sides too large to replicate
+// and merge (DESIGN.md "Multi-GPU": C4): there the K base pointers are peer mappings of the owners' memory.
+extern "C" int lfm_sessions_share_items_local(lfm_session **sessions, int32_t k)
+{
+    if (!sessions || k < 1 || k > 8) return fail(LFM_EINVAL, "1 to 8 sessions");
+    lfm_session *s0 = sessions[0];
+    for (int i = 0; i < k; ++i) {
+        lfm_session *s = sessions[i];
+        if (!s || s->device != s0->device || s->scoring_only || s->n_feat[0] != s0->n_feat[0] || s->d != s0->d ||
+            s->adadelta || !s->itf.identity || s->comm)
+            return fail(LFM_EINVAL, "sharing needs training sessions of one device with the same identity item side, adagrad, no communicator");
+    }
+    const uint32_t n_items = (uint32_t)s0->n_feat[0];
+    if (n_items < (uint32_t)k) return fail(LFM_EINVAL, "fewer item rows than sessions");
+    const uint32_t rps = (n_items + (uint32_t)k - 1) / (uint32_t)k;
+    for (int i = 0; i < k; ++i) {
+        ItemShards &sh = sessions[i]->shards;
+        memset(&sh, 0, sizeof(sh));
+        sh.n = k;
+        sh.rows_per_shard = rps;
+        sh.magic = (uint32_t)((1ull << 32) / (uint64_t)rps) + 1u;
+        for (int j = 0; j < 8; ++j) {
+            lfm_session *owner = sessions[std::min(j, k - 1)];
+            const size_t first = (size_t)std::min<uint32_t>((uint32_t)j * rps, n_items);
+            sh.W[j] = owner->tab[0][0].p + first * (size_t)owner->d;
+            sh.G[j] = owner->tab[0][1].p + first * (size_t)owner->d;
+            sh.b[j] = owner->tab[0][3].p + first;
+            sh.bG[j] = owner->tab[0][4].p + first;
+        }
+    }
+    return LFM_OK;
+}
+
 extern "C" int lfm_session_comm_any(lfm_session *s, int32_t flag)
 {
     if (!s) return fail(LFM_EINVAL, "null session");
@@ -1555,6 +1591,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // in_positives pre-filter of the tile kernel (debug bit 8 = 256: off; bit 9 = 512: probed for every candidate
     // together with its row instead of after the scoring pass for the violators only)
     a.bloom = (s->bloom_valid && !(opts->debug & 256)) ? s->bloom.p : nullptr;
+    a.shards = s->shards;
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
     // never calls log(): PYX:881 / C_OMP:7446 (WARP), PYX:1039 / C_OMP:8452 (k-OS).
@@ -1650,6 +1687,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             }
             use_tile = true;
         }
+        if (s->shards.n > 0 && !(tile[4].ok && tile[4].ahead))
+            return fail(LFM_EUNSUPPORTED, "owner-sharded item tables run on the steady-state tile kernel only (parallel WARP, identity "
+                                          "features, adagrad, no regularisation, d <= 64, max_sampled = 10)");
         if (use_tile) {
             a.n_items_magic = (uint32_t)((1ull << 32) / (uint64_t)s->itf.rows) + 1u;
             if (!s->recs_valid) {
@@ -1661,6 +1701,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         }
     }
 
+    if (s->shards.n > 0 && !use_tile)
+        return fail(LFM_EUNSUPPORTED, "owner-sharded item tables run on the steady-state tile kernel only (parallel WARP, identity "
+                                      "features, adagrad, no regularisation, d <= 64, max_sampled = 10)");
     // Every other parallel-mode adagrad model (with or without L2 regularisation): the pipelined row-stream kernels
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
     FeatPlan fplan;
@@ -1744,7 +1787,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const int64_t allowed = allowed_in_flight(begin - seg_begin);
             // pick the kernel variant for this launch
             int ng = 0;
-            if (use_tile) {
+            if (use_tile && s->shards.n > 0) ng = 4;  // the only kernel that addresses sharded item tables
+            else if (use_tile) {
                 for (int c : {4, 2, 1})
                     if (!ng && tile[c].ok && (allowed / c >= (int64_t)s->cus * 8 || c == 1)) ng = c;
                 if (!ng)
@@ -1888,6 +1932,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     opts->in_flight = in_flight;
     opts->launches = n_launches;
     opts->streams_used = used_second_stream ? 2 : 1;
+    opts->tile_ahead = (tile_ng_used == 4 && tile[4].ahead) ? 1 : 0;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));

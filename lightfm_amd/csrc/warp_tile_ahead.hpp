@@ -26,7 +26,69 @@
 
 namespace lfm {
 
-template <int NBF>
+// Where an item row lives.  SHARDED = false: one table (base + row * d).  SHARDED = true: device.hpp: ItemShards --
+// the row's range j = row / rows_per_shard picks the owner's base pointer (a select chain over <= 8 pointers: a
+// dynamically indexed kernel-argument array would go through scratch memory), the rest of the id is the row inside.
+template <bool SHARDED>
+struct ItemAddr {
+    const ItemShards &sh;
+    float *W0, *G0, *b0, *bG0;
+    const float *bread0;
+    int d;
+    __device__ __forceinline__ static float *pick(float *const (&p)[8], uint32_t j)
+    {
+        float *a01 = (j & 1u) ? p[1] : p[0], *a23 = (j & 1u) ? p[3] : p[2];
+        float *a45 = (j & 1u) ? p[5] : p[4], *a67 = (j & 1u) ? p[7] : p[6];
+        float *lo = (j & 2u) ? a23 : a01, *hi = (j & 2u) ? a67 : a45;
+        return (j & 4u) ? hi : lo;
+    }
+    __device__ __forceinline__ void split(int row, uint32_t &j, uint32_t &local) const
+    {
+        j = __umulhi((uint32_t)row, sh.magic);
+        int r = row - (int)(j * sh.rows_per_shard);
+        if (r < 0) {  // magic = floor(2^32 / n) + 1 overshoots by at most one
+            --j;
+            r += (int)sh.rows_per_shard;
+        }
+        local = (uint32_t)r;
+    }
+    __device__ __forceinline__ float *W(int row) const
+    {
+        if constexpr (!SHARDED) return W0 + (size_t)row * d;
+        uint32_t j, l;
+        split(row, j, l);
+        return pick(sh.W, j) + (size_t)l * d;
+    }
+    __device__ __forceinline__ float *G(int row) const
+    {
+        if constexpr (!SHARDED) return G0 + (size_t)row * d;
+        uint32_t j, l;
+        split(row, j, l);
+        return pick(sh.G, j) + (size_t)l * d;
+    }
+    __device__ __forceinline__ float *b(int row) const
+    {
+        if constexpr (!SHARDED) return b0 + row;
+        uint32_t j, l;
+        split(row, j, l);
+        return pick(sh.b, j) + l;
+    }
+    __device__ __forceinline__ float *bG(int row) const
+    {
+        if constexpr (!SHARDED) return bG0 + row;
+        uint32_t j, l;
+        split(row, j, l);
+        return pick(sh.bG, j) + l;
+    }
+    // the bias the SCORING reads: the launch's cached snapshot, or -- sharded -- the owner's live cell
+    __device__ __forceinline__ const float *bscore(int row) const
+    {
+        if constexpr (!SHARDED) return bread0 + row;
+        return b(row);
+    }
+};
+
+template <int NBF, bool SHARDED = false>
 __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 {
     constexpr int LPR = 16, VEC = 4, NG = 4;
@@ -47,8 +109,9 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
     float *vrows = tile + (size_t)g * GS;
     float *urow = tile + UB + (size_t)g * US;
     const bool pc = VEC * p < d;
-    const float *Wi = a.m.W[0], *Wu = a.m.W[1];
-    const float *bi_tab = a.b_read[0], *bu_tab = a.b_read[1];
+    const float *Wu = a.m.W[1];
+    const float *bu_tab = a.b_read[1];
+    const ItemAddr<SHARDED> item{a.shards, a.m.W[0], a.m.G[0], a.m.b[0], a.m.bG[0], a.b_read[0], d};
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
     const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
@@ -66,7 +129,6 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
     const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
-    float *WiW = a.m.W[0], *Gi = a.m.G[0];
     float *WuW = a.m.W[1], *Gu = a.m.G[1];
 
     // The whole first-batch gather of one pass: straight-line, every lane takes part (the record of a
@@ -81,13 +143,13 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
             float *ub = tile + UB + __builtin_amdgcn_readfirstlane(gg) * (US - LPR * VEC);
             if (g == gg && pc) dma_lane_x4(Wu + (size_t)user * d + VEC * p, ub);
         }
-        if (pc) dma_lane_x4(Wi + (size_t)pos * d + VEC * p, tile);  // row 0 of every group
+        if (pc) dma_lane_x4(item.W(pos) + VEC * p, tile);  // row 0 of every group
 #pragma unroll
         for (int k = 1; k <= NBF; ++k) {
             const int neg = row_bcast(myitem, k);
-            if (pc) dma_lane_x4(Wi + (size_t)neg * d + VEC * p, tile + (size_t)k * KS);
+            if (pc) dma_lane_x4(item.W(neg) + VEC * p, tile + (size_t)k * KS);
         }
-        dma_lane_dword(bi_tab + myitem, tile + BB);
+        dma_lane_dword(item.bscore(myitem), tile + BB);
         dma_lane_dword(bu_tab + user, tile + BB + WAVE);
     };
 
@@ -175,22 +237,22 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
         // the first violator's update: one round trip, behind the gather's
         float gP[NG], gN[NG], gU[NG], obW[NG], obG[NG];
         auto load_rows = [&](int gg, int user, int pos, int neg, bool only_neg) {
-            const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+            const size_t bu_ = (size_t)user * d;
             unsigned cc = lane < d ? (unsigned)lane : 0u;
             asm volatile("" : "+v"(cc));  // uniform row base + a lane offset the compiler cannot hoist
-            gN[gg] = (Gi + bn)[cc];
-            if (only_neg) cN[gg] = (Wi + bn)[cc];  // the choice is a later violator: its row is re-read (weights as of now)
+            gN[gg] = item.G(neg)[cc];
+            if (only_neg) cN[gg] = item.W(neg)[cc];  // the choice is a later violator: its row is re-read (weights as of now)
             if (!only_neg) {
-                gP[gg] = (Gi + bp)[cc];
+                gP[gg] = item.G(pos)[cc];
                 gU[gg] = (Gu + bu_)[cc];
             }
             // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
-            const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-            const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
-            const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
+            const int irow = lane == 0 ? pos : neg;
+            const float *bWp = lane >= 2 ? a.m.b[1] + user : item.b(irow);
+            const float *bGp = lane >= 2 ? a.m.bG[1] + user : item.bG(irow);
             if (!only_neg || lane == 1) {
-                obW[gg] = bWp[brow];
-                obG[gg] = bGp[brow];
+                obW[gg] = *bWp;
+                obG[gg] = *bGp;
             }
         };
         if (__ballot(act) != 0ull) {
@@ -267,7 +329,8 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                     const int pos = __builtin_amdgcn_readlane(c_pos, gg * LPR);
                     const int neg = __builtin_amdgcn_readlane(chosen, gg * LPR);
                     const double loss = read_laned(lossd, gg * LPR);
-                    const size_t bp = (size_t)pos * d, bn = (size_t)neg * d, bu_ = (size_t)user * d;
+                    const size_t bu_ = (size_t)user * d;
+                    float *const wP = item.W(pos), *const wN = item.W(neg), *const aP = item.G(pos), *const aN = item.G(neg);
                     const float Ur = cU[gg], Pr = cP[gg], Nr = cN[gg];
                     const double u = (double)Ur;
                     const double df = (double)__fsub_rn(Nr, Pr);  // float32 subtraction, PYX:634-635
@@ -282,19 +345,19 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                     if (lane < d) {
                         unsigned cq = (unsigned)lane;
                         asm volatile("" : "+v"(cq));
-                        publish(WiW + bp + cq, nWP, Pr, um);
-                        publish(Gi + bp + cq, nGP, gP[gg], um);
-                        publish(WiW + bn + cq, nWN, Nr, um);
-                        publish(Gi + bn + cq, nGN, gN[gg], um);
+                        publish(wP + cq, nWP, Pr, um);
+                        publish(aP + cq, nGP, gP[gg], um);
+                        publish(wN + cq, nWN, Nr, um);
+                        publish(aN + cq, nGN, gN[gg], um);
                         publish(WuW + bu_ + cq, nWU, Ur, um);
                         publish(Gu + bu_ + cq, nGU, gU[gg], um);
                     }
                     if (lane < 3) {
-                        const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
-                        float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
-                        float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
-                        publish(bWp + brow, bnW, obW[gg], um);
-                        publish(bGp + brow, bnG, obG[gg], um);
+                        const int irow = lane == 0 ? pos : neg;
+                        float *bWp = lane == 2 ? a.m.b[1] + user : item.b(irow);
+                        float *bGp = lane == 2 ? a.m.bG[1] + user : item.bG(irow);
+                        publish(bWp, bnW, obW[gg], um);
+                        publish(bGp, bnG, obG[gg], um);
                     }
                 }
             }

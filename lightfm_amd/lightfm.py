@@ -164,6 +164,13 @@ class _Session(object):
         N.check(N.lib().lfm_sessions_merge_local_hot(arr, len(sessions), sides, mode, int(bool(overlap))))
 
     @staticmethod
+    def share_items_local(sessions):
+        """Owner-sharded item tables over K sessions of one device (lfm_sessions_share_items_local): session j owns
+        the item rows [j * rps, (j + 1) * rps), rps = ceil(n_items / K); every session trains against the owners' rows."""
+        arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
+        N.check(N.lib().lfm_sessions_share_items_local(arr, len(sessions)))
+
+    @staticmethod
     def merge_local_flush(sessions):
         arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
         N.check(N.lib().lfm_sessions_merge_local_flush(arr, len(sessions)))

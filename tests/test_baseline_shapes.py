@@ -43,7 +43,11 @@ def _spread(st, rng):
     st.user_biases[:] = rng.randn(len(st.user_biases)).astype(np.float32) * 0.3
 
 
-def test_c2_shape_default_launch_plan_samples_exact():
+@pytest.mark.parametrize("variant", ["steady-state", "plain"])
+def test_c2_shape_default_launch_plan_samples_exact(variant):
+    """variant: the kernel the default plan runs at this shape -- the gather-ahead steady-state variant
+    (csrc/warp_tile_ahead.hpp) -- and the plain four-per-pass tile kernel it replaces there (debug bit 10; what
+    every other max_sampled, adadelta and regularised models run)."""
     _need_gpu()
     from lightfm_amd import synthetic
     from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
@@ -62,7 +66,7 @@ def test_c2_shape_default_launch_plan_samples_exact():
     item_f, user_f = H.identity_features(ni), H.identity_features(nu)
 
     options.set(mode="parallel", launches_per_epoch=0, ramp_k=-1, max_waves=0, first_batch=0, warp_kernel=0,
-                update_mode=0, debug=0)
+                update_mode=0, debug=0 if variant == "steady-state" else 1024)
     fl = FastLightFM(*a.arrays(), d, 0, a.lr, a.rho, a.eps, a.max_sampled)
     session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f))
     try:
@@ -79,6 +83,7 @@ def test_c2_shape_default_launch_plan_samples_exact():
     neg, sampled = logs
     # the plan that ran is the one bench.py times
     assert opts.kernel_used == 1 and opts.tile_ng == 4, (opts.kernel_used, opts.tile_ng)
+    assert opts.tile_ahead == (1 if variant == "steady-state" else 0), "the steady-state (gather-ahead) variant is what bench.py times"
     assert opts.launches >= 3, opts.launches
     assert opts.streams_used == 2, "the second stream was not used"
     assert opts.in_flight >= 256 * 3 * 4 * 4, opts.in_flight  # >= 3 workgroups per CU at full residency
