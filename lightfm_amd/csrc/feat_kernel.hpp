@@ -536,7 +536,26 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if (lane >= 1 && lane <= no_pos)  // sample_range, PYX:84-90
                         it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
                     state = (uint32_t)read_lane((int)s, no_pos);
+#ifndef LFM_KOS_SPLIT_GATHER
+                    // The first batch of candidate negatives is known already (its draws follow the positives' in the
+                    // position's stream): its representations are built in the SAME pass as the user's and the sampled
+                    // positives' -- one extent fetch, one entry list, one sequence of row gathers for all 1 + n + batch
+                    // jobs instead of two (two round trips fewer per interaction; the sampling loop below then finds
+                    // its first batch in the tile)
+                    {
+                        const int nb0 = min(max_sampled, min(a.first_batch, CB));
+                        uint32_t s2 = state;  // lane k: the stream after min(k + 1, nb0) steps
+                        for (int j = 0; j < nb0; ++j)
+                            if (j <= lane) s2 = lcg(s2);
+                        const int myneg0 = (int)(draw(s2) % (uint32_t)a.itf.rows);  // PYX:1014-1016
+                        const int ck = max(lane - no_pos - 1, 0);
+                        const int cand0 = __shfl(myneg0, ck, WAVE);
+                        build_reps(lane == 0 ? user : (lane <= no_pos ? it : cand0), lane == 0 ? 1 : 0,
+                                   lane <= no_pos ? lane : cand_base + ck, 1 + no_pos + nb0, nullptr);
+                    }
+#else
                     build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos, nullptr);
+#endif
                     if (lane >= 1 && lane <= no_pos) {
                         pair_idx[lane - 1] = it;
                         pair_val[lane - 1] = tile_dot(reps, reps + (size_t)lane * TS, d);
@@ -584,6 +603,9 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         lo = uni(lo_v);
                         hi = uni(hi_v);
                     } else {
+#ifndef LFM_KOS_SPLIT_GATHER
+                        if (!(LOSS == LFM_LOSS_WARP_KOS_ID && sampled == 0))  // k-OS: the first batch is in the tile already
+#endif
                         build_reps(myneg, 0, cand_base + lane, nb, nullptr);
                     }
                     float sc = 0.0f;

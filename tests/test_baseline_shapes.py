@@ -185,3 +185,50 @@ def test_c1_ml100k_serial_ten_epochs_bit_exact_vs_reference():
     p_ref = precision_at_k(ref, test, train_interactions=train, k=10).mean()
     assert p_hip == p_ref
     assert p_hip > 0.03  # well above the 10 / 1,682 of random ranking: the model learned
+
+
+def test_c3_shape_default_launch_plan_samples_exact():
+    """BASELINE configs[2]: ML-20M shape, loss = 'bpr', no_components = 128, item features [identity | 8 tags of
+    1,128].  The row-stream kernel (csrc/feat_kernel.hpp) under the default launch plan at full residency
+    (2 048 interactions in flight), frozen weights: every position's negative and draw count (BPR draws until
+    the candidate is not one of the user's positives, PYX:1123-1127) and the counters equal the oracle's."""
+    _need_gpu()
+    from lightfm_amd import synthetic
+    from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM, make_opts
+    from lightfm_amd.lightfm import _Session
+    from lightfm_amd.options import options
+    nu, ni, d = ML20M_USERS, ML20M_ITEMS, 128
+    coo = synthetic.make_interactions(nu, ni, 1_200_000, seed=44)
+    n = coo.nnz
+    item_f = synthetic.tag_item_features(ni)
+    user_f = H.identity_features(nu)
+    rng = np.random.RandomState(19)
+    st = oracle.State(item_f.shape[1], nu, d, rng)
+    st.item_embeddings *= 40.0
+    st.user_embeddings *= 40.0
+    st.item_biases[:] = rng.randn(item_f.shape[1]).astype(np.float32) * 0.3
+    a, b = st.copy(), st.copy()
+    zeros = np.zeros_like(coo.data)
+    seeds = rng.randint(0, np.iinfo(np.int32).max, size=1).astype(np.uint32)
+    options.set(mode="parallel", launches_per_epoch=0, ramp_k=-1, max_waves=0, first_batch=0, feat_kernel=0, update_mode=0, debug=0)
+    fl = FastLightFM(*a.arrays(), d, 0, a.lr, a.rho, a.eps, a.max_sampled)
+    session = _Session(fl, CSRMatrix(item_f), CSRMatrix(user_f))
+    try:
+        session.set_interactions(None, np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col), coo.data, zeros)
+        session.build_positives(nu, ni)
+        session.device_shuffle(424242, 171717)
+        shuffle = session.download_shuffle(n)
+        opts, logs = make_opts(n, want_log=True)
+        session.epoch("bpr", 0.0, 0.0, 5, 10, seeds, opts)
+        session.sync_to_host(fl)
+    finally:
+        session.close()
+    neg, sampled = logs
+    assert opts.kernel_used == 2 and opts.in_flight >= 2048, (opts.kernel_used, opts.in_flight)
+    o = oracle.Opts(n, rng_mode=1, log=True)
+    oracle.fit_bpr(item_f, user_f, H.positives_csr(coo), coo.row, coo.col, coo.data, zeros, shuffle, b, 0.0, 0.0, seeds, o)
+    assert np.array_equal(sampled, o.sampled), "draw counts differ at %d positions" % int((sampled != o.sampled).sum())
+    assert np.array_equal(neg, o.neg), "negatives differ at %d positions" % int((neg != o.neg).sum())
+    assert list(opts.counters) == o.counters, (list(opts.counters), o.counters)
+    assert (o.sampled > 1).sum() > 100, "the case should include draws that hit a positive"
+    H.assert_states_equal(a, st, exact=True)

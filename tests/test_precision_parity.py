@@ -112,3 +112,12 @@ def test_warp_kos_shared_tag_rows():
     train, test = _data(4000, 3000, 300_000)
     feats = synthetic.tag_item_features(3000, n_tags=100, per_item=4)
     _gap("warp-kos", 64, train, test, feats, epochs=5)
+
+
+@pytest.mark.timeout(900)
+def test_warp_identity_c2_regime_regularised():
+    """The same regime with L2 regularisation (item_alpha = user_alpha = 1e-6): the REG instantiation of the
+    tile kernel -- lazy scales extrapolated per launch, folds on the device (device.hpp: RegScale) -- against
+    the reference's racy `scale *= 1 + alpha lr` (PYX:640-691)."""
+    train, test = _data(17312, 13372, 2_500_000)
+    _gap("warp", 64, train, test, None, epochs=5, item_alpha=1e-6, user_alpha=1e-6)

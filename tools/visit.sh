@@ -302,6 +302,61 @@ for sub in ("c5pmc", "c5pmc2"):
 PY
   find $OUT -name "*.db" -size +5M -delete
   ;;
+r4d)
+  # round 4: the driver's sequence on the current tree -- full GPU suite, smoke, the default bench line (with the
+  # extra_configs legs, their cpu baselines, early_epochs, thread scaling)
+  timeout -k 5 1500 $PYT tests -m gpu -x -q > $OUT/suite.log 2>&1
+  echo "suite: exit $?  $(grep -aE ' passed| failed' $OUT/suite.log | tail -1)"; summ $OUT/suite.log 12
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ( time timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2>&1 | grep real
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_default.json"))
+    def show(n, v, r, e, c):
+        print("  %-8s %8.1f M/s  frac %.3f  atomic %.3f  launch %.3f ms  U %.3f  traffic %s  early %.1f M/s  cpu %s  %s" % (n, v / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r.get("traffic_over_algorithmic"), (e or {}).get("value", 0) / 1e6, (c or {}).get("value"), r["kernel"]))
+    show("c2", d["value"], d["roofline"], d.get("early_epochs"), d.get("cpu_baseline"))
+    for e in d.get("extra_configs", []):
+        if "error" in e: print("  ", e)
+        else: show(e["name"], e["value"], e["roofline"], e.get("early_epochs"), e.get("cpu_baseline"))
+    q = d.get("quality") or {}
+    print("  quality", q.get("precision_at_10"), q.get("precision_at_10_ref"), q.get("delta"))
+    print("  cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("thread_scaling"), "fit", (d.get("end_to_end_fit") or {}).get("value"))
+except Exception as e:
+    print("  no result:", e)
+PY
+  tail -3 $OUT/bench_default.err | cut -c1-300
+  ;;
+r4e)
+  # round 4: knob sweep of the row-stream kernel on the C5 shard (--scale 0.25; no code change): candidate batch,
+  # wavefronts per workgroup, LDS budget / residency
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  ENVV= run c5_default $C5
+  for fb in 3 5 7; do ENVV= run c5_fb$fb $C5 --first-batch $fb; done
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_BLOCK=2" run c5_wpb2 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_BLOCK=4" run c5_wpb4 $C5
+  ENVV="LIGHTFM_AMD_FEAT_LDS_KB=22 LIGHTFM_AMD_FEAT_WAVES_PER_CU=7" run c5_lds22_w7 $C5
+  ENVV="LIGHTFM_AMD_FEAT_LDS_KB=26 LIGHTFM_AMD_FEAT_WAVES_PER_CU=6" run c5_lds26_w6 $C5
+  ENVV= run c5_default_2 $C5
+  # k-OS: candidates' representations built in the same pass as the positives' (default) against the split gather
+  ENVV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_split/liblfm_hip.so" run c5_split_gather $C5
+  ENVV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_split/liblfm_hip.so" run c5_split_gather_2 $C5
+  ENVV= run c5_default_3 $C5
+  timeout -k 5 900 $PYT tests/test_hip_feat.py tests/test_hip_parity.py "tests/test_baseline_shapes.py::test_c3_shape_default_launch_plan_samples_exact" "tests/test_precision_parity.py::test_warp_identity_c2_regime_regularised" "tests/test_precision_parity.py::test_warp_kos_shared_tag_rows" tests/test_golden.py -m gpu -q -x -s > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  grep -a "per side, fixed" $OUT/tests.log | cut -c1-220
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
