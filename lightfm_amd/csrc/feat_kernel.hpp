@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if (lane >= 1 && lane <= no_pos)  // sample_range, PYX:84-90
                         it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
                     state = (uint32_t)read_lane((int)s, no_pos);
-#ifndef LFM_KOS_SPLIT_GATHER
+#ifdef LFM_KOS_MERGED_GATHER  // A/B build (profiles/r04_visit_e.txt: 3 % SLOWER on C5 -- the kernel is issue-bound, and one 21-job list costs more instructions than two lists save round trips)
                     // The first batch of candidate negatives is known already (its draws follow the positives' in the
                     // position's stream): its representations are built in the SAME pass as the user's and the sampled
                     // positives' -- one extent fetch, one entry list, one sequence of row gathers for all 1 + n + batch
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         lo = uni(lo_v);
                         hi = uni(hi_v);
                     } else {
-#ifndef LFM_KOS_SPLIT_GATHER
+#ifdef LFM_KOS_MERGED_GATHER
                         if (!(LOSS == LFM_LOSS_WARP_KOS_ID && sampled == 0))  // k-OS: the first batch is in the tile already
 #endif
                         build_reps(myneg, 0, cand_base + lane, nb, nullptr);
