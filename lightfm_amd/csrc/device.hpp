@@ -332,6 +332,25 @@ __device__ __forceinline__ float tile_dot(const float *u, const float *v, int d)
     float acc = __fadd_rn(u[d], v[d]);
     int c = 0;
     if ((d & 3) == 0) {
+        // 16 components per step: eight ds_read_b128 in flight, the products (independent) before the additions (one
+        // sequential chain) -- the LDS latency is paid once per 16 components instead of once per 4
+        for (; c + 16 <= d; c += 16) {
+            float4 a[4], x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = *reinterpret_cast<const float4 *>(u + c + 4 * j);
+                x[j] = *reinterpret_cast<const float4 *>(v + c + 4 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = __fmul_rn(a[j].x, x[j].x), p1 = __fmul_rn(a[j].y, x[j].y);
+                const float p2 = __fmul_rn(a[j].z, x[j].z), p3 = __fmul_rn(a[j].w, x[j].w);
+                acc = __fadd_rn(acc, p0);
+                acc = __fadd_rn(acc, p1);
+                acc = __fadd_rn(acc, p2);
+                acc = __fadd_rn(acc, p3);
+            }
+        }
         for (; c < d; c += 4) {
             float4 a = *reinterpret_cast<const float4 *>(u + c);
             float4 x = *reinterpret_cast<const float4 *>(v + c);

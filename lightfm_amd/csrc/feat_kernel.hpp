@@ -76,12 +76,17 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const int lane = lane_id(), wib = uni((int)(threadIdx.x >> 6));
     const int d = a.m.d, TS = a.tile_stride, RR = a.tile_rows, SR = a.stage_rows;
     const int LPR = d >> 2, RPI = WAVE / LPR;  // lanes per row, rows per DMA instruction
-    const size_t wave_floats = (size_t)SR * d + (size_t)RR * TS + 3 * (size_t)a.pair_cap;
+    const size_t wave_floats = (size_t)SR * d + (size_t)RR * TS + 3 * (size_t)a.pair_cap + 2 * WAVE;
     float *stage = smem + (size_t)wib * wave_floats;  // [SR][d] packed: what LDS-DMA deposits
     float *reps = stage + (size_t)SR * d;              // [RR][TS] representations, bias in column d
     int *pair_idx = reinterpret_cast<int *>(reps + (size_t)RR * TS);  // k-OS (PYX:109-111)
     float *pair_val = reinterpret_cast<float *>(pair_idx + a.pair_cap);
     int *pair_slot = reinterpret_cast<int *>(pair_val + a.pair_cap);
+    // weights and biases of a round's entries, by entry (fast reduce below): LDS broadcasts instead of lane reads
+    float *wl = reinterpret_cast<float *>(pair_slot + a.pair_cap), *bl = wl + WAVE;
+    // d == 64 NC (d = 64 or 128: every BASELINE configuration): the reduce runs with compile-time LDS offsets
+    constexpr int DF = 64 * NC;
+    const bool fastd = d == DF;
     const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
     const int max_sampled = a.m.max_sampled;
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         if (keep) keep->n = -1;
         int cur = -1;
         float acc[NC], accb = 0.0f;
+        float accb_job = 0.0f;  // fast reduce: lane j = the bias accumulator of job j
         int cc_[NC];  // this lane's components, lanes past d clamped to component 0 (never stored)
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 const int c = lane + WAVE * q;
                 if (c < d) rp[c] = acc[q];
             }
-            if (lane == 0) rp[d] = accb;
+            if (!fastd && lane == 0) rp[d] = accb;  // (fast reduce: the bias column is written once, after the last round)
         };
         for (int r = 0; r * WAVE < T; ++r) {
             Entries e;
@@ -209,12 +215,63 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             if (lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
             if constexpr (TIMED) asm volatile("" : "+v"(e.feat), "+v"(e.w));
             stamp(1);
+            // end of every job's entries inside this round (lane j = job j), for the fast reduce
+            const int jend_round = off + len - r * WAVE;
             for (int ce = 0; ce < e.n; ce += SR) {
                 const int nc = min(SR, e.n - ce);
                 dma_rows(e.feat, e.eside, ce, nc, stage, false);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
+                if (fastd) {
+                    if (ce == 0) {  // the round's weights (PYX:306: data * scale through float64) and biases, by entry
+                        float wv = e.w;
+                        if constexpr (REG) wv = (float)((double)wv * (double)(e.eside ? wsc_u : wsc_i));
+                        wl[lane] = wv;
+                        bl[lane] = bx;
+                        wave_sync();
+                    }
+                    // Fast reduce (d = 64 NC): job by job, four entries per step.  Within a job the float32 accumulation
+                    // is one sequential chain in CSR order (PYX:306-313); everything around it is now cheap: the rows'
+                    // LDS offsets are compile-time constants of ONE address register, the weights are LDS broadcasts
+                    // (two ds_read2 per four entries instead of one lane read per entry), and the bias column is
+                    // summed afterwards by one lane per job.
+                    for (int t = ce; t < ce + nc;) {
+                        const int jt = read_lane(e.job, t);
+                        if (jt != cur) {
+                            if (cur >= 0) flush();
+                            cur = jt;
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+                        }
+                        const int jend = min(ce + nc, read_lane(jend_round, jt));
+                        const float *xb = stage + (size_t)(t - ce) * DF + lane;  // this lane's components of entry t's row
+                        const float *wb = wl + t;                               // wave-uniform
+                        int left = jend - t;
+                        for (; left >= 4; left -= 4, xb += 4 * DF, wb += 4) {
+                            float xv[4][NC], wt[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                wt[u] = wb[u];
+#pragma unroll
+                                for (int q = 0; q < NC; ++q) xv[u][q] = xb[u * DF + WAVE * q];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int q = 0; q < NC; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(wt[u], xv[u][q]));
+                        }
+                        for (; left > 0; --left, xb += DF, ++wb) {
+                            const float wt = wb[0];
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(wt, xb[WAVE * q]));
+                        }
+                        t = jend;
+                    }
+                    wave_sync();  // the stage is rewritten by the next chunk
+                    stamp(3);
+                    continue;
+                }
 #ifdef LFM_FEAT_REDUCE_BATCH4  // A/B build (profiles/r04_visit_b.txt: C5 -6 %, C3 +4 %: not the bound -- kept for study)
                 // Reduction of the staged rows, job by job.  Within a job the float32 accumulation is one
                 // sequential chain in CSR order (PYX:306-313); what is NOT sequential is everything around it, so
@@ -285,8 +342,17 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 wave_sync();  // the stage is rewritten by the next chunk
                 stamp(3);
             }
+            if (fastd) {
+                // bias column of the round: lane j walks job j's entries of this round in CSR order (PYX:314)
+                if (lane < J) {
+                    const int b0 = max(off - r * WAVE, 0), b1 = min(jend_round, e.n);
+                    for (int k = b0; k < b1; ++k) accb_job = __fadd_rn(accb_job, __fmul_rn(wl[k], bl[k]));
+                }
+                wave_sync();  // wl / bl are rewritten by the next round
+            }
         }
         if (cur >= 0) flush();
+        if (fastd && lane < J) reps[(size_t)rrow * TS + d] = accb_job;  // (a job without entries: the zero it already holds)
         wave_sync();
         stamp(3);
     };

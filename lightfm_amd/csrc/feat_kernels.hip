@@ -58,7 +58,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     }
     if (g.rr > WAVE) return false;
     g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : max_sampled, cb));
-    g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap) * 4;
+    g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap + 2 * WAVE) * 4;
     *p = g;
     return true;
 }

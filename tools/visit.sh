@@ -357,6 +357,37 @@ PY
   echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
   grep -a "per side, fixed" $OUT/tests.log | cut -c1-220
   ;;
+r4f)
+  # round 4: the fast (compile-time-offset, LDS-broadcast) reduce of the row-stream kernels against the previous build
+  # (lightfm_amd/_lib_split = per-entry reduce), C5 shard --scale 0.25 and C3; exactness tests first
+  timeout -k 5 900 $PYT tests/test_hip_feat.py tests/test_hip_parity.py tests/test_hip_round2.py tests/test_golden.py "tests/test_baseline_shapes.py::test_c3_shape_default_launch_plan_samples_exact" "tests/test_precision_parity.py::test_warp_kos_shared_tag_rows" "tests/test_precision_parity.py::test_bpr_tag_features_c3_regime" -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  PREV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_split/liblfm_hip.so"
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  C3="--config c3 --steps 3 --warmup 1 --epochs-per-step 2"
+  for i in 1 2; do
+    ENVV= run c5_fast_$i $C5
+    ENVV=$PREV run c5_prev_$i $C5
+  done
+  ENVV= run c5_fast_fb3 $C5 --first-batch 3
+  ENVV= run c5_fast_fb4 $C5 --first-batch 4
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=12 LIGHTFM_AMD_FEAT_LDS_KB=13" run c5_fast_w12 $C5
+  for i in 1 2; do
+    ENVV= run c3_fast_$i $C3
+    ENVV=$PREV run c3_prev_$i $C3
+  done
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
