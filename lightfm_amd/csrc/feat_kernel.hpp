@@ -583,6 +583,9 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             } else {
                 // fit_warp (PYX:826-904) and fit_warp_kos (PYX:958-1061) share the negative sampling
                 int pos_item = item, prow = 1;
+                float Pkos[NC];  // k-OS: the chosen positive's representation (its tile row is reused by the candidates)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) Pkos[q] = 0.0f;
                 double pp = 0.0;
                 bool have_pos = false;  // the positive's score is known (k-OS: before the negatives)
                 int lo = 0, hi = 0;
@@ -602,26 +605,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if (lane >= 1 && lane <= no_pos)  // sample_range, PYX:84-90
                         it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
                     state = (uint32_t)read_lane((int)s, no_pos);
-#ifdef LFM_KOS_MERGED_GATHER  // A/B build (profiles/r04_visit_e.txt: 3 % SLOWER on C5 -- the kernel is issue-bound, and one 21-job list costs more instructions than two lists save round trips)
-                    // The first batch of candidate negatives is known already (its draws follow the positives' in the
-                    // position's stream): its representations are built in the SAME pass as the user's and the sampled
-                    // positives' -- one extent fetch, one entry list, one sequence of row gathers for all 1 + n + batch
-                    // jobs instead of two (two round trips fewer per interaction; the sampling loop below then finds
-                    // its first batch in the tile)
-                    {
-                        const int nb0 = min(max_sampled, min(a.first_batch, CB));
-                        uint32_t s2 = state;  // lane k: the stream after min(k + 1, nb0) steps
-                        for (int j = 0; j < nb0; ++j)
-                            if (j <= lane) s2 = lcg(s2);
-                        const int myneg0 = (int)(draw(s2) % (uint32_t)a.itf.rows);  // PYX:1014-1016
-                        const int ck = max(lane - no_pos - 1, 0);
-                        const int cand0 = __shfl(myneg0, ck, WAVE);
-                        build_reps(lane == 0 ? user : (lane <= no_pos ? it : cand0), lane == 0 ? 1 : 0,
-                                   lane <= no_pos ? lane : cand_base + ck, 1 + no_pos + nb0, nullptr);
-                    }
-#else
                     build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos, nullptr);
-#endif
                     if (lane >= 1 && lane <= no_pos) {
                         pair_idx[lane - 1] = it;
                         pair_val[lane - 1] = tile_dot(reps, reps + (size_t)lane * TS, d);
@@ -650,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     pp = (double)unif(pair_val[kk]);
                     prow = uni(pair_slot[kk]);
                     have_pos = true;
+                    rep_regs(prow, Pkos);  // the sampled positives' rows are dead from here on: candidates take them (feat_plan)
                     wave_sync();
                 } else {
                     c0++;
@@ -669,9 +654,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                         lo = uni(lo_v);
                         hi = uni(hi_v);
                     } else {
-#ifdef LFM_KOS_MERGED_GATHER
-                        if (!(LOSS == LFM_LOSS_WARP_KOS_ID && sampled == 0))  // k-OS: the first batch is in the tile already
-#endif
                         build_reps(myneg, 0, cand_base + lane, nb, nullptr);
                     }
                     float sc = 0.0f;
@@ -706,7 +688,12 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                     if (loss > MAX_LOSS) loss = MAX_LOSS;
                     float Uv[NC], Pv[NC], Nv[NC], diff[NC];
                     rep_regs(0, Uv);
-                    rep_regs(prow, Pv);
+                    if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) {
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) Pv[q] = Pkos[q];
+                    } else {
+                        rep_regs(prow, Pv);
+                    }
                     rep_regs(chosen_row, Nv);
 #pragma unroll
                     for (int q = 0; q < NC; ++q) diff[q] = __fsub_rn(Nv[q], Pv[q]);

@@ -16,13 +16,17 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     g.ts = d + 4;
     g.pair_cap = 0;
     int cb = std::max(1, std::min(max_sampled, 16));
+    int kos_rows = 0;  // k-OS: tile rows the positives phase needs (the candidates reuse them)
     switch (loss) {
     case LFM_LOSS_LOGISTIC_ID: g.cand_base = 2; cb = 0; break;
     case LFM_LOSS_BPR_ID: g.cand_base = 3; cb = 0; break;
     case LFM_LOSS_WARP_ID: g.cand_base = 2; break;
     case LFM_LOSS_WARP_KOS_ID:
         if (n_positives < 1 || n_positives > 32) return false;
-        g.cand_base = 1 + n_positives;
+        // row 0 = the user, rows 1 .. n = the sampled positives; once the k-th is chosen (and kept in registers) the
+        // candidates take the same rows: 1 + max(n, batch) tile rows instead of 1 + n + batch
+        g.cand_base = 1;
+        kos_rows = 1 + n_positives;
         g.pair_cap = ((n_positives + 3) / 4) * 4;
         break;
     default: return false;
@@ -37,19 +41,28 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     // default budget per wavefront (8 wavefronts run per CU, session.hip): the representation tile
     // of the loss plus a staging area of >= 16 rows (C3 sweep: 20 staged rows at 8 wavefronts per CU
     // beat 38 rows at 7), at most 19 KiB
-    const size_t tile_bytes = (size_t)(g.cand_base + cb) * g.ts * 4 + 3 * (size_t)g.pair_cap * 4;
+    const size_t tile_bytes = (size_t)std::max(g.cand_base + cb, kos_rows) * g.ts * 4 + 3 * (size_t)g.pair_cap * 4;
     const size_t floor_b = d > 64 ? 12 * 1024 : 6 * 1024;
-    const size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024
-                                        : std::min<size_t>(19 * 1024, std::max(floor_b, tile_bytes + (size_t)16 * d * 4 + 256));
+    size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024
+                                  : std::min<size_t>(19 * 1024, std::max(floor_b, tile_bytes + (size_t)16 * d * 4 + 256));
+    // WARP / k-OS (not bound by the atomic unit): 12 wavefronts per CU when a twelfth of the LDS still stages >= 8 rows
+    int waves_per_cu = 8;
+    if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID)) {
+        const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255;
+        if (b12 >= tile_bytes + 2 * WAVE * 4 + (size_t)8 * d * 4) {
+            budget = b12;
+            waves_per_cu = 12;
+        }
+    }
     g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : 1;
     const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list
     for (;; --cb) {
-        g.rr = g.cand_base + cb;
-        const size_t fixed = (size_t)g.rr * g.ts * 4 + 3 * (size_t)g.pair_cap * 4;
+        g.rr = std::max(g.cand_base + cb, kos_rows);
+        const size_t fixed = (size_t)g.rr * g.ts * 4 + 3 * (size_t)g.pair_cap * 4 + 2 * WAVE * 4;
         if (fixed < budget) {
             int sr = (int)((budget - fixed) / ((size_t)d * 4));
             sr = std::min(sr, want) & ~1;
-            if (sr >= 8 || (sr >= 4 && cb <= 1)) {
+            if (sr >= 8 || (sr >= 6 && budget_kb > 0) || (sr >= 4 && cb <= 1)) {
                 g.sr = sr;
                 break;
             }
@@ -59,6 +72,10 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     if (g.rr > WAVE) return false;
     g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : max_sampled, cb));
     g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap + 2 * WAVE) * 4;
+    // residency (wavefronts per CU the session launches): the atomic-heavy losses publish fastest from 8 (C3: 43 M/s at
+    // 2 048 interactions in flight against 35 M/s at 3 072); WARP / k-OS take what the LDS allows, up to 12 (C5 shard:
+    // 43.3 -> 49.8 M/s from 8 to 12 once the reduce was cheap, profiles/r04_visit_f.txt)
+    g.waves_per_cu = waves_per_cu;
     *p = g;
     return true;
 }

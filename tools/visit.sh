@@ -388,6 +388,33 @@ PY
     ENVV=$PREV run c3_prev_$i $C3
   done
   ;;
+r4g)
+  # round 4: row-stream kernels after the fast reduce -- k-OS candidates reuse the positives' tile rows, 12 wavefronts per
+  # CU for WARP / k-OS (default), residency sweep around it; exactness + precision gates first
+  timeout -k 5 1200 $PYT tests/test_hip_feat.py tests/test_hip_parity.py tests/test_hip_round2.py tests/test_golden.py tests/test_lightfm_api.py "tests/test_baseline_shapes.py::test_c3_shape_default_launch_plan_samples_exact" "tests/test_precision_parity.py::test_warp_kos_shared_tag_rows" "tests/test_precision_parity.py::test_warp_shared_tag_rows" -m gpu -q -x -s > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  grep -a "per side, fixed" $OUT/tests.log | cut -c1-220
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  ENVV= run c5_default_w12 $C5
+  ENVV= run c5_default_w12_fb4 $C5 --first-batch 4
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=8 LIGHTFM_AMD_FEAT_LDS_KB=19" run c5_w8_lds19 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=10 LIGHTFM_AMD_FEAT_LDS_KB=15" run c5_w10_lds15 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=14 LIGHTFM_AMD_FEAT_LDS_KB=11" run c5_w14_lds11 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=16 LIGHTFM_AMD_FEAT_LDS_KB=10" run c5_w16_lds10 $C5
+  ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=16 LIGHTFM_AMD_FEAT_LDS_KB=10" run c5_w16_lds10_fb4 $C5 --first-batch 4
+  ENVV= run c5_default_w12_2 $C5
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
