@@ -161,6 +161,29 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // rows of entries [c0e, c0e + nc) of the current round: memory -> dst[0 .. nc) by LDS-DMA
     auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, bool gtab) {
         const int rsub = lane / LPR, piece = lane - rsub * LPR;
+        if (RPI == 2) {
+            // d = 128: two rows per instruction.  Every lane forms the address of ITS entry's row once; an instruction's
+            // two row addresses then come from lane reads (scalar) and a select by the lane's half -- no ds_bpermute
+            // round trips, no per-instruction table select and 64-bit multiply (27 -> ~12 instructions per two rows)
+            const float *tab = gtab ? (eside ? a.m.G[1] : a.m.G[0]) : (eside ? a.m.W[1] : a.m.W[0]);
+            const unsigned long long mine = (unsigned long long)(uintptr_t)(tab + (size_t)feat * d);
+            const int alo = (int)(unsigned)mine, ahi = (int)(unsigned)(mine >> 32);
+            auto two_rows = [&](int i0, bool guard) {
+                const int e0 = (c0e + i0) & (WAVE - 1), e1 = (c0e + i0 + 1) & (WAVE - 1);
+                const unsigned lo0 = (unsigned)read_lane(alo, e0), hi0 = (unsigned)read_lane(ahi, e0);
+                const unsigned lo1 = (unsigned)read_lane(alo, e1), hi1 = (unsigned)read_lane(ahi, e1);
+                const unsigned long long base = rsub ? (((unsigned long long)hi1 << 32) | lo1) : (((unsigned long long)hi0 << 32) | lo0);
+                const float *src = reinterpret_cast<const float *>((uintptr_t)base) + piece * 4;
+                if (!guard || i0 + rsub < nc) __builtin_amdgcn_global_load_lds(src, (lds_f32_t *)(dst + (size_t)i0 * d), 16, 0, 0);
+            };
+            int i0 = 0;
+            for (; i0 + 4 <= nc; i0 += 4) {  // four rows per step, no per-lane predicate
+                two_rows(i0, false);
+                two_rows(i0 + 2, false);
+            }
+            for (; i0 < nc; i0 += 2) two_rows(i0, true);
+            return;
+        }
         for (int i0 = 0; i0 < nc; i0 += RPI) {
             const int e = c0e + i0 + rsub;
             const bool valid = rsub < RPI && (i0 + rsub) < nc;
@@ -175,8 +198,13 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // When the whole flat list fits one round (<= 64 entries) it is handed back in `keep` so that
     // an update of the same jobs need not fetch it again.
     auto build_reps = [&](int row, int side, int rrow, int J, Entries *keep) {
-        for (int j = 0; j < J; ++j) {  // a job without entries keeps the zero representation
-            float *rp = reps + (size_t)read_lane(rrow, j) * TS;
+        int start, len, off, T;
+        stamp(0);
+        job_extent(row, side, J, start, len, off, T);
+        // a job without entries has the zero representation (every other job's row is written when its last entry has
+        // been reduced): only those rows are cleared -- rare (an empty feature row), so the common case clears nothing
+        for (unsigned long long em = __ballot(lane < J && len == 0); em != 0ull; em &= em - 1ull) {
+            float *rp = reps + (size_t)read_lane(rrow, __ffsll((long long)em) - 1) * TS;
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const int c = lane + WAVE * q;
@@ -184,9 +212,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             }
             if (lane == 0) rp[d] = 0.0f;
         }
-        int start, len, off, T;
-        stamp(0);
-        job_extent(row, side, J, start, len, off, T);
         if (keep) keep->n = -1;
         int cur = -1;
         float acc[NC], accb = 0.0f;

@@ -70,7 +70,10 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
         if (cb <= 1) return false;
     }
     if (g.rr > WAVE) return false;
-    g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : max_sampled, cb));
+    // candidates whose representations are built speculatively in the first batch: 4 (C5 shard, 7.7 draws per interaction
+    // on average: 57.2 M/s with all 10 in one batch, 59.4 with 4 + the rest -- an issue-bound kernel pays for every
+    // representation it builds in vain; profiles/r04_visit_g.txt)
+    g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : std::min(max_sampled, 4), cb));
     g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap + 2 * WAVE) * 4;
     // residency (wavefronts per CU the session launches): the atomic-heavy losses publish fastest from 8 (C3: 43 M/s at
     // 2 048 interactions in flight against 35 M/s at 3 072); WARP / k-OS take what the LDS allows, up to 12 (C5 shard:

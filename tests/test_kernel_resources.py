@@ -75,22 +75,20 @@ def test_gather_ahead_kernel_budget_and_waits(tmp_path):
     variant is about -- no wait for outstanding memory operations between the top of a pass and the gather of the
     next one (a compiler-placed vmcnt(0) there would wait for the previous pass's atomics)."""
     k = _usage("warp_tile_ahead.hip", tmp_path)
-    u = _one(k, "fit_warp_tile_ahead_kernelILi10EEE")
-    assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 3, u
-    hipcc = _hipcc()
-    out = subprocess.run([hipcc] + [f for f in FLAGS if not f.startswith("-Rpass") and f != "-c"] +
-                         ["-S", os.path.join(CSRC, "warp_tile_ahead.hip"), "-o", str(tmp_path / "a.s")],
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = open(str(tmp_path / "a.s")).read().splitlines()
-    dma = [i for i, l in enumerate(lines) if "global_load_lds_dword " in l]   # the bias DMAs end a gather
-    assert len(dma) == 4, dma                                                 # prologue + in-loop gather, two each
-    waits = [i for i, l in enumerate(lines) if "s_waitcnt" in l and "vmcnt" in l]
-    prologue_wait = min(i for i in waits if i > dma[1])
-    between = [i for i in waits if prologue_wait < i < dma[2]]
-    assert not between, [lines[i] for i in between]
-    atomics = [i for i, l in enumerate(lines) if "global_atomic_add_f32" in l]
-    assert atomics and min(atomics) > dma[3]                                  # publication follows the next pass's gather
+    for frag in ("fit_warp_tile_ahead_kernelILi10ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1EEE"):  # plain, owner-sharded items
+        u = _one(k, frag)
+        assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 3, (frag, u)
+    bodies = _asm("warp_tile_ahead.hip", tmp_path)
+    for frag in ("fit_warp_tile_ahead_kernelILi10ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1EEE"):
+        lines = [b for n, b in bodies.items() if frag in n][0].splitlines()
+        dma = [i for i, l in enumerate(lines) if "global_load_lds_dword " in l]   # the bias DMAs end a gather
+        assert len(dma) == 4, (frag, dma)                                         # prologue + in-loop gather, two each
+        waits = [i for i, l in enumerate(lines) if "s_waitcnt" in l and "vmcnt" in l]
+        prologue_wait = min(i for i in waits if i > dma[1])
+        between = [i for i in waits if prologue_wait < i < dma[2]]
+        assert not between, (frag, [lines[i] for i in between])
+        atomics = [i for i, l in enumerate(lines) if "global_atomic_add_f32" in l]
+        assert atomics and min(atomics) > dma[3], frag                            # publication follows the next pass's gather
 
 
 @pytest.mark.timeout(1200)

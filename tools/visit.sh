@@ -415,6 +415,36 @@ PY
   ENVV="LIGHTFM_AMD_FEAT_WAVES_PER_CU=16 LIGHTFM_AMD_FEAT_LDS_KB=10" run c5_w16_lds10_fb4 $C5 --first-batch 4
   ENVV= run c5_default_w12_2 $C5
   ;;
+r4h)
+  # round 4: full GPU suite on the current tree, then row-stream kernels A/B against the previous commit's library
+  # (lightfm_amd/_lib_prev): DMA address generation without ds_bpermute, four rows per issue step, empty-job clears only,
+  # first batch of 4 candidates
+  timeout -k 5 1500 $PYT tests -m gpu -x -q > $OUT/suite.log 2>&1
+  echo "suite: exit $?  $(grep -aE ' passed| failed' $OUT/suite.log | tail -1)"; summ $OUT/suite.log 12
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  PREV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_prev/liblfm_hip.so"
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  C3="--config c3 --steps 3 --warmup 1 --epochs-per-step 2"
+  for i in 1 2; do
+    ENVV= run c5_new_$i $C5
+    ENVV=$PREV run c5_prev_fb4_$i $C5 --first-batch 4
+  done
+  for i in 1 2; do
+    ENVV= run c3_new_$i $C3
+    ENVV=$PREV run c3_prev_$i $C3
+  done
+  ENVV= run c5_full_size --config c5shard --steps 2 --warmup 1 --epochs-per-step 1
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
