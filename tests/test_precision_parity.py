@@ -12,7 +12,7 @@ so that the reference finishes in tens of seconds.
 Hogwild training is not deterministic on either side, so the comparison is between MEANS over a
 FIXED number of seeds (N_SEEDS per side, seeds 1..N_SEEDS on both sides, no early stop: the verdict
 cannot depend on when the loop ends); the test prints mean +- standard error of both sides and
-asserts |difference of the means| <= GATE.
+asserts |difference of the means| <= GATE (the smallest problem takes more seeds, see there).
 """
 import os
 
@@ -42,7 +42,7 @@ def _p10(model, train_csr, test_csr, feats):
                                 item_features=feats).mean())
 
 
-def _gap(loss, d, train, test, feats, epochs, **model_kw):
+def _gap(loss, d, train, test, feats, epochs, n_seeds=N_SEEDS, **model_kw):
     from concurrent.futures import ThreadPoolExecutor
     from lightfm_amd import LightFM, options
     from oracle import oracle
@@ -60,7 +60,7 @@ def _gap(loss, d, train, test, feats, epochs, **model_kw):
         r.fit(train, item_features=feats, epochs=epochs, num_threads=_ref_threads())
         return r
 
-    seeds = list(range(1, N_SEEDS + 1))
+    seeds = list(range(1, n_seeds + 1))
     with ThreadPoolExecutor(max_workers=REF_PARALLEL) as pool:
         pending = [pool.submit(fit_ref, seed) for seed in seeds]
         for seed in seeds:
@@ -107,11 +107,14 @@ def test_warp_shared_tag_rows():
 
 @pytest.mark.timeout(900)
 def test_warp_kos_shared_tag_rows():
-    """Hybrid k-OS WARP (k=5, n=10) with shared tag rows."""
+    """Hybrid k-OS WARP (k=5, n=10) with shared tag rows.  The smallest problem of the file: one fit's precision@10
+    scatters by ~0.0015 on BOTH sides (the reference's 16-thread Hogwild is not reproducible either: its 6-seed mean
+    moved between 0.1327 and 0.1348 over three runs of this test on one box while this backend's stayed at
+    0.1342-0.1349), so the means are taken over 18 seeds per side -- standard error of the difference ~0.0005."""
     from lightfm_amd import synthetic
     train, test = _data(4000, 3000, 300_000)
     feats = synthetic.tag_item_features(3000, n_tags=100, per_item=4)
-    _gap("warp-kos", 64, train, test, feats, epochs=5)
+    _gap("warp-kos", 64, train, test, feats, epochs=5, n_seeds=18)
 
 
 @pytest.mark.timeout(900)
