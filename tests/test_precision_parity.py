@@ -92,7 +92,7 @@ def test_bpr_tag_features_c3_regime():
     from lightfm_amd import synthetic
     train, test = _data(8656, 13372, 1_000_000)
     feats = synthetic.tag_item_features(13372, n_tags=1128, per_item=8)
-    _gap("bpr", 128, train, test, feats, epochs=3)
+    _gap("bpr", 128, train, test, feats, epochs=3, n_seeds=10)
 
 
 @pytest.mark.timeout(900)
@@ -102,7 +102,7 @@ def test_warp_shared_tag_rows():
     from lightfm_amd import synthetic
     train, test = _data(8656, 6686, 1_000_000)
     feats = synthetic.tag_item_features(6686, n_tags=200, per_item=4)
-    _gap("warp", 64, train, test, feats, epochs=5)
+    _gap("warp", 64, train, test, feats, epochs=5, n_seeds=10)
 
 
 @pytest.mark.timeout(900)
