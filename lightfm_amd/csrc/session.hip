@@ -1678,7 +1678,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // the steady-state variant with the next pass's gather issued inside the current pass (warp_tile_ahead.hpp):
             // adagrad, no regularisation, max_sampled = 10 in one batch; debug bit 10 (1024) keeps the plain kernel
             if (t.dma4 && !s->adadelta && item_alpha == 0.0 && user_alpha == 0.0 && opts->warp_kernel != 2 &&
-                !(opts->debug & (1024 | 512))) {
+                a.update_mode == 0 && !(opts->debug & (1024 | 512))) {  // (atomic publication only: no per-publication mode switch)
                 const size_t ahead = warp_tile_ahead_smem(s->d, s->max_sampled, t.first_batch);
                 if (ahead) {
                     t.ahead = true;

@@ -52,6 +52,16 @@ struct ItemAddr {
         }
         local = (uint32_t)r;
     }
+    // row address for the gathers: rows are >= 0 and a table below 4 GB is addressed with ONE 32-bit multiply
+    __device__ __forceinline__ const float *Wg(int row, bool small) const
+    {
+        if constexpr (!SHARDED) {
+            if (small) return W0 + (uint32_t)row * (uint32_t)d;
+            return W0 + (size_t)(uint32_t)row * (size_t)d;
+        } else {
+            return W(row);
+        }
+    }
     __device__ __forceinline__ float *W(int row) const
     {
         if constexpr (!SHARDED) return W0 + (size_t)row * d;
@@ -112,10 +122,10 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
     const float *Wu = a.m.W[1];
     const float *bu_tab = a.b_read[1];
     const ItemAddr<SHARDED> item{a.shards, a.m.W[0], a.m.G[0], a.m.b[0], a.m.bG[0], a.b_read[0], d};
+    const bool small_items = (uint64_t)a.itf.rows * (uint64_t)d < (1ull << 30);  // item table below 4 GB: 32-bit row offsets
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
     const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
-    const int um = a.update_mode;
     const uint32_t *bloom = a.bloom;
 
     // lane p needs the position's stream after min(p, NBF) draws: (A^k, C (A^(k-1) + ... + 1)) mod 2^32
@@ -143,11 +153,11 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
             float *ub = tile + UB + __builtin_amdgcn_readfirstlane(gg) * (US - LPR * VEC);
             if (g == gg && pc) dma_lane_x4(Wu + (size_t)user * d + VEC * p, ub);
         }
-        if (pc) dma_lane_x4(item.W(pos) + VEC * p, tile);  // row 0 of every group
+        if (pc) dma_lane_x4(item.Wg(pos, small_items) + VEC * p, tile);  // row 0 of every group
 #pragma unroll
         for (int k = 1; k <= NBF; ++k) {
             const int neg = row_bcast(myitem, k);
-            if (pc) dma_lane_x4(item.W(neg) + VEC * p, tile + (size_t)k * KS);
+            if (pc) dma_lane_x4(item.Wg(neg, small_items) + VEC * p, tile + (size_t)k * KS);
         }
         dma_lane_dword(item.bscore(myitem), tile + BB);
         dma_lane_dword(bu_tab + user, tile + BB + WAVE);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 
         // ---- in_positives (Bloom pre-filter probed by the violators, device.hpp: Bloom) and the accumulator rows of
         // the first violator's update: one round trip, behind the gather's
-        float gP[NG], gN[NG], gU[NG], obW[NG], obG[NG];
+        float gP[NG], gN[NG], gU[NG];
         auto load_rows = [&](int gg, int user, int pos, int neg, bool only_neg) {
             const size_t bu_ = (size_t)user * d;
             unsigned cc = lane < d ? (unsigned)lane : 0u;
@@ -246,13 +256,20 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                 gP[gg] = item.G(pos)[cc];
                 gU[gg] = (Gu + bu_)[cc];
             }
-            // bias cells: lane 0 = positive item, 1 = negative item, 2.. = user (PYX:571-599)
-            const int irow = lane == 0 ? pos : neg;
-            const float *bWp = lane >= 2 ? a.m.b[1] + user : item.b(irow);
-            const float *bGp = lane >= 2 ? a.m.bG[1] + user : item.bG(irow);
-            if (!only_neg || lane == 1) {
-                obW[gg] = *bWp;
-                obG[gg] = *bGp;
+        };
+        // The bias cells (PYX:571-599) of ALL interactions of the pass are one lane each: lane 16 g + 0 = positive item of
+        // group g, + 1 = its negative, + 2 = its user -- one cell evaluation and two publications per pass instead of
+        // one of each per updating interaction.
+        const bool has_viol = act && vm != 0ull;
+        float obW = 0.0f, obG = 1.0f;
+        auto bias_ptrs = [&](int neg, float *&bWp, float *&bGp) {
+            if (p == 2) {
+                bWp = a.m.b[1] + c_user;
+                bGp = a.m.bG[1] + c_user;
+            } else {
+                const int irow = p == 0 ? c_pos : neg;
+                bWp = item.b(irow);
+                bGp = item.bG(irow);
             }
         };
         if (__ballot(act) != 0ull) {
@@ -267,6 +284,12 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
             }
             const uint32_t bmask = Bloom::mask(bh);
             const int maybe_pos = ((bword & bmask) == bmask) ? 1 : 0;
+            if (has_viol && p < 3) {  // bias cells of the speculated update
+                float *bWp, *bGp;
+                bias_ptrs(spec_cand, bWp, bGp);
+                obW = *bWp;
+                obG = *bGp;
+            }
             int used = NBF;
             while (true) {
                 const bool part = act && chosen < 0 && vm != 0ull;
@@ -307,8 +330,21 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
         }
 
         // ---- updates: float64 cell arithmetic (PYX:416-449) and atomic publication, one interaction after the other
+        const bool bupd = act && chosen >= 0 && p < 3;
         if (upd != 0ull) {
-            // the first violator was a positive and a later one is the choice: its rows
+            {   // the first violator was a positive and a later one is the choice: its bias cell (lane 16 g + 1)
+                const bool bre = bupd && p == 1 && chosen != spec_cand;
+                if (__ballot(bre) != 0ull) {
+                    if (bre) {
+                        float *bWp, *bGp;
+                        bias_ptrs(chosen, bWp, bGp);
+                        obW = *bWp;
+                        obG = *bGp;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+            }
+            // ... and its rows
 #pragma unroll
             for (int gg = 0; gg < NG; ++gg) {
                 if ((upd >> (gg * LPR)) & 1ull) {
@@ -339,26 +375,32 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                     cell_math(Pr, gP[gg], 0.0f, 1.0, -loss * u, h, 0.0, nWP, nGP, nM, lr);
                     cell_math(Nr, gN[gg], 0.0f, 1.0, loss * u, h, 0.0, nWN, nGN, nM, lr);
                     cell_math(Ur, gU[gg], 0.0f, 1.0, loss * df, h, 0.0, nWU, nGU, nM, lr);
-                    float bnW, bnG, bnM;
-                    cell_math(obW[gg], obG[gg], 0.0f, 1.0, lane == 0 ? -loss : loss, h, 0.0, bnW, bnG, bnM, lr);
-                    asm volatile("" : "+v"(nWP), "+v"(nGP), "+v"(nWN), "+v"(nGN), "+v"(nWU), "+v"(nGU), "+v"(bnW), "+v"(bnG));
+                    asm volatile("" : "+v"(nWP), "+v"(nGP), "+v"(nWN), "+v"(nGN), "+v"(nWU), "+v"(nGU));
                     if (lane < d) {
+                        // publication: new - old by global_atomic_add_f32, unconditionally (this variant runs update_mode
+                        // 0 only; a zero delta is added as such: the per-publication mode switch and zero test cost a
+                        // dozen scalar instructions and three branches each, eight times per interaction)
                         unsigned cq = (unsigned)lane;
                         asm volatile("" : "+v"(cq));
-                        publish(wP + cq, nWP, Pr, um);
-                        publish(aP + cq, nGP, gP[gg], um);
-                        publish(wN + cq, nWN, Nr, um);
-                        publish(aN + cq, nGN, gN[gg], um);
-                        publish(WuW + bu_ + cq, nWU, Ur, um);
-                        publish(Gu + bu_ + cq, nGU, gU[gg], um);
+                        atomicAdd(wP + cq, __fsub_rn(nWP, Pr));
+                        atomicAdd(aP + cq, __fsub_rn(nGP, gP[gg]));
+                        atomicAdd(wN + cq, __fsub_rn(nWN, Nr));
+                        atomicAdd(aN + cq, __fsub_rn(nGN, gN[gg]));
+                        atomicAdd(WuW + bu_ + cq, __fsub_rn(nWU, Ur));
+                        atomicAdd(Gu + bu_ + cq, __fsub_rn(nGU, gU[gg]));
                     }
-                    if (lane < 3) {
-                        const int irow = lane == 0 ? pos : neg;
-                        float *bWp = lane == 2 ? a.m.b[1] + user : item.b(irow);
-                        float *bGp = lane == 2 ? a.m.bG[1] + user : item.bG(irow);
-                        publish(bWp, bnW, obW[gg], um);
-                        publish(bGp, bnG, obG[gg], um);
-                    }
+                }
+            }
+            // the pass's bias cells, all interactions at once
+            {
+                float bnW, bnG, bnM;
+                double blr;
+                cell_math(obW, obG, 0.0f, 1.0, p == 0 ? -lossd : lossd, h, 0.0, bnW, bnG, bnM, blr);
+                if (bupd) {
+                    float *bWp, *bGp;
+                    bias_ptrs(chosen, bWp, bGp);
+                    atomicAdd(bWp, __fsub_rn(bnW, obW));
+                    atomicAdd(bGp, __fsub_rn(bnG, obG));
                 }
             }
         }

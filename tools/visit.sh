@@ -445,6 +445,65 @@ PY
   done
   ENVV= run c5_full_size --config c5shard --steps 2 --warmup 1 --epochs-per-step 1
   ;;
+r4i)
+  # round 4: instruction mix / issue utilisation of the steady-state tile kernel (C2) and the row-stream kernel (C3, C5): two PMC passes each
+  cd /tmp && export TMPDIR=/tmp
+  S="--no-cpu-baseline --no-quality --no-fit --steps 2 --warmup 1 --epochs-per-step 4"
+  for cfg in "c2" "c3" "c5shard --scale 0.1"; do
+    tag=$(echo $cfg | cut -d' ' -f1)
+    EPS="--epochs-per-step 4"; [ "$tag" != "c2" ] && EPS="--epochs-per-step 1"
+    S="--no-cpu-baseline --no-quality --no-fit --steps 2 --warmup 1 $EPS"
+    timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/${tag}_a -o pmc -- python $R/bench.py $S --config $cfg > $OUT/${tag}_a.json 2> $OUT/${tag}_a.err
+    timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU -d $OUT/${tag}_b -o pmc -- python $R/bench.py $S --config $cfg > $OUT/${tag}_b.json 2> $OUT/${tag}_b.err
+  done
+  cd $R && python - <<PY
+import sqlite3, json, glob
+for tag in ("c2", "c3", "c5shard"):
+    for sub in ("a", "b"):
+        try:
+            db = glob.glob("$OUT/%s_%s/**/*results.db" % (tag, sub), recursive=True)[0]
+            con = sqlite3.connect(db)
+            rows = con.execute("select k.name, p.counter_name, sum(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+            b = json.load(open("$OUT/%s_%s.json" % (tag, sub)))
+            tot = {}
+            for name, c, v in rows:
+                if "fit_" in name: tot[c] = tot.get(c, 0) + v
+            eps = b["config"]["epochs_per_step"]; n_ep = 1 + 3 + max(0, 1 * eps - 4) + 2 * eps   # ramp + early + warm-up + timed
+            n_int = float(b["config"]["workload"].split(" x ")[-1].split(" interactions")[0].replace(",", "")) * n_ep
+            print("  %s_%s (%.1f M/s, %d epochs assumed):" % (tag, sub, b["value"] / 1e6, n_ep), {c: round(v / n_int, 1) for c, v in tot.items()})
+        except Exception as e:
+            print("  %s_%s: %r" % (tag, sub, e))
+PY
+  find $OUT -name "*.db" -size +5M -delete
+  ;;
+r4j)
+  # round 4: the leaner steady-state tile kernel (lane-parallel bias cells, unconditional atomics, 32-bit gather offsets)
+  # against the previous one (lightfm_amd/_lib_prev); exactness + gates first
+  timeout -k 5 1200 $PYT tests/test_hip_warp_tile.py tests/test_hip_parity.py tests/test_baseline_shapes.py tests/test_sharded_items.py tests/test_hip_round2.py tests/test_lightfm_api.py tests/test_reference_suite.py "tests/test_precision_parity.py::test_warp_identity_c2_regime" -m gpu -q -x -s > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  grep -a "per side, fixed" $OUT/tests.log | cut -c1-220
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s  early %.1f" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight"), (d.get("early_epochs") or {}).get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  PREV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_prev/liblfm_hip.so"
+  C2="--config c2 --steps 5 --warmup 2 --epochs-per-step 16"
+  C4="--config c4shard --steps 3 --warmup 1 --epochs-per-step 8"
+  for i in 1 2; do
+    ENVV= run c2_new_$i $C2
+    ENVV=$PREV run c2_prev_$i $C2
+  done
+  ENVV= run c4_new $C4
+  ENVV=$PREV run c4_prev $C4
+  ENVV= run c4_new_2 $C4
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
