@@ -224,18 +224,25 @@ def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note, thread
     return cpu, p_ref
 
 
-def committed_traffic(config_name, kernel_name):
-    """(HBM bytes per launch, source) of the dominant kernel from profiles/traffic.json."""
+def committed_traffic(config_name, kernel_name, interactions_per_launch=None):
+    """(HBM bytes per launch, source, the profiled run's own figures) of the dominant kernel from profiles/traffic.json.
+    Where the committed entry carries bytes per INTERACTION they are scaled to this run's launch length (the profiled run
+    and this one differ in launch count and, slightly, in the epochs they cover; the entry's own traffic / algorithmic
+    ratio is the consistent pair and is reported next to it)."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         e = table.get(config_name)
         if e and kernel_name in e.get("kernel", ""):
-            return float(e["hbm_bytes_per_launch"]), e.get("source")
+            if interactions_per_launch and e.get("hbm_bytes_per_interaction"):
+                extra = {k: e[k] for k in ("traffic_over_algorithmic_profiled", "updates_per_interaction_profiled",
+                                           "draws_per_interaction_profiled", "profiled_epochs", "profiled_scale") if k in e}
+                return float(e["hbm_bytes_per_interaction"]) * interactions_per_launch, e.get("source"), extra
+            return float(e["hbm_bytes_per_launch"]), e.get("source"), {}
         if e:
-            return None, "profiles/traffic.json holds %s for this config, this run's kernel is %s" % (e.get("kernel"), kernel_name)
+            return None, "profiles/traffic.json holds %s for this config, this run's kernel is %s" % (e.get("kernel"), kernel_name), {}
     except Exception as e:  # reporting only
-        return None, "profiles/traffic.json unreadable: %r" % (e,)
-    return None, "no committed counter summary for this config"
+        return None, "profiles/traffic.json unreadable: %r" % (e,), {}
+    return None, "no committed counter summary for this config", {}
 
 
 def parse_args():
@@ -442,7 +449,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     else:
         kernel_name = "fit_%s_kernel (generic)" % loss.replace("-", "_")
     achieved = alg / kernel_s / 1e9
-    traffic, traffic_source = committed_traffic(name, kernel_name)
+    traffic, traffic_source, traffic_extra = committed_traffic(name, kernel_name, counters[0] / max(1, launches))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
@@ -458,6 +465,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
                 "updates_per_interaction": counters[2] / max(1.0, counters[0])}
     if traffic is not None:
         roofline["traffic_over_algorithmic"] = traffic / (alg / launches)
+        roofline["traffic_profiled_run"] = traffic_extra
 
     # Second ceiling of the update-heavy configurations: every updated cell is published with one
     # global_atomic_add_f32 per table (W, G), and the chip executes a fixed ~320 G of them per second

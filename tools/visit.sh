@@ -504,6 +504,13 @@ PY
   ENVV=$PREV run c4_prev $C4
   ENVV= run c4_new_2 $C4
   ;;
+r4k)
+  # round 4: rocprofv3 kernel trace + FETCH / WRITE / TCC counter passes of the four configurations on the final kernels
+  for cfg in c2 c3 c4shard; do bash tools/profile2.sh r04_$cfg --config $cfg; done
+  bash tools/profile2.sh r04_c5shard --config c5shard --scale 0.1
+  cp $R/profiles/r04_c*_kernel_stats.txt $R/profiles/r04_c*_pmc_summary.json $OUT/ 2>/dev/null
+  ls -la $OUT | head -20
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
