@@ -222,16 +222,19 @@ def test_committed_traffic_feeds_the_roofline():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    names = {"c2": "fit_warp_tile_kernel<16, 4, false, false, true, false>",
-             "c4shard": "fit_warp_tile_kernel<16, 4, false, false, true, false>",
-             "c3": "fit_feat_kernel<2, 2, false, false>"}
+    names = {"c2": "fit_warp_tile_ahead_kernel<10, false>",
+             "c4shard": "fit_warp_tile_ahead_kernel<10, false>",
+             "c3": "fit_feat_kernel<2, 2, false, false>",
+             "c5shard": "fit_feat_kernel<3, 2, false, false>"}
     for cfg, kernel in names.items():
         assert os.path.exists(os.path.join(root, table[cfg]["source"]))
-        value, source = bench.committed_traffic(cfg, kernel)
+        value, source, extra = bench.committed_traffic(cfg, kernel)
         assert value is not None and value > 1e9 and source == table[cfg]["source"], (cfg, value, source)
-    value, why = bench.committed_traffic("c2", "fit_warp_kernel (generic)")
+        # scaled to a run's own launch length: bytes per interaction of the profiled run x interactions per launch
+        half, _, extra = bench.committed_traffic(cfg, kernel, table[cfg]["interactions_per_launch_profiled"] / 2)
+        assert abs(half / (value / 2) - 1.0) < 1e-9 and 0.5 < extra["traffic_over_algorithmic_profiled"] < 2.5
+    value, why, _ = bench.committed_traffic("c2", "fit_warp_kernel (generic)")
     assert value is None and "this run's kernel" in why
-    assert bench.committed_traffic("c5shard", "fit_feat_kernel<3, 2, false, false>")[0] is None
 
 
 def test_evaluation_reductions_match_the_sparse_matrix_formulation():
