@@ -511,6 +511,61 @@ r4k)
   cp $R/profiles/r04_c*_kernel_stats.txt $R/profiles/r04_c*_pmc_summary.json $OUT/ 2>/dev/null
   ls -la $OUT | head -20
   ;;
+r4m)
+  # round 4: what predict_ranks is bound by -- kernel trace + SQ counters of tools/ranks_timing.py (all ML-20M users)
+  cd /tmp && export TMPDIR=/tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/tools/ranks_timing.py > $OUT/ranks_trace.txt 2> $OUT/ranks_trace.err
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_a -o pmc -- python $R/tools/ranks_timing.py > $OUT/ranks_a.txt 2> $OUT/ranks_a.err
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU -d $OUT/pmc_b -o pmc -- python $R/tools/ranks_timing.py > $OUT/ranks_b.txt 2> $OUT/ranks_b.err
+  cd $R && cat $OUT/ranks_trace.txt | tail -3 && python - <<PY
+import sqlite3, glob
+try:
+    db = glob.glob("$OUT/trace/**/*results.db", recursive=True)[0]
+    con = sqlite3.connect(db)
+    for r in con.execute("select name, count(*), sum(duration)/1e6, avg(duration)/1e3 from kernels group by name order by sum(duration) desc limit 8"):
+        print("  %-70s calls %4d total %9.2f ms avg %10.1f us" % (r[0][:70], r[1], r[2], r[3]))
+except Exception as e:
+    print("trace:", e)
+for sub in ("pmc_a", "pmc_b"):
+    try:
+        db = glob.glob("$OUT/%s/**/*results.db" % sub, recursive=True)[0]
+        con = sqlite3.connect(db)
+        rows = con.execute("select k.name, p.counter_name, count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id where k.name like '%ranks_mfma2%' group by k.name, p.counter_name").fetchall()
+        print("  %s:" % sub, {c: round(v / n, 0) for _, c, n, v in rows}, "per launch")
+    except Exception as e:
+        print(sub, e)
+PY
+  find $OUT -name "*.db" -size +5M -delete
+  ;;
+r4n)
+  # round 4: row-stream kernels with DMA row addresses through an LDS table (one ds_read_b64 per instruction, eight per
+  # wait) against the previous commit's library; exactness + gates first
+  timeout -k 5 1200 $PYT tests/test_hip_feat.py tests/test_hip_parity.py tests/test_hip_round2.py tests/test_golden.py "tests/test_baseline_shapes.py::test_c3_shape_default_launch_plan_samples_exact" "tests/test_precision_parity.py::test_warp_shared_tag_rows" "tests/test_precision_parity.py::test_bpr_tag_features_c3_regime" -m gpu -q -x -s > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  grep -a "per side, fixed" $OUT/tests.log | cut -c1-220
+  line() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-34s %9.2f M/s  frac %.3f  atomic %.3f  launch %.3f ms  S %.2f U %.3f  in_flight %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["atomic_unit"]["frac"], r["avg_launch_ms"], r["draws_per_interaction"], r["updates_per_interaction"], r.get("interactions_in_flight")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit"
+  run() { tag=$1; shift; env $ENVV timeout 400 python bench.py $S "$@" > $OUT/$tag.json 2> $OUT/$tag.err; line $tag $OUT/$tag.json; }
+  PREV="LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_prev/liblfm_hip.so"
+  C5="--config c5shard --scale 0.25 --steps 2 --warmup 1 --epochs-per-step 1"
+  C3="--config c3 --steps 3 --warmup 1 --epochs-per-step 2"
+  for i in 1 2; do
+    ENVV= run c5_new_$i $C5
+    ENVV=$PREV run c5_prev_$i $C5
+  done
+  for i in 1 2; do
+    ENVV= run c3_new_$i $C3
+    ENVV=$PREV run c3_prev_$i $C3
+  done
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
