@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // rows of entries [c0e, c0e + nc) of the current round: memory -> dst[0 .. nc) by LDS-DMA
     auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, bool gtab) {
         const int rsub = lane / LPR, piece = lane - rsub * LPR;
-        if (RPI == 2) {
+        if (LPR == 32) {
             // d = 128: two rows per instruction.  Every lane forms the address of ITS entry's row once and drops it
             // into a small LDS table; an instruction's two lane halves then read their row's address back with ONE
             // ds_read_b64 at an immediate offset of one base register (entry c0e + i0 + 2 k + half): a block of eight
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             e.n = min(WAVE, T - r * WAVE);
             if (keep && T <= WAVE) *keep = e;
             float bx = 0.0f;
-            if (lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
             if constexpr (TIMED) asm volatile("" : "+v"(e.feat), "+v"(e.w));
             stamp(1);
             // end of every job's entries inside this round (lane j = job j), for the fast reduce
@@ -253,6 +252,9 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             for (int ce = 0; ce < e.n; ce += SR) {
                 const int nc = min(SR, e.n - ce);
                 dma_rows(e.feat, e.eside, ce, nc, stage, false);
+                // the round's bias cells are requested BEHIND the first chunk's rows (both need the entry list; a wait
+                // for the biases placed before the rows' requests would cost the round a round trip of its own)
+                if (ce == 0 && lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
