@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const int lane = lane_id(), wib = uni((int)(threadIdx.x >> 6));
     const int d = a.m.d, TS = a.tile_stride, RR = a.tile_rows, SR = a.stage_rows;
     const int LPR = d >> 2, RPI = WAVE / LPR;  // lanes per row, rows per DMA instruction
-    const size_t wave_floats = (size_t)SR * d + (size_t)RR * TS + 3 * (size_t)a.pair_cap + 2 * WAVE + 2 * (WAVE + 16);
+    const size_t wave_floats = (size_t)SR * d + (size_t)RR * TS + 3 * (size_t)a.pair_cap + 2 * WAVE;
     float *stage = smem + (size_t)wib * wave_floats;  // [SR][d] packed: what LDS-DMA deposits
     float *reps = stage + (size_t)SR * d;              // [RR][TS] representations, bias in column d
     int *pair_idx = reinterpret_cast<int *>(reps + (size_t)RR * TS);  // k-OS (PYX:109-111)
@@ -84,9 +84,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     int *pair_slot = reinterpret_cast<int *>(pair_val + a.pair_cap);
     // weights and biases of a round's entries, by entry (fast reduce below): LDS broadcasts instead of lane reads
     float *wl = reinterpret_cast<float *>(pair_slot + a.pair_cap), *bl = wl + WAVE;
-    // row addresses of a DMA call's entries, by entry (+ 16 padding entries holding a valid address), see dma_rows
-    unsigned long long *atab = reinterpret_cast<unsigned long long *>(bl + WAVE);
-    if (lane < 16) atab[WAVE + lane] = (unsigned long long)(uintptr_t)a.m.W[0];
     // d == 64 NC (d = 64 or 128: every BASELINE configuration): the reduce runs with compile-time LDS offsets
     constexpr int DF = 64 * NC;
     const bool fastd = d == DF;
@@ -164,32 +161,27 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // rows of entries [c0e, c0e + nc) of the current round: memory -> dst[0 .. nc) by LDS-DMA
     auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, bool gtab) {
         const int rsub = lane / LPR, piece = lane - rsub * LPR;
-        if (LPR == 32) {
-            // d = 128: two rows per instruction.  Every lane forms the address of ITS entry's row once and drops it
-            // into a small LDS table; an instruction's two lane halves then read their row's address back with ONE
-            // ds_read_b64 at an immediate offset of one base register (entry c0e + i0 + 2 k + half): a block of eight
-            // instructions (16 rows) costs eight back-to-back LDS reads and ONE wait, an instruction one 64-bit add and
-            // the M0 write (was: two dependent ds_bpermute round trips, a table select and a 64-bit multiply per
-            // instruction).  Reads past the chunk hit padding entries (valid addresses); no per-lane predicate: with an
-            // odd row count the last instruction's second half fetches some valid row into a staging row nobody reads
-            // (SR is even).
+        if (RPI == 2) {
+            // d = 128: two rows per instruction.  Every lane forms the address of ITS entry's row once; an instruction's
+            // two row addresses then come from lane reads (scalar) and a select by the lane's half -- no ds_bpermute
+            // round trips, no per-instruction table select and 64-bit multiply (27 -> ~12 instructions per two rows)
             const float *tab = gtab ? (eside ? a.m.G[1] : a.m.G[0]) : (eside ? a.m.W[1] : a.m.W[0]);
-            atab[lane] = (unsigned long long)(uintptr_t)(tab + (size_t)feat * d);
-            wave_sync();
-            const unsigned long long *ab = atab + c0e + rsub;
-            for (int i0 = 0; i0 < nc; i0 += 16, ab += 16) {
-                unsigned long long base[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) base[k] = ab[2 * k];  // (entries beyond the round: the table's padding)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (i0 + 2 * k < nc) {  // wave-uniform
-                        const float *src = reinterpret_cast<const float *>((uintptr_t)base[k]) + piece * 4;
-                        __builtin_amdgcn_global_load_lds(src, (lds_f32_t *)(dst + (size_t)(i0 + 2 * k) * d), 16, 0, 0);
-                    }
-                }
+            const unsigned long long mine = (unsigned long long)(uintptr_t)(tab + (size_t)feat * d);
+            const int alo = (int)(unsigned)mine, ahi = (int)(unsigned)(mine >> 32);
+            auto two_rows = [&](int i0, bool guard) {
+                const int e0 = (c0e + i0) & (WAVE - 1), e1 = (c0e + i0 + 1) & (WAVE - 1);
+                const unsigned lo0 = (unsigned)read_lane(alo, e0), hi0 = (unsigned)read_lane(ahi, e0);
+                const unsigned lo1 = (unsigned)read_lane(alo, e1), hi1 = (unsigned)read_lane(ahi, e1);
+                const unsigned long long base = rsub ? (((unsigned long long)hi1 << 32) | lo1) : (((unsigned long long)hi0 << 32) | lo0);
+                const float *src = reinterpret_cast<const float *>((uintptr_t)base) + piece * 4;
+                if (!guard || i0 + rsub < nc) __builtin_amdgcn_global_load_lds(src, (lds_f32_t *)(dst + (size_t)i0 * d), 16, 0, 0);
+            };
+            int i0 = 0;
+            for (; i0 + 4 <= nc; i0 += 4) {  // four rows per step, no per-lane predicate
+                two_rows(i0, false);
+                two_rows(i0 + 2, false);
             }
-            wave_sync();  // the table is rewritten by the next call
+            for (; i0 < nc; i0 += 2) two_rows(i0, true);
             return;
         }
         for (int i0 = 0; i0 < nc; i0 += RPI) {
@@ -245,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             e.n = min(WAVE, T - r * WAVE);
             if (keep && T <= WAVE) *keep = e;
             float bx = 0.0f;
+            if (lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
             if constexpr (TIMED) asm volatile("" : "+v"(e.feat), "+v"(e.w));
             stamp(1);
             // end of every job's entries inside this round (lane j = job j), for the fast reduce
@@ -252,9 +245,6 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
             for (int ce = 0; ce < e.n; ce += SR) {
                 const int nc = min(SR, e.n - ce);
                 dma_rows(e.feat, e.eside, ce, nc, stage, false);
-                // the round's bias cells are requested BEHIND the first chunk's rows (both need the entry list; a wait
-                // for the biases placed before the rows' requests would cost the round a round trip of its own)
-                if (ce == 0 && lane < e.n) bx = (e.eside ? a.m.b[1] : a.m.b[0])[e.feat];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);

@@ -49,7 +49,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     int waves_per_cu = 8;
     if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID)) {
         const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255;
-        if (b12 >= tile_bytes + 2 * WAVE * 4 + 2 * (WAVE + 16) * 4 + (size_t)8 * d * 4) {
+        if (b12 >= tile_bytes + 2 * WAVE * 4 + (size_t)8 * d * 4) {
             budget = b12;
             waves_per_cu = 12;
         }
@@ -58,7 +58,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list
     for (;; --cb) {
         g.rr = std::max(g.cand_base + cb, kos_rows);
-        const size_t fixed = (size_t)g.rr * g.ts * 4 + 3 * (size_t)g.pair_cap * 4 + 2 * WAVE * 4 + 2 * (WAVE + 16) * 4;
+        const size_t fixed = (size_t)g.rr * g.ts * 4 + 3 * (size_t)g.pair_cap * 4 + 2 * WAVE * 4;
         if (fixed < budget) {
             int sr = (int)((budget - fixed) / ((size_t)d * 4));
             sr = std::min(sr, want) & ~1;
@@ -74,7 +74,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     // on average: 57.2 M/s with all 10 in one batch, 59.4 with 4 + the rest -- an issue-bound kernel pays for every
     // representation it builds in vain; profiles/r04_visit_g.txt)
     g.first_batch = cb == 0 ? 1 : std::max(1, std::min(first_batch > 0 ? first_batch : std::min(max_sampled, 4), cb));
-    g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap + 2 * WAVE + 2 * (WAVE + 16)) * 4;
+    g.smem = (size_t)g.waves_per_block * ((size_t)g.sr * d + (size_t)g.rr * g.ts + 3 * (size_t)g.pair_cap + 2 * WAVE) * 4;
     // residency (wavefronts per CU the session launches): the atomic-heavy losses publish fastest from 8 (C3: 43 M/s at
     // 2 048 interactions in flight against 35 M/s at 3 072); WARP / k-OS take what the LDS allows, up to 12 (C5 shard:
     // 43.3 -> 49.8 M/s from 8 to 12 once the reduce was cheap, profiles/r04_visit_f.txt)
