@@ -46,8 +46,10 @@ struct RanksArgs {
     float *item_eps;        // ranks_mfma2_kernel: [2][n_items] item-side terms of the pre-filter's error bound
     float *test_scores;     // ranks_mfma2_kernel: [test_nnz] exact scores of the test interactions
     int64_t test_nnz;
-    const int32_t *work;    // ranks_mfma2_kernel: [n_work][2] (32-user tile of ulist, first test item of the pass)
+    const int32_t *work;    // ranks_mfma2_kernel: [n_work][2] (32-user tile of ulist, first test item of the pass);
+                            // ranks_mfma3_kernel: [n_work][4] (tile, first test item, first item, end item of the segment)
     int32_t n_work;
+    int32_t item_rows;      // ranks_mfma3_kernel: rows of item_rep (it reads the table through a buffer descriptor)
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)
@@ -104,6 +106,11 @@ hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus);
 // users as tile columns (a lane owns a user for the whole sweep); ulist ordered by test count, largest first
 hipError_t launch_ranks_mfma2(const RanksArgs &a, hipStream_t st, int cus);
 int ranks_mfma2_item_rows(int d);  // rows the component-major item table must have for it
+// the bucket-search sweep (the default): work items of four ints (tile, first test item of the pass, item segment)
+hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus);
+int ranks_mfma3_waves_per_cu(int d);
+int ranks_mfma3_pass_items();
+bool ranks_mfma3_supported(int d, int64_t n_items, int item_rows);  // the table must fit one 2 GB buffer
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);
 

@@ -502,6 +502,322 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// predict_ranks, third formulation (the default): the lane-per-user MFMA sweep of ranks_mfma2_kernel
+// with the per-(score, threshold) compare chain replaced by a SEARCH.  ranks_mfma2_kernel spends ~100
+// VALU instructions per score on 16 thresholds (8.6 G VALU instructions against 0.17 G MFMAs per ML-20M
+// sweep: it is bound by VALU issue, profiles/r04_visit_m.txt).  Here
+//   * a pass holds up to 31 test items of a user, sorted ascending in LDS ([rank][user column], +inf
+//     beyond; the two half-wave lanes of a user share the column);
+//   * per score: x_lo = s - eps, x_hi = s + eps, then log2(32) = 5 (4, 3 for light passes) dependent
+//     ds_read + v_cmp + v_cndmask + v_add steps give k = #{thresholds < x_lo} (the row offsets are
+//     instruction immediates), one more read the smallest threshold >= x_lo (in the rounding band iff it
+//     is <= x_hi), and one ds_add_u32 counts the score in bucket k.  Eight scores go through the steps
+//     side by side.  The count of the threshold of rank r is the sum of the buckets above r, taken once
+//     per work item;
+//   * eps of a score is the bound of ITS octet of items (max over 8 items, x 1.125 for the roundings of
+//     s -/+ eps): one instruction per score instead of eight; the band is re-decided with the reference's
+//     sequential dot as before (PYX:1317-1319), so the ranks are the reference's integers;
+//   * a work item = (32-user tile, pass, segment of the item table): partial counts are integers < 2^24
+//     published with float atomics (exact), segments are dispatched segment-major so that the wavefronts
+//     resident at one time walk the same ~1 MB of the table.
+// LDS 12.3 KB and <= 168 VGPRs per wavefront: three wavefronts per SIMD (d <= 64).
+// max over the aligned group of eight lanes, in all eight
+__device__ __forceinline__ float octet_max(float v)
+{
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));  // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));  // [2,3,0,1]
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)));  // lane ^ 4
+}
+
+constexpr int R3_ROWS = 32;            // rows of the sorted-threshold / bucket arrays: up to 31 thresholds per pass
+constexpr unsigned R3_CNT = 0x3ffffffu;  // hist_s: bucket count in the low 26 bits, the test slot of rank r above
+
+// The 16 scores of a lane: bucket counts, and the mask of scores with a threshold in their rounding band
+// (score r -> bit 15 - r).  Items that do not count arrive as -inf (bucket 0, near nothing).  ejq / njq: item-side
+// bound terms, octet maxima, by item lane.  cb: the lane's byte offset in a row of srt_s / hist_s (4 col).
+// t0, t1a, t1b: the thresholds the first two steps of every search compare with (rows R/2 - 1, R/4 - 1, 3R/4 - 1),
+// held in registers.  The W scores of a group take each further step TOGETHER -- W reads in flight, one wait -- which
+// the scheduling barriers keep (left alone, the compiler forms chains of two to four scores and the wavefront spends
+// half its life waiting for LDS round trips, visit r4o).
+#ifndef LFM_RANKS3_GROUP
+#define LFM_RANKS3_GROUP 8
+#endif
+// (a & mask) | c and (m & a) | (~m & b) as the single instructions they are (the compiler's own forms of the
+// expressions below are compare + select chains)
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned c)
+{
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned bit_select(unsigned m, unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+}
+
+// "x > v" is taken from the SIGN of v - x (equal -> +0, v = +inf or x = -inf -> +inf: "not above", as the compare
+// gives; no NaN reaches here): shifts and bit merges instead of compare + select, whose VCC round trip costs a
+// wait state per use on this chip.
+template <int L>
+__device__ __forceinline__ unsigned count_tile(const f32x16 &acc, float ejq, float njq, float nu2, float eu2,
+                                               unsigned cb, float t0, float t1a, float t1b, const char *srt_b, char *hist_b)
+{
+    constexpr int W = LFM_RANKS3_GROUP;
+    constexpr int SH0 = L + 6;  // log2 of the byte offset of half the rows (2^L rows of 128 B)
+    unsigned nband = 0u;        // complement of the band mask
+#pragma unroll
+    for (int g0 = 0; g0 < 16; g0 += W) {
+        float xl[W], xh[W];
+        unsigned ib[W];
+#pragma unroll
+        for (int gq = 0; gq < W / 4; ++gq) {
+            const int g = g0 / 4 + gq;  // rows 8 g + 4 half + 0..3 of the tile: half of an octet of items, whose bound it takes
+            const float eps = __fmaf_rn(nu2, read_lanef(njq, 8 * g), __fadd_rn(eu2, read_lanef(ejq, 8 * g)));
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int q = 4 * gq + qq, r = g0 + q;
+                xl[q] = __fsub_rn(acc[r], eps);
+                xh[q] = __fadd_rn(acc[r], eps);
+                const unsigned m0 = (unsigned)(__float_as_int(__fsub_rn(t0, xl[q])) >> 31);  // all ones: above t0
+                ib[q] = and_or(m0, 1u << SH0, cb);
+                const float v1 = __uint_as_float(bit_select(m0, __float_as_uint(t1b), __float_as_uint(t1a)));
+                ib[q] = and_or(__float_as_uint(__fsub_rn(v1, xl[q])) >> (31 - (SH0 - 1)), 1u << (SH0 - 1), ib[q]);
+            }
+        }
+#pragma unroll
+        for (int lv = 2; lv < L; ++lv) {
+            const int sh = SH0 - lv;  // this step adds 2^sh bytes
+            float v[W];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < W; ++q) v[q] = *(const float *)(srt_b + ib[q] + ((1 << sh) - 128));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < W; ++q) ib[q] = and_or(__float_as_uint(__fsub_rn(v[q], xl[q])) >> (31 - sh), 1u << sh, ib[q]);
+        }
+        float succ[W];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < W; ++q) succ[q] = *(const float *)(srt_b + ib[q]);  // rows >= the pass's thresholds hold +inf
+#pragma unroll
+        for (int q = 0; q < W; ++q) atomicAdd((unsigned *)(hist_b + ib[q]), 1u);
+        __builtin_amdgcn_sched_barrier(0);
+        // in the band iff succ <= x_hi, i.e. x_hi - succ is not negative
+#pragma unroll
+        for (int q = 0; q < W; ++q) nband = __builtin_amdgcn_alignbit(nband, __float_as_uint(__fsub_rn(xh[q], succ[q])), 31);
+    }
+    return ~nband & 0xffffu;
+}
+
+// Scores with a threshold inside [x_lo, x_hi], re-decided with the reference's sequential dot (PYX:1317-1319).
+__device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, int m, float nu2, float eu2,
+                                           const float *urow, const float *vT, int I, int d, const float *sc_s,
+                                           const float *ej_s, const float *nj_s, const float *srt_s,
+                                           const unsigned *hist_s, const int32_t *tids, float *ranks)
+{
+    const int half = lane >> 5, col = lane & 31;
+    asm volatile("" : "+s"(I), "+s"(d), "+s"(vT));  // rare path: nothing of its address arithmetic is hoisted into the sweep
+    while (band) {
+        const int bit = __ffs((int)band) - 1;
+        band &= band - 1u;
+        const int r = 15 - bit;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half, item = j0 + i;
+        const float sc = sc_s[r * WAVE + lane];
+        const float eps = __fmaf_rn(nu2, nj_s[i], __fadd_rn(eu2, ej_s[i]));
+        const float xl = __fsub_rn(sc, eps), xh = __fadd_rn(sc, eps);
+        bool need = false;
+        for (int t = 0; t < m; ++t) {
+            const float th = srt_s[t * 32 + col];
+            need = need || (!(xl > th) && th <= xh && item != tids[hist_s[t * 32 + col] >> 26]);
+        }
+        if (need) {
+            // the reference's sequential dot (PYX:320-334); eight products' operands requested at a time
+            float ex = __fadd_rn(urow[d], vT[(size_t)d * I + item]);
+#pragma unroll 1
+            for (int c0 = 0; c0 < d; c0 += 8) {
+                float uu[8], vv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = min(c0 + q, d - 1);
+                    uu[q] = urow[c];
+                    vv[q] = vT[(size_t)c * I + item];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c0 + q < d) ex = __fadd_rn(ex, __fmul_rn(uu[q], vv[q]));
+            }
+            for (int t = 0; t < m; ++t) {
+                const float th = srt_s[t * 32 + col];
+                const int slot = (int)(hist_s[t * 32 + col] >> 26);
+                if (!(xl > th) && th <= xh && item != tids[slot] && ex >= th) atomicAdd(&ranks[slot], 1.0f);
+            }
+        }
+    }
+}
+
+template <int KSTEPS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KSTEPS > 32 ? 2 : 3, KSTEPS > 32 ? 2 : 3)))
+void ranks_mfma3_kernel(RanksArgs a)
+{
+    constexpr int ROWS = R3_ROWS, MT = ROWS - 1;
+    __shared__ float srt_s[ROWS * 32];      // [rank][user column] thresholds of the pass, ascending, +inf beyond
+    __shared__ unsigned hist_s[ROWS * 32];  // [bucket][user column] scores with `bucket` thresholds below | slot of the rank << 26
+    __shared__ float sc_s[16 * WAVE];       // sorting scratch [slot][user column]; slow path: the tile's scores [r][lane]
+    __shared__ float ej_s[32], nj_s[32];    // slow path: bound terms of the tile's items
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    const int d = a.d, I = a.test.cols;
+    const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
+    const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
+    const float INF = __int_as_float(0x7f800000);
+    // the component-major item table and the bound terms as buffers (launch_ranks_mfma3 checks they are < 2 GB)
+    const unsigned row2 = 8u * (unsigned)I;  // bytes of two table rows
+    const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vT, 0, (int)(4u * (unsigned)I * (unsigned)a.item_rows), 0x00020000);
+    const __amdgpu_buffer_rsrc_t esrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.item_eps, 0, (int)row2, 0x00020000);
+    const unsigned cb = 4u * (unsigned)col;
+    const char *srt_b = (const char *)srt_s;
+    char *hist_b = (char *)hist_s;
+    for (int w = blockIdx.x; w < a.n_work; w += gridDim.x) {
+        const int tile = a.work[4 * w], p0 = a.work[4 * w + 1], jb = a.work[4 * w + 2], je = a.work[4 * w + 3];
+        const int ui = tile * 32 + col;
+        const bool uok = ui < a.n_ulist;
+        const int user = uok ? a.ulist[ui] : 0;
+        const float *urow = a.user_rep + (size_t)user * a.rs;
+        float ub[KSTEPS];
+        float n2 = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int k = 2 * kk + half;
+            ub[kk] = (uok && k < d) ? urow[k] : 0.0f;
+            n2 += ub[kk] * ub[kk];
+        }
+        n2 += __shfl_xor(n2, 32, WAVE);
+        const float bu = uok ? urow[d] : 0.0f;
+        // the user-side terms of the bound, x 1.125: the margin for the roundings of s - eps and s + eps
+        const float nu2 = sqrtf(n2) * 1.0000005f * 1.125f, eu2 = kappa * fabsf(bu) * 1.125f;
+        const int t_lo = uok ? a.test.indptr[user] : 0, t_hi = uok ? a.test.indptr[user + 1] : 0;
+        const int m = max(0, min(MT, (t_hi - t_lo) - p0));
+        const int32_t *tids = a.test.indices + t_lo + p0;
+        float *ranks = a.ranks + t_lo + p0;
+        // ---- this pass's thresholds (exact scores of the test items, PYX:1278-1293, from test_scores_kernel),
+        // sorted by (value, slot): rank = number of smaller ones, each half-wave lane places every other slot
+        wave_sync();
+#pragma unroll 1
+        for (int t = half; t < ROWS; t += 2) {
+            sc_s[t * 32 + col] = t < m ? a.test_scores[t_lo + p0 + t] : INF;
+            srt_s[t * 32 + col] = INF;
+            hist_s[t * 32 + col] = 0u;
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int t = half; t < m; t += 2) {
+            const float v = sc_s[t * 32 + col];
+            int rk = 0;
+#pragma unroll 1
+            for (int t2 = 0; t2 < m; ++t2) {
+                const float o = sc_s[t2 * 32 + col];
+                rk += (o < v || (o == v && t2 < t)) ? 1 : 0;
+            }
+            srt_s[rk * 32 + col] = v;
+            hist_s[rk * 32 + col] = (unsigned)t << 26;
+        }
+        wave_sync();
+        const int levels = __ballot(m > 15) != 0ull ? 5 : (__ballot(m > 7) != 0ull ? 4 : 3);
+        // the thresholds of the first two steps of every search of this pass
+        const int rows = 1 << levels;
+        const float t0 = srt_s[(rows / 2 - 1) * 32 + col], t1a = srt_s[(rows / 4 - 1) * 32 + col],
+                    t1b = srt_s[(3 * rows / 4 - 1) * 32 + col];
+        // train row cursor of the user at the segment's first item, one entry ahead
+        int tp = 0, tend = 0, next = 0x7fffffff, next2 = 0x7fffffff;
+        if (uok) {
+            tp = a.train.indptr[user];
+            tend = a.train.indptr[user + 1];
+            int lo = tp, hi = tend;  // first entry >= jb
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (a.train.indices[mid] < jb) lo = mid + 1; else hi = mid;
+            }
+            tp = lo;
+            if (tp < tend) next = a.train.indices[tp];
+            if (tp + 1 < tend) next2 = a.train.indices[tp + 1];
+        }
+        // A operand of a tile: V[item j0 + col][2 kk + half], walked down the component-major table through ONE
+        // buffer descriptor: a 32-bit lane offset, the row as the scalar offset (no per-load address arithmetic)
+        float av[KSTEPS], bj = 0.0f, ej = 0.0f, njk = 0.0f;
+        auto load_tile = [&](int j0) {
+            const unsigned jc = (unsigned)min(j0 + col, I - 1);
+            const unsigned voff = 4u * (jc + (unsigned)half * (unsigned)I);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                av[kk] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, voff, (unsigned)kk * row2, 0));
+            bj = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, 4u * jc, (unsigned)d * (row2 >> 1), 0));
+            ej = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(esrc, 4u * jc, 0, 0));
+            njk = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(esrc, 4u * jc, row2 >> 1, 0));
+        };
+        load_tile(jb);
+        // the biases as one more step of the product: (b_j, 1) . (1, b_u)
+        const float ub_x = half ? bu : 1.0f;
+        for (int j0 = jb; j0 < je; j0 += 32) {
+            const float av_x = half ? 1.0f : bj;
+            const float ejq = octet_max(ej) * 1.125f, njq = octet_max(njk);
+            // items that do not count: train positives inside [j0, j0 + 32) (PYX:1303-1304), rows past the table
+            unsigned tmask = j0 + 32 > I ? ~0u << (I - j0) : 0u;
+            while (next < j0 + 32) {
+                tmask |= 1u << (next - j0);
+                ++tp;
+                next = next2;
+                next2 = tp + 1 < tend ? a.train.indices[tp + 1] : 0x7fffffff;
+            }
+            const unsigned tm = tmask >> (4 * half);
+            // they start from -inf and stay there: below every threshold, near none
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int iA = (r & 3) + 8 * (r >> 2);
+                int off;  // 0 / -1 (written as the instruction: the compiler's own form is and + compare + select)
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(off) : "v"(tm), "n"(iA));
+                acc[r] = __int_as_float(off & (int)0xff800000);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], ub[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_x, ub_x, acc, 0, 0, 0);
+            // the MFMAs have read this tile's operands: request the next tile's now
+            if (j0 + 32 < je) load_tile(j0 + 32);
+            unsigned band;
+            if (levels == 5) band = count_tile<5>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
+            else if (levels == 4) band = count_tile<4>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
+            else band = count_tile<3>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
+            if (__ballot(band != 0u) != 0ull) {
+                if (half == 0) {
+                    ej_s[col] = ejq;
+                    nj_s[col] = njq;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc_s[r * WAVE + lane] = acc[r];
+                wave_sync();
+                band_recheck3(band, lane, j0, m, nu2, eu2, urow, vT, I, d, sc_s, ej_s, nj_s, srt_s, hist_s, tids, ranks);
+                wave_sync();
+            }
+        }
+        // counts: threshold of rank r is exceeded by the scores of every bucket above r
+        wave_sync();
+        if (half == 0) {
+            unsigned run = 0u;
+#pragma unroll 1
+            for (int k = ROWS - 1; k >= 1; --k) {
+                run += hist_s[k * 32 + col] & R3_CNT;
+                if (k - 1 < m && run) atomicAdd(&ranks[hist_s[(k - 1) * 32 + col] >> 26], (float)run);
+            }
+        }
+    }
+}
+
 bool ranks_mfma_supported(int d) { return d >= 1 && d <= 128; }
 
 hipError_t launch_ranks_mfma(const RanksArgs &a, hipStream_t st, int cus)
@@ -526,6 +842,38 @@ static hipError_t launch_ranks_mfma2_k(const RanksArgs &a, hipStream_t st, int c
         grid = std::min(a.n_work, per_cu * std::max(cus, 1));
     ranks_mfma2_kernel<KSTEPS><<<grid, 64, 0, st>>>(a);
     return hipGetLastError();
+}
+
+template <int KSTEPS>
+static hipError_t launch_ranks_mfma3_k(const RanksArgs &a, hipStream_t st, int cus)
+{
+    int per_cu = 0, grid = a.n_work;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma3_kernel<KSTEPS>, 64, 0) == hipSuccess && per_cu > 0)
+        grid = std::min(a.n_work, per_cu * std::max(cus, 1));
+    ranks_mfma3_kernel<KSTEPS><<<grid, 64, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+// wavefronts launch_ranks_mfma3 keeps resident per CU (the host sizes its work items by it)
+int ranks_mfma3_waves_per_cu(int d) { return d <= 64 ? 12 : 8; }
+int ranks_mfma3_pass_items() { return R3_ROWS - 1; }
+bool ranks_mfma3_supported(int d, int64_t n_items, int item_rows)
+{
+    return ranks_mfma_supported(d) && n_items * item_rows * 4 < ((int64_t)1 << 31);
+}
+
+// a.work: [n_work][4] (32-user tile of ulist, first test item of the pass, first item, end item of the segment);
+// segments start at multiples of 32 and hold < 2^26 items; a.ulist / a.item_rep / a.item_eps as for launch_ranks_mfma2
+hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus)
+{
+    if (a.n_ulist <= 0 || a.n_work <= 0) return hipSuccess;
+    const float kappa = 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
+    item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
+    test_scores_kernel<<<(int)((a.test_nnz + 255) / 256), 256, 0, st>>>(a);
+    if (a.d <= 32) return launch_ranks_mfma3_k<16>(a, st, cus);
+    if (a.d <= 64) return launch_ranks_mfma3_k<32>(a, st, cus);
+    if (a.d <= 128) return launch_ranks_mfma3_k<64>(a, st, cus);
+    return hipErrorInvalidValue;
 }
 
 int ranks_mfma2_item_rows(int d) { return std::max(d + 1, d <= 32 ? 32 : (d <= 64 ? 64 : 128)); }

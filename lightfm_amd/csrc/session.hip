@@ -2145,19 +2145,101 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.item_eps = ieps.p;
     a.test_scores = tscores.p;
     a.test_nnz = test->nnz;
-    // LIGHTFM_AMD_RANKS_MFMA: 0 the scalar kernel, 1 the first MFMA formulation (users as tile rows),
-    // unset / 2 the second (a lane owns a user); the tests compare all three
+    a.item_rows = irows;
+    // LIGHTFM_AMD_RANKS_MFMA: 0 the scalar kernel, 1 the first MFMA formulation (users as tile rows), 2 the
+    // second (a lane owns a user, compare chain), unset / 3 the third (a lane owns a user, bucket search); the
+    // tests compare all four
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
-    int mfma_mode = mfma_env == nullptr ? 2 : atoi(mfma_env);
+    int mfma_mode = mfma_env == nullptr ? 3 : atoi(mfma_env);
     // the MFMA sweeps mask train positives by walking each user's train row alongside the item tiles: they
     // need ascending column indices (tocsr() of a COO gives them; a CSR handed in by the caller may not).
     // Unsorted rows run the scalar kernel, whose lookup is the reference's binary search.  Checked on the
     // device (the host loop over ML-20M's 18 M train entries cost 15 ms per call).
-    if (mfma_mode != 0 && train->nnz > 1) {
-        int unsorted = 0;
+    const bool check_sorted = mfma_mode != 0 && train->nnz > 1;
+    if (check_sorted) {
         HIP_TRY(hipMemsetAsync(s->flag.p, 0, sizeof(int), s->stream));
         rows_sorted_kernel<<<(int)std::min<int64_t>(4096, ((int64_t)train->rows + 255) / 256), 256, 0, s->stream>>>(
             dtrain.indptr.p, dtrain.indices.p, train->rows, s->flag.p);
+    }
+    // (host, while the representation kernels and the check run) users with test interactions, in tiles of 32 per
+    // wavefront, most test items first: the users of a wavefront then need the same number of threshold passes and
+    // the heavy wavefronts are dispatched first.  A counting sort: the order of a stable sort by count.
+    std::vector<int32_t> ul;
+    if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
+        int32_t cmax = 0;
+        size_t n_with = 0;
+        for (int32_t u = 0; u < test->rows; ++u) {
+            const int32_t c = test->indptr[u + 1] - test->indptr[u];
+            if (c > 0) {
+                ++n_with;
+                cmax = std::max(cmax, c);
+            }
+        }
+        ul.resize(n_with);
+        std::vector<size_t> start((size_t)cmax + 2, 0);  // bucket cmax - c: the heaviest users first
+        if (mfma_mode != 1)
+            for (int32_t u = 0; u < test->rows; ++u) {
+                const int32_t c = test->indptr[u + 1] - test->indptr[u];
+                if (c > 0) ++start[(size_t)(cmax - c) + 1];
+            }
+        for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+        for (int32_t u = 0; u < test->rows; ++u) {
+            const int32_t c = test->indptr[u + 1] - test->indptr[u];
+            if (c > 0) ul[start[mfma_mode != 1 ? (size_t)(cmax - c) : 0]++] = u;
+        }
+    }
+    // work items of the lane-per-user sweeps
+    std::vector<int32_t> wl;
+    const bool bucket_search = mfma_mode != 2 && ranks_mfma3_supported(s->d, itf.rows, irows);
+    if (mfma_mode >= 2 && ranks_mfma_supported(s->d) && !bucket_search) {
+        // ranks_mfma2_kernel: every 32-user tile x every pass of 16 test items its heaviest (first) user needs
+        for (size_t t0 = 0; t0 < ul.size(); t0 += 32) {
+            const int32_t u0 = ul[t0];
+            const int32_t cnt = test->indptr[u0 + 1] - test->indptr[u0];
+            for (int32_t p0 = 0; p0 < cnt; p0 += 16) {
+                wl.push_back((int32_t)(t0 / 32));
+                wl.push_back(p0);
+            }
+        }
+    } else if (mfma_mode >= 2 && ranks_mfma_supported(s->d)) {
+        // ranks_mfma3_kernel: (32-user tile, pass of up to 31 test items of its heaviest user, segment of the item
+        // table).  Enough segments that every resident wavefront gets ~8 items (an even finish), none shorter than
+        // 32 tiles of items; segment-major, heaviest passes first: the wavefronts resident at one time read the
+        // same part of the table.
+        const int32_t mt = ranks_mfma3_pass_items();
+        std::vector<int32_t> passes;
+        for (size_t t0 = 0; t0 < ul.size(); t0 += 32) {
+            const int32_t u0 = ul[t0];
+            const int32_t cnt = test->indptr[u0 + 1] - test->indptr[u0];
+            for (int32_t p0 = 0; p0 < cnt; p0 += mt) {
+                passes.push_back((int32_t)(t0 / 32));
+                passes.push_back(p0);
+            }
+        }
+        const int64_t n_pass = (int64_t)passes.size() / 2;
+        const int64_t resident = (int64_t)std::max(s->cus, 1) * ranks_mfma3_waves_per_cu(s->d);
+        const int64_t item_tiles = ((int64_t)test->cols + 31) / 32;
+        int64_t segs = std::max<int64_t>(1, (8 * resident + n_pass - 1) / std::max<int64_t>(n_pass, 1));
+        segs = std::min(segs, std::max<int64_t>(1, item_tiles / 32));
+        segs = std::max(segs, (item_tiles * 32 + (1 << 25) - 1) / (1 << 25));  // < 2^26 items per segment
+        if (const char *e = getenv("LIGHTFM_AMD_RANKS_SEGMENTS"))
+            segs = std::max<int64_t>(1, std::min<int64_t>(atoi(e), item_tiles));
+        const int64_t seg_tiles = (item_tiles + segs - 1) / segs;
+        if (n_pass * segs > (int64_t)INT32_MAX / 4) return fail(LFM_EINVAL, "too many test interactions for one call");
+        wl.reserve((size_t)(n_pass * segs * 4));
+        for (int64_t sg = 0; sg < segs; ++sg) {
+            const int64_t jb = sg * seg_tiles * 32, je = std::min<int64_t>((sg + 1) * seg_tiles * 32, test->cols);
+            if (jb >= je) break;
+            for (int64_t p = 0; p < n_pass; ++p) {
+                wl.push_back(passes[2 * p]);
+                wl.push_back(passes[2 * p + 1]);
+                wl.push_back((int32_t)jb);
+                wl.push_back((int32_t)je);
+            }
+        }
+    }
+    if (check_sorted) {
+        int unsorted = 0;
         HIP_TRY(hipMemcpyAsync(&unsorted, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (unsorted) mfma_mode = 0;
@@ -2165,36 +2247,17 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.work = nullptr;
     a.n_work = 0;
     if (mfma_mode != 0 && ranks_mfma_supported(s->d)) {
-        // users with test interactions, in tiles of 32 per wavefront, most test items first: the
-        // users of a wavefront then need the same number of threshold passes and the heavy
-        // wavefronts are dispatched first
-        std::vector<int32_t> ul;
-        for (int32_t u = 0; u < test->rows; ++u)
-            if (test->indptr[u + 1] > test->indptr[u]) ul.push_back(u);
-        if (mfma_mode != 1)
-            std::stable_sort(ul.begin(), ul.end(), [&](int32_t x, int32_t y) {
-                return test->indptr[x + 1] - test->indptr[x] > test->indptr[y + 1] - test->indptr[y];
-            });
         LFM_TRY(ulist.upload(ul.data(), ul.size()));
         a.ulist = ulist.p;
         a.n_ulist = (int32_t)ul.size();
         if (mfma_mode == 1) {
             HIP_TRY(launch_ranks_mfma(a, s->stream, s->cus));
         } else {
-            // work items: every 32-user tile x every pass of 16 test items its heaviest (first) user needs
-            std::vector<int32_t> wl;
-            for (size_t t0 = 0; t0 < ul.size(); t0 += 32) {
-                const int32_t u0 = ul[t0];
-                const int32_t cnt = test->indptr[u0 + 1] - test->indptr[u0];
-                for (int32_t p0 = 0; p0 < cnt; p0 += 16) {
-                    wl.push_back((int32_t)(t0 / 32));
-                    wl.push_back(p0);
-                }
-            }
             LFM_TRY(work.upload(wl.data(), wl.size()));
             a.work = work.p;
-            a.n_work = (int32_t)(wl.size() / 2);
-            HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
+            a.n_work = (int32_t)(wl.size() / (bucket_search ? 4 : 2));
+            if (bucket_search) HIP_TRY(launch_ranks_mfma3(a, s->stream, s->cus));
+            else HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
         }
     } else {
         HIP_TRY(launch_ranks(a, s->stream));

@@ -98,7 +98,7 @@ def test_intersecting_train_and_test_is_rejected(fitted):
     precision_at_k(model, train, train_interactions=train, check_intersections=False)
 
 
-_RANK_KERNELS = (("lane-per-user", "2"), ("users-as-rows", "1"), ("scalar", "0"))
+_RANK_KERNELS = (("bucket-search", "3"), ("lane-per-user", "2"), ("users-as-rows", "1"), ("scalar", "0"))
 
 
 def _ranks_by_kernel(model, test, train=None, **kw):
@@ -114,8 +114,9 @@ def _ranks_by_kernel(model, test, train=None, **kw):
 
 
 def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
-    """predict_ranks through both MFMA pre-filters (csrc/predict_kernels.hip: ranks_mfma2_kernel -- the
-    default, a lane owns a user -- and ranks_mfma_kernel) and through the scalar sequential-dot kernel
+    """predict_ranks through the three MFMA pre-filters (csrc/predict_kernels.hip: ranks_mfma3_kernel -- the
+    default: a lane owns a user, a search over the sorted thresholds counts a score -- ranks_mfma2_kernel, the
+    same sweep with a compare chain, and ranks_mfma_kernel) and through the scalar sequential-dot kernel
     on a TRAINED model at the ML-20M item count: every rank identical (an MFMA score only decides
     comparisons outside its rounding band, the rest is re-decided with the sequential dot)."""
     import scipy.sparse as sp
@@ -125,6 +126,7 @@ def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
     m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=3)
     ranks = _ranks_by_kernel(m, test, train)
     assert len(ranks["scalar"]) == test.nnz and ranks["scalar"].max() > 100
+    assert np.array_equal(ranks["bucket-search"], ranks["scalar"])
     assert np.array_equal(ranks["lane-per-user"], ranks["scalar"])
     assert np.array_equal(ranks["users-as-rows"], ranks["scalar"])
     # heavy users (more test items than one pass of the kernels holds) and an odd no_components
@@ -132,6 +134,7 @@ def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
     heavy = sp.coo_matrix((np.ones(300, np.float32), (np.repeat([3, 4000], 150), np.tile(np.arange(150) * 7, 2))),
                           shape=test.shape, dtype=np.float32)
     out = _ranks_by_kernel(m2, heavy)
+    assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
     assert np.array_equal(out["users-as-rows"], out["scalar"])
 
@@ -150,12 +153,23 @@ def test_mfma_ranks_shapes_and_ties(d, n_items):
     m.item_embeddings[h:2 * h] = m.item_embeddings[:h]
     m.item_biases[h:2 * h] = m.item_biases[:h]
     out = _ranks_by_kernel(m, test, train)
+    assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
     assert np.array_equal(out["users-as-rows"], out["scalar"])
+    # the default kernel with the item table cut into three segments (partial counts meet in float atomics; the
+    # train-row cursor starts in the middle of a row)
+    import os
+    os.environ["LIGHTFM_AMD_RANKS_SEGMENTS"] = "3"
+    try:
+        cut = m.predict_rank(test, train_interactions=train, check_intersections=False).data
+    finally:
+        os.environ.pop("LIGHTFM_AMD_RANKS_SEGMENTS", None)
+    assert np.array_equal(cut, out["scalar"])
     fresh = LightFM(no_components=d, loss="warp", random_state=5)
     fresh._initialize(d, n_items, 300)
     fresh.item_embeddings *= 1e-3
     out = _ranks_by_kernel(fresh, test, train)
+    assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
 
 

@@ -41,7 +41,7 @@ def _usage(source, tmp_path):
             name = m.group(1)
             kernels[name] = {}
             continue
-        m = re.search(r"remark: +(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        m = re.search(r"remark: +(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
         if m and name:
             kernels[name][m.group(1).split(" ")[0]] = int(m.group(2))
     assert kernels, "no resource remarks in the compiler output"
@@ -100,6 +100,10 @@ def test_scoring_kernel_budgets(tmp_path):
         u = _one(k, "ranks_mfma2_kernelILi%dEEE" % ks)
         assert u["Occupancy"] >= 2 and u["VGPRs"] + u["AGPRs"] <= 256, (ks, u)
     assert _one(k, "ranks_mfma2_kernelILi64EEE")["Occupancy"] >= 1
+    # the bucket-search sweep (the default): three wavefronts per SIMD for d <= 64 (12.3 KB of LDS each), two for d <= 128
+    for ks, occ in ((16, 3), (32, 3), (64, 2)):
+        u = _one(k, "ranks_mfma3_kernelILi%dEEE" % ks)
+        assert u["Occupancy"] >= occ and u["VGPRs"] + u["AGPRs"] <= 512 // occ and u["LDS"] <= 160 * 1024 // (4 * occ), (ks, u)
 
 
 @pytest.mark.timeout(1200)
@@ -144,3 +148,9 @@ def test_instruction_selection_of_the_hot_kernels(tmp_path):
     sweep = [b for n, b in ranks.items() if "ranks_mfma2_kernelILi32EEE" in n][0]
     assert sweep.count("v_mfma_f32_32x32x2_f32") == 32  # d = 64: 32 steps of k = 2
     assert "scratch_" not in sweep and "v_pk_add_f32" in sweep
+    # the bucket-search sweep: biases as a 33rd step, the item table through buffer loads with scalar row offsets (no
+    # per-load address arithmetic), bucket counts by LDS atomics, every rank published by a hardware float atomic
+    search = [b for n, b in ranks.items() if "ranks_mfma3_kernelILi32EEE" in n][0]
+    assert search.count("v_mfma_f32_32x32x2_f32") == 33 and "scratch_" not in search
+    assert search.count("buffer_load_dword") >= 2 * 35 and search.count("ds_add_u32") >= 16
+    assert "global_atomic_add_f32" in search

@@ -566,6 +566,35 @@ PY
     ENVV=$PREV run c3_prev_$i $C3
   done
   ;;
+r4o)
+  # round 4: predict_ranks with the bucket-search sweep (ranks_mfma3_kernel) -- exactness first, then time against the
+  # compare-chain sweep in one process, kernel trace + SQ counters
+  timeout -k 5 900 $PYT tests/test_evaluation_gpu.py tests/test_golden.py tests/test_lightfm_api.py "tests/test_baseline_shapes.py::test_predict_ranks_vs_oracle_at_ml20m_items" tests/test_reference_suite.py -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  cd /tmp && export TMPDIR=/tmp
+  RANKS_TIMING_MODES=3,2 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/tools/ranks_timing.py > $OUT/ranks_trace.txt 2> $OUT/ranks_trace.err
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_a -o pmc -- python $R/tools/ranks_timing.py > $OUT/ranks_a.txt 2> $OUT/ranks_a.err
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU -d $OUT/pmc_b -o pmc -- python $R/tools/ranks_timing.py > $OUT/ranks_b.txt 2> $OUT/ranks_b.err
+  cd $R && grep -a "mode\|identical" $OUT/ranks_trace.txt | cut -c1-330 && tail -3 $OUT/ranks_trace.err | cut -c1-300 && python - <<PY
+import sqlite3, glob
+try:
+    db = glob.glob("$OUT/trace/**/*results.db", recursive=True)[0]
+    con = sqlite3.connect(db)
+    for r in con.execute("select name, count(*), sum(duration)/1e6, avg(duration)/1e3 from kernels group by name order by sum(duration) desc limit 8"):
+        print("  %-70s calls %4d total %9.2f ms avg %10.1f us" % (r[0][:70], r[1], r[2], r[3]))
+except Exception as e:
+    print("trace:", e)
+for sub in ("pmc_a", "pmc_b"):
+    try:
+        db = glob.glob("$OUT/%s/**/*results.db" % sub, recursive=True)[0]
+        con = sqlite3.connect(db)
+        rows = con.execute("select k.name, p.counter_name, count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id where k.name like '%ranks_mfma3%' group by k.name, p.counter_name").fetchall()
+        print("  %s:" % sub, {c: round(v / n, 0) for _, c, n, v in rows}, "per launch")
+    except Exception as e:
+        print(sub, e)
+PY
+  find $OUT -name "*.db" -size +5M -delete
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
