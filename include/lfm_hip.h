@@ -201,8 +201,8 @@ int lfm_predict(const lfm_csr *item_features, const lfm_csr *user_features,
 
 /* predict_ranks, PYX:1232-1323 (LFM:979-987): ranks[] += count, in place.  The dense all-items pass runs
  * on the matrix cores (v_mfma_f32_32x32x2_f32 pre-filter + sequential-dot re-check inside the rounding
- * band): the ranks are the reference's integers.  LIGHTFM_AMD_RANKS_MFMA = 0 | 1 select the scalar / the
- * first MFMA kernel (cross-checks). */
+ * band): the ranks are the reference's integers.  LIGHTFM_AMD_RANKS_MFMA = 0 | 1 | 2 select the scalar / the
+ * first / the second MFMA kernel (cross-checks); unset or 3 = the bucket-search sweep. */
 int lfm_predict_ranks(const lfm_csr *item_features, const lfm_csr *user_features,
                       const lfm_csr *test_interactions, const lfm_csr *train_interactions,
                       float *ranks, const lfm_model *model);

@@ -516,8 +516,8 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
 //     is <= x_hi), and one ds_add_u32 counts the score in bucket k.  Eight scores go through the steps
 //     side by side.  The count of the threshold of rank r is the sum of the buckets above r, taken once
 //     per work item;
-//   * eps of a score is the bound of ITS octet of items (max over 8 items, x 1.125 for the roundings of
-//     s -/+ eps): one instruction per score instead of eight; the band is re-decided with the reference's
+//   * eps of a score is the bound of ITS octet of items (max over 8 items, x (1 + 1 / (2 (d + 2))) for the roundings
+//     of s -/+ eps): one instruction per score instead of eight; the band is re-decided with the reference's
 //     sequential dot as before (PYX:1317-1319), so the ranks are the reference's integers;
 //   * a work item = (32-user tile, pass, segment of the item table): partial counts are integers < 2^24
 //     published with float atomics (exact), segments are dispatched segment-major so that the wavefronts
@@ -540,11 +540,20 @@ constexpr unsigned R3_CNT = 0x3ffffffu;  // hist_s: bucket count in the low 26 b
 // (score r -> bit 15 - r).  Items that do not count arrive as -inf (bucket 0, near nothing).  ejq / njq: item-side
 // bound terms, octet maxima, by item lane.  cb: the lane's byte offset in a row of srt_s / hist_s (4 col).
 // t0, t1a, t1b: the thresholds the first two steps of every search compare with (rows R/2 - 1, R/4 - 1, 3R/4 - 1),
-// held in registers.  The W scores of a group take each further step TOGETHER -- W reads in flight, one wait -- which
-// the scheduling barriers keep (left alone, the compiler forms chains of two to four scores and the wavefront spends
-// half its life waiting for LDS round trips, visit r4o).
+// held in registers.  The scores go through the further steps W at a time.
 #ifndef LFM_RANKS3_GROUP
 #define LFM_RANKS3_GROUP 8
+#endif
+// LFM_RANKS3_LOCKSTEP 1: scheduling barriers keep the W scores of a group in step through the search (W reads in flight,
+// one wait).  Measured SLOWER than the compiler's own interleaving of shorter chains (visit r4q: 9.0 against 7.5 ms
+// without the exact re-checks), so it is off.
+#ifndef LFM_RANKS3_LOCKSTEP
+#define LFM_RANKS3_LOCKSTEP 0
+#endif
+// LFM_R3X: timing experiments of tools/visit.sh r4q (WRONG ranks): 1 no bucket atomics, 2 no LDS search steps,
+// 3 no matrix products; all without the exact re-checks
+#ifndef LFM_R3X
+#define LFM_R3X 0
 #endif
 // (a & mask) | c and (m & a) | (~m & b) as the single instructions they are (the compiler's own forms of the
 // expressions below are compare + select chains)
@@ -594,20 +603,22 @@ __device__ __forceinline__ unsigned count_tile(const f32x16 &acc, float ejq, flo
         for (int lv = 2; lv < L; ++lv) {
             const int sh = SH0 - lv;  // this step adds 2^sh bytes
             float v[W];
-            __builtin_amdgcn_sched_barrier(0);
+            if (LFM_R3X == 2) continue;
+            if (LFM_RANKS3_LOCKSTEP) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < W; ++q) v[q] = *(const float *)(srt_b + ib[q] + ((1 << sh) - 128));
-            __builtin_amdgcn_sched_barrier(0);
+            if (LFM_RANKS3_LOCKSTEP) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < W; ++q) ib[q] = and_or(__float_as_uint(__fsub_rn(v[q], xl[q])) >> (31 - sh), 1u << sh, ib[q]);
         }
         float succ[W];
-        __builtin_amdgcn_sched_barrier(0);
+        if (LFM_RANKS3_LOCKSTEP) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < W; ++q) succ[q] = *(const float *)(srt_b + ib[q]);  // rows >= the pass's thresholds hold +inf
 #pragma unroll
-        for (int q = 0; q < W; ++q) atomicAdd((unsigned *)(hist_b + ib[q]), 1u);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < W; ++q)
+            if (LFM_R3X != 1) atomicAdd((unsigned *)(hist_b + ib[q]), 1u);
+        if (LFM_RANKS3_LOCKSTEP) __builtin_amdgcn_sched_barrier(0);
         // in the band iff succ <= x_hi, i.e. x_hi - succ is not negative
 #pragma unroll
         for (int q = 0; q < W; ++q) nband = __builtin_amdgcn_alignbit(nband, __float_as_uint(__fsub_rn(xh[q], succ[q])), 31);
@@ -615,47 +626,56 @@ __device__ __forceinline__ unsigned count_tile(const f32x16 &acc, float ejq, flo
     return ~nband & 0xffffu;
 }
 
-// Scores with a threshold inside [x_lo, x_hi], re-decided with the reference's sequential dot (PYX:1317-1319).
-__device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, int m, float nu2, float eu2,
-                                           const float *urow, const float *vT, int I, int d, const float *sc_s,
-                                           const float *ej_s, const float *nj_s, const float *srt_s,
+// Scores with a threshold inside [x_lo, x_hi], re-decided with the reference's sequential dot (PYX:1317-1319, 320-334).
+// Every lane takes its next flagged score and looks whether one of its thresholds really needs the exact score; the
+// exact scores are then computed by the WHOLE wavefront, one pending lane at a time: lane c multiplies component c
+// (one load round trip for all d products), and the sum runs over them in the reference's order through lane reads --
+// the same float32 operations as the reference's loop, without its d dependent memory round trips (one lane walking
+// the d components alone cost ~5 000 cycles per score, a third of the sweep's time at ML-20M: visit r4q).
+__device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, int m, float nu2, float eu2, int user,
+                                           const float *user_rep, int rs, const float *vT, int I, int d,
+                                           const float *sc_s, const float *ej_s, const float *nj_s, const float *srt_s,
                                            const unsigned *hist_s, const int32_t *tids, float *ranks)
 {
     const int half = lane >> 5, col = lane & 31;
     asm volatile("" : "+s"(I), "+s"(d), "+s"(vT));  // rare path: nothing of its address arithmetic is hoisted into the sweep
-    while (band) {
-        const int bit = __ffs((int)band) - 1;
-        band &= band - 1u;
-        const int r = 15 - bit;
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half, item = j0 + i;
-        const float sc = sc_s[r * WAVE + lane];
-        const float eps = __fmaf_rn(nu2, nj_s[i], __fadd_rn(eu2, ej_s[i]));
-        const float xl = __fsub_rn(sc, eps), xh = __fadd_rn(sc, eps);
-        bool need = false;
-        for (int t = 0; t < m; ++t) {
-            const float th = srt_s[t * 32 + col];
-            need = need || (!(xl > th) && th <= xh && item != tids[hist_s[t * 32 + col] >> 26]);
+    while (__ballot(band != 0u) != 0ull) {
+        bool pend = false;
+        int item = 0, k = 0;
+        float xl = 0.0f, xh = 0.0f;
+        if (band) {
+            const int bit = __ffs((int)band) - 1;
+            band &= band - 1u;
+            const int r = 15 - bit;
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            item = j0 + i;
+            const float sc = sc_s[r * WAVE + lane];
+            const float eps = __fmaf_rn(nu2, nj_s[i & 24], __fadd_rn(eu2, ej_s[i & 24]));  // the octet's bound, as the sweep took it
+            xl = __fsub_rn(sc, eps);
+            xh = __fadd_rn(sc, eps);
+            // the thresholds in [x_lo, x_hi] are the ranks k, k + 1, ... (k = thresholds below x_lo; rows >= m hold +inf)
+            for (int step = R3_ROWS / 2; step >= 1; step >>= 1)
+                if (xl > srt_s[(k + step - 1) * 32 + col]) k += step;
+            for (int t = k; t < m && srt_s[t * 32 + col] <= xh; ++t) pend = pend || item != tids[hist_s[t * 32 + col] >> 26];
         }
-        if (need) {
-            // the reference's sequential dot (PYX:320-334); eight products' operands requested at a time
-            float ex = __fadd_rn(urow[d], vT[(size_t)d * I + item]);
-#pragma unroll 1
-            for (int c0 = 0; c0 < d; c0 += 8) {
-                float uu[8], vv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c = min(c0 + q, d - 1);
-                    uu[q] = urow[c];
-                    vv[q] = vT[(size_t)c * I + item];
+        unsigned long long todo = __ballot(pend);
+        while (todo) {
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int usr = read_lane(user, L), itm = read_lane(item, L);
+            const float *ur = user_rep + (size_t)usr * rs;
+            float p0 = 0.0f, p1 = 0.0f;
+            if (lane < d) p0 = __fmul_rn(ur[lane], vT[(size_t)lane * I + itm]);
+            if (lane + WAVE < d) p1 = __fmul_rn(ur[lane + WAVE], vT[(size_t)(lane + WAVE) * I + itm]);
+            float ex = __fadd_rn(ur[d], vT[(size_t)d * I + itm]);
+            const int d0 = min(d, WAVE);
+            for (int c = 0; c < d0; ++c) ex = __fadd_rn(ex, read_lanef(p0, c));
+            for (int c = WAVE; c < d; ++c) ex = __fadd_rn(ex, read_lanef(p1, c - WAVE));
+            if (lane == L) {
+                for (int t = k; t < m && srt_s[t * 32 + col] <= xh; ++t) {
+                    const int slot = (int)(hist_s[t * 32 + col] >> 26);
+                    if (item != tids[slot] && ex >= srt_s[t * 32 + col]) atomicAdd(&ranks[slot], 1.0f);
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (c0 + q < d) ex = __fadd_rn(ex, __fmul_rn(uu[q], vv[q]));
-            }
-            for (int t = 0; t < m; ++t) {
-                const float th = srt_s[t * 32 + col];
-                const int slot = (int)(hist_s[t * 32 + col] >> 26);
-                if (!(xl > th) && th <= xh && item != tids[slot] && ex >= th) atomicAdd(&ranks[slot], 1.0f);
             }
         }
     }
@@ -675,6 +695,9 @@ void ranks_mfma3_kernel(RanksArgs a)
     const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
     const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
     const float INF = __int_as_float(0x7f800000);
+    // s - eps and s + eps are rounded: each by at most u |s| (1 + ...) <= eps / (4 (d + 2)), as eps >= kappa |s|; twice that
+    // is added to eps so that "x_lo > threshold" still implies "s - threshold > eps"
+    const float margin = 1.0f + 1.0f / (float)(2 * (d + 2));
     // the component-major item table and the bound terms as buffers (launch_ranks_mfma3 checks they are < 2 GB)
     const unsigned row2 = 8u * (unsigned)I;  // bytes of two table rows
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vT, 0, (int)(4u * (unsigned)I * (unsigned)a.item_rows), 0x00020000);
@@ -698,8 +721,8 @@ void ranks_mfma3_kernel(RanksArgs a)
         }
         n2 += __shfl_xor(n2, 32, WAVE);
         const float bu = uok ? urow[d] : 0.0f;
-        // the user-side terms of the bound, x 1.125: the margin for the roundings of s - eps and s + eps
-        const float nu2 = sqrtf(n2) * 1.0000005f * 1.125f, eu2 = kappa * fabsf(bu) * 1.125f;
+        // the user-side terms of the bound, with the margin for the roundings of s - eps and s + eps
+        const float nu2 = sqrtf(n2) * 1.0000005f * margin, eu2 = kappa * fabsf(bu) * margin;
         const int t_lo = uok ? a.test.indptr[user] : 0, t_hi = uok ? a.test.indptr[user + 1] : 0;
         const int m = max(0, min(MT, (t_hi - t_lo) - p0));
         const int32_t *tids = a.test.indices + t_lo + p0;
@@ -764,7 +787,7 @@ void ranks_mfma3_kernel(RanksArgs a)
         const float ub_x = half ? bu : 1.0f;
         for (int j0 = jb; j0 < je; j0 += 32) {
             const float av_x = half ? 1.0f : bj;
-            const float ejq = octet_max(ej) * 1.125f, njq = octet_max(njk);
+            const float ejq = octet_max(ej) * margin, njq = octet_max(njk);
             // items that do not count: train positives inside [j0, j0 + 32) (PYX:1303-1304), rows past the table
             unsigned tmask = j0 + 32 > I ? ~0u << (I - j0) : 0u;
             while (next < j0 + 32) {
@@ -784,7 +807,7 @@ void ranks_mfma3_kernel(RanksArgs a)
                 acc[r] = __int_as_float(off & (int)0xff800000);
             }
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
+            for (int kk = 0; kk < (LFM_R3X == 3 ? 1 : KSTEPS); ++kk)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], ub[kk], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_x, ub_x, acc, 0, 0, 0);
             // the MFMAs have read this tile's operands: request the next tile's now
@@ -793,6 +816,7 @@ void ranks_mfma3_kernel(RanksArgs a)
             if (levels == 5) band = count_tile<5>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
             else if (levels == 4) band = count_tile<4>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
             else band = count_tile<3>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
+            if (LFM_R3X) band = 0u;
             if (__ballot(band != 0u) != 0ull) {
                 if (half == 0) {
                     ej_s[col] = ejq;
@@ -801,7 +825,7 @@ void ranks_mfma3_kernel(RanksArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc_s[r * WAVE + lane] = acc[r];
                 wave_sync();
-                band_recheck3(band, lane, j0, m, nu2, eu2, urow, vT, I, d, sc_s, ej_s, nj_s, srt_s, hist_s, tids, ranks);
+                band_recheck3(band, lane, j0, m, nu2, eu2, user, a.user_rep, a.rs, vT, I, d, sc_s, ej_s, nj_s, srt_s, hist_s, tids, ranks);
                 wave_sync();
             }
         }

@@ -126,7 +126,10 @@ def test_predict_rank_known_answers(LightFM):
     dense = sp.csr_matrix(np.ones((nu, ni)))
     ranks = model.predict_rank(dense, num_threads=2).toarray()
     for row in range(nu):
-        assert np.array_equal(np.sort(ranks[row]), np.arange(ni))
+        # two items with EXACTLY the same float32 score share a (pessimistic) rank in the reference too: ~2.5 % of the
+        # unseeded ten-user models of this test have such a pair (tools/ranks_stress.py, profiles/r04_visit_p.txt)
+        if len(np.unique(model.predict(np.repeat(row, ni), np.arange(ni)))) == ni:
+            assert np.array_equal(np.sort(ranks[row]), np.arange(ni))
     assert np.all(model.predict_rank(dense, train_interactions=dense, check_intersections=False).toarray() == 0)
     ranks = model.predict_rank(dense, train_interactions=train, check_intersections=False).toarray()
     assert np.array_equal(ranks.max(axis=1), ni - 1 - np.asarray(train.getnnz(axis=1)).ravel())

@@ -29,6 +29,8 @@ from oracle import oracle, ref_suite
 # single-threaded fits compared bit for bit between two runs (test_movielens.py:655-666): only the
 # serial mode reproduces a run; everything else runs in the default parallel mode
 DETERMINISM = ("test_random_state_fixing",)
+# asserts that hold only without exact score ties, on unseeded models
+TIE_SENSITIVE = ("test_predict_ranks",)
 
 
 def _skip_unless_available():
@@ -36,6 +38,22 @@ def _skip_unless_available():
         pytest.skip("neither /root/reference nor oracle/_ref/pysuite is present")
     if not oracle.ref_available("strict"):
         pytest.skip("oracle/_ref/strict not built")
+
+
+def _retry_tie_sensitive(dst, backend, outcomes):
+    """The reference's predict_rank test asserts that a dense row's ranks are a permutation, on an UNSEEDED model: two
+    items with exactly equal float32 scores repeat a (pessimistic) rank.  2.5 % of such models have a pair like that
+    -- 76 rows in 3 000 models on the HIP backend, 77 in 3 000 with the reference's own extension
+    (profiles/r04_visit_p.txt).  One more model for that test before it counts as failed."""
+    retried, tail = {}, ""
+    for test_id, outcome in list(outcomes.items()):
+        if outcome == "FAILED" and any(t in test_id for t in TIE_SENSITIVE):
+            again, _, tail_again = ref_suite.run(dst, backend, files=("test_api",), select=" or ".join(TIE_SENSITIVE))
+            retried[test_id] = [outcome, again.get(test_id)]
+            if again.get(test_id) == "PASSED":
+                outcomes[test_id] = "PASSED"
+            tail += tail_again[-1500:]
+    return retried, tail
 
 
 def test_reference_suite_passes_on_the_reference_backend(tmp_path_factory):
@@ -46,8 +64,9 @@ def test_reference_suite_passes_on_the_reference_backend(tmp_path_factory):
     fast_mod, class_mod, _ = ref_suite.loaded_backend(dst, "reference")
     assert fast_mod.endswith("_lightfm_fast_openmp") and class_mod.endswith("_lightfm_fast_openmp")
     outcomes, rc, tail = ref_suite.run(dst, "reference")
+    retried, _ = _retry_tie_sensitive(dst, "reference", outcomes)
     bad = {k: v for k, v in outcomes.items() if v != "PASSED"}
-    assert rc == 0 and not bad, (bad, tail[-3000:])
+    assert (rc == 0 or retried) and not bad, (bad, tail[-3000:])
     assert len(outcomes) == 64, len(outcomes)
 
 
@@ -88,10 +107,14 @@ def test_reference_suite_on_the_hip_backend(tmp_path_factory):
     outcomes, rc, tail = ref_suite.run(dst, "hip", select=deselect)
     serial, rc2, tail2 = ref_suite.run(dst, "hip", files=("test_movielens",), mode="serial", select=" or ".join(DETERMINISM))
     outcomes.update(serial)
+    retried, tail_again = _retry_tie_sensitive(dst, "hip", outcomes)
+    if retried and all(v == "PASSED" for k, v in outcomes.items() if k not in serial):
+        rc = 0
+    tail += tail_again
     record = os.path.join(ref_suite.ROOT, "gpurun_out")
     if os.path.isdir(record):  # evidence for profiles/: which reference tests ran and how they ended
         with open(os.path.join(record, "reference_suite_on_hip.json"), "w") as f:
-            json.dump({"outcomes": outcomes, "tail": tail[-4000:], "tail_serial": tail2[-1500:]}, f, indent=1)
+            json.dump({"outcomes": outcomes, "retried": retried, "tail": tail[-4000:], "tail_serial": tail2[-1500:]}, f, indent=1)
     bad = {k: v for k, v in outcomes.items() if v != "PASSED"}
     assert not bad, (bad, tail[-5000:], tail2[-2000:])
     assert rc == 0 and rc2 == 0

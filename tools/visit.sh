@@ -595,6 +595,46 @@ for sub in ("pmc_a", "pmc_b"):
 PY
   find $OUT -name "*.db" -size +5M -delete
   ;;
+r4p)
+  # round 4: predict_ranks stress -- the default kernel against the scalar kernel on random small dense problems
+  timeout 600 python tools/ranks_stress.py ${1:-200} ${2:-0} > $OUT/stress.txt 2>&1
+  tail -40 $OUT/stress.txt | cut -c1-400
+  ;;
+r4q)
+  # round 4: where the bucket-search sweep's time goes -- exactness first, then timing-only variants of predict_kernels.hip
+  # (tools/build_variants.sh: x1 no bucket atomics, x2 no LDS search steps, x3 no matrix products, x9 no exact re-checks,
+  # lock = groups in step), then latency / wait counters of the shipped kernel
+  timeout -k 5 600 $PYT tests/test_evaluation_gpu.py tests/test_golden.py tests/test_lightfm_api.py "tests/test_baseline_shapes.py::test_predict_ranks_vs_oracle_at_ml20m_items" -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  timeout 300 python tools/ranks_stress.py 200 500 > $OUT/stress.txt 2>&1; grep -a "differ" $OUT/stress.txt | tail -3
+  for v in _lib _lib_x9 _lib_lock _lib_x1 _lib_x2 _lib_x3 $*; do
+    [ -f $R/lightfm_amd/$v/liblfm_hip.so ] || continue
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
+    echo "$v: $(grep -a 'mode 3' $OUT/t$v.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-110)"
+  done
+  [ -n "$SKIP_PMC" ] && exit 0
+  cd /tmp && export TMPDIR=/tmp
+  i=0
+  for set in "LdsLatency" "VmemLatency" "SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH SQ_INSTS_SMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i -o pmc -- python $R/tools/ranks_timing.py > $OUT/pmc_$i.txt 2> $OUT/pmc_$i.err
+  done
+  cd $R && python - <<PY
+import sqlite3, glob
+for i in (1, 2, 3, 4):
+    try:
+        db = glob.glob("$OUT/pmc_%d/**/*results.db" % i, recursive=True)[0]
+        con = sqlite3.connect(db)
+        rows = con.execute("select k.name, p.counter_name, count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id where k.name like '%ranks_mfma3%' group by k.name, p.counter_name").fetchall()
+        print("  pmc_%d:" % i, {c: round(v / n, 1) for _, c, n, v in rows}, "per launch")
+        if i == 4:
+            for r in con.execute("select name, count(*), avg(duration)/1e3 from kernels where name like '%ranks%' or name like '%test_scores%' or name like '%rep_rows%' or name like '%item_eps%' or name like '%rows_sorted%' group by name"):
+                print("  %-60s calls %3d avg %9.1f us" % (r[0][:60], r[1], r[2]))
+    except Exception as e:
+        print("pmc_%d:" % i, e)
+PY
+  find $OUT -name "*.db" -size +5M -delete
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
