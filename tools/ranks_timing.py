@@ -27,7 +27,7 @@ for mode in modes:
         pairs = float(n_eval) * data.shape[1]
         print("mode %s: precision_at_k over %d users x %d items (%d test interactions): wall %.2fs, kernels %.1f ms = %.1f G user-item "
               "scores/s (%.2f TFLOP/s of 2*d flops, %.3f of the 157.3 TFLOP/s fp32 matrix peak), p@10 %.4f" % (mode, n_eval, data.shape[1],
-              test_sub.nnz, dt, kms, pairs / kms / 1e6, 2 * 64 * pairs / kms / 1e9, 2 * 64 * pairs / kms / 1e9 / 157.3e3, p), flush=True)
+              test_sub.nnz, dt, kms, pairs / kms / 1e6, 2 * 64 * pairs / kms / 1e9, 2 * 64 * pairs / kms / 1e9 / 157.3, p), flush=True)
     seen[mode] = pk
 if len(seen) > 1:
     print("identical precision vectors across modes:", all(np.array_equal(seen[modes[0]], v) for v in seen.values()))
