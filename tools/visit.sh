@@ -635,6 +635,22 @@ for i in (1, 2, 3, 4):
 PY
   find $OUT -name "*.db" -size +5M -delete
   ;;
+r4s)
+  # round 4: predict_ranks at the other width classes (d = 128: two wavefronts per SIMD; d = 32), both sweeps
+  for D in 128 32; do
+    RANKS_TIMING_D=$D RANKS_TIMING_MODES=3,2 timeout 300 python tools/ranks_timing.py > $OUT/d$D.txt 2>&1
+    grep -a "mode\|identical" $OUT/d$D.txt | sed 's/precision_at_k over.*wall/wall/' | cut -c1-200
+  done
+  ;;
+r4t)
+  # round 4: the rocprofv3 --kernel-trace --stats summary of a predict_ranks call (tools/ranks_timing.py, d = 64, the default kernel and
+  # the compare-chain sweep in one process) as CSV, for profiles/
+  cd /tmp && export TMPDIR=/tmp
+  RANKS_TIMING_MODES=3,2 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ranks -- python $R/tools/ranks_timing.py > $OUT/ranks_trace.txt 2> $OUT/ranks_trace.err
+  cd $R; grep -a "mode\|identical" $OUT/ranks_trace.txt | sed 's/precision_at_k over.*wall/wall/' | cut -c1-200
+  f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/ranks_kernel_stats.csv && head -12 $OUT/ranks_kernel_stats.csv | cut -c1-200
+  find $OUT/trace -type f -size +2M -delete
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
