@@ -741,8 +741,8 @@ void ranks_mfma3_kernel(RanksArgs a)
         for (int t = half; t < m; t += 2) {
             const float v = sc_s[t * 32 + col];
             int rk = 0;
-#pragma unroll 1
-            for (int t2 = 0; t2 < m; ++t2) {
+#pragma unroll 8
+            for (int t2 = 0; t2 < ROWS; ++t2) {  // all rows (+inf beyond the lane's m: never smaller, never equal): eight reads in flight
                 const float o = sc_s[t2 * 32 + col];
                 rk += (o < v || (o == v && t2 < t)) ? 1 : 0;
             }

@@ -651,6 +651,17 @@ r4t)
   f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/ranks_kernel_stats.csv && head -12 $OUT/ranks_kernel_stats.csv | cut -c1-200
   find $OUT/trace -type f -size +2M -delete
   ;;
+r4u)
+  # round 4: predict_ranks -- exactness of the current build, then the segment count of the item table (no rebuild)
+  timeout -k 5 600 $PYT tests/test_evaluation_gpu.py "tests/test_baseline_shapes.py::test_predict_ranks_vs_oracle_at_ml20m_items" -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  timeout 300 python tools/ranks_stress.py 150 300 > $OUT/stress.txt 2>&1; grep -a "differ" $OUT/stress.txt | tail -3
+  for sg in ${*:-0}; do
+    if [ "$sg" = 0 ]; then unset LIGHTFM_AMD_RANKS_SEGMENTS; else export LIGHTFM_AMD_RANKS_SEGMENTS=$sg; fi
+    RANKS_TIMING_MODES=3 timeout 200 python tools/ranks_timing.py > $OUT/seg$sg.txt 2>&1
+    echo "segments $sg: $(grep -a 'mode 3' $OUT/seg$sg.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-150)"
+  done
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
