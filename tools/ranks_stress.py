@@ -19,6 +19,9 @@ for c in range(cases):
     if c % 3 == 0:  # tight scores: everything inside the rounding band
         m.item_embeddings *= 1e-3
     dense = sp.csr_matrix(np.ones((nu, ni), np.float32))
+    if c % 5 == 4:  # a sparse test matrix that INTERSECTS the train matrix (train positives among the test items)
+        dense = (sp.rand(nu, ni, density=0.3, format="csr", random_state=c) + train).tocsr()
+        dense.data[:] = 1.0
     tr = train if c % 2 else None
     out = {}
     for mode in ("3", "0"):
