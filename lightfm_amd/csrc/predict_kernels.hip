@@ -510,15 +510,15 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
 // sweep: it is bound by VALU issue, profiles/r04_visit_m.txt).  Here
 //   * a pass holds up to 31 test items of a user, sorted ascending in LDS ([rank][user column], +inf
 //     beyond; the two half-wave lanes of a user share the column);
-//   * per score: x_lo = s - eps, x_hi = s + eps, then log2(32) = 5 (4, 3 for light passes) dependent
-//     ds_read + v_cmp + v_cndmask + v_add steps give k = #{thresholds < x_lo} (the row offsets are
-//     instruction immediates), one more read the smallest threshold >= x_lo (in the rounding band iff it
-//     is <= x_hi), and one ds_add_u32 counts the score in bucket k.  Eight scores go through the steps
-//     side by side.  The count of the threshold of rank r is the sum of the buckets above r, taken once
-//     per work item;
+//   * per score: x_lo = s - eps, x_hi = s + eps, then log2(32) = 5 (4, 3 for light passes) search steps give
+//     k = #{thresholds < x_lo}: the first two against three thresholds held in registers, the others a
+//     ds_read_b32 (the row offset is an instruction immediate) + subtract + shift + v_and_or_b32 each -- the
+//     comparison is the sign of (threshold - x_lo).  One more read returns the smallest threshold >= x_lo (in
+//     the rounding band iff it is <= x_hi), one ds_add_u32 counts the score in bucket k.  The count of the
+//     threshold of rank r is the sum of the buckets above r, taken once per work item;
 //   * eps of a score is the bound of ITS octet of items (max over 8 items, x (1 + 1 / (2 (d + 2))) for the roundings
 //     of s -/+ eps): one instruction per score instead of eight; the band is re-decided with the reference's
-//     sequential dot as before (PYX:1317-1319), so the ranks are the reference's integers;
+//     sequential dot (PYX:1317-1319), computed by the whole wavefront, so the ranks are the reference's integers;
 //   * a work item = (32-user tile, pass, segment of the item table): partial counts are integers < 2^24
 //     published with float atomics (exact), segments are dispatched segment-major so that the wavefronts
 //     resident at one time walk the same ~1 MB of the table.
