@@ -50,6 +50,8 @@ struct RanksArgs {
                             // ranks_mfma3_kernel: [n_work][4] (tile, first test item, first item, end item of the segment)
     int32_t n_work;
     int32_t item_rows;      // ranks_mfma3_kernel: rows of item_rep (it reads the table through a buffer descriptor)
+    const float *item_rows_rm;  // optional [n_items][rs] row-major item representations (bias at [d]): test_scores_kernel reads
+                                // two contiguous rows per test interaction instead of d + 1 lines of the component-major table
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)

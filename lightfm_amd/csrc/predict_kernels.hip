@@ -345,7 +345,25 @@ __global__ void test_scores_kernel(RanksArgs a)
         const int mid = (lo + hi) >> 1;
         if ((int64_t)a.test.indptr[mid] <= t) lo = mid; else hi = mid;
     }
-    a.test_scores[t] = dense_dot(a.user_rep + (size_t)lo * a.rs, a.item_rep, (size_t)a.test.cols, a.test.indices[t], a.d);
+    const float *u = a.user_rep + (size_t)lo * a.rs;
+    if (a.item_rows_rm == nullptr) {
+        a.test_scores[t] = dense_dot(u, a.item_rep, (size_t)a.test.cols, a.test.indices[t], a.d);
+        return;
+    }
+    // the same operations in the same order (PYX:320-334) from two contiguous rows (rs is a multiple of four floats)
+    const float *v = a.item_rows_rm + (size_t)a.test.indices[t] * a.rs;
+    const int d = a.d;
+    float acc = __fadd_rn(u[d], v[d]);
+    int c = 0;
+    for (; c + 4 <= d; c += 4) {
+        const float4 x = *(const float4 *)(u + c), y = *(const float4 *)(v + c);
+        acc = __fadd_rn(acc, __fmul_rn(x.x, y.x));
+        acc = __fadd_rn(acc, __fmul_rn(x.y, y.y));
+        acc = __fadd_rn(acc, __fmul_rn(x.z, y.z));
+        acc = __fadd_rn(acc, __fmul_rn(x.w, y.w));
+    }
+    for (; c < d; ++c) acc = __fadd_rn(acc, __fmul_rn(u[c], v[c]));
+    a.test_scores[t] = acc;
 }
 
 template <int KSTEPS>

@@ -653,7 +653,7 @@ r4t)
   ;;
 r4u)
   # round 4: predict_ranks -- exactness of the current build, then the segment count of the item table (no rebuild)
-  timeout -k 5 600 $PYT tests/test_evaluation_gpu.py "tests/test_baseline_shapes.py::test_predict_ranks_vs_oracle_at_ml20m_items" -m gpu -q -x > $OUT/tests.log 2>&1
+  timeout -k 5 600 $PYT tests/test_evaluation_gpu.py tests/test_golden.py "tests/test_baseline_shapes.py::test_predict_ranks_vs_oracle_at_ml20m_items" -m gpu -q -x > $OUT/tests.log 2>&1
   echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
   timeout 300 python tools/ranks_stress.py 150 300 > $OUT/stress.txt 2>&1; grep -a "differ" $OUT/stress.txt | tail -3
   for sg in ${*:-0}; do
