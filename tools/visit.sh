@@ -662,6 +662,12 @@ r4u)
     echo "segments $sg: $(grep -a 'mode 3' $OUT/seg$sg.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-150)"
   done
   ;;
+r4v)
+  # round 4: the callers of predict_ranks outside tests/test_evaluation_gpu.py on the final tree
+  timeout -k 5 600 $PYT tests/test_lightfm_api.py tests/test_reference_suite.py tests/test_abi.py -m gpu -q -x > $OUT/tests.log 2>&1
+  echo "tests: exit $?  $(grep -aE ' passed| failed' $OUT/tests.log | tail -1)"; summ $OUT/tests.log 12
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  ;;
 emu)
   # tools/visit.sh emu <shape> <epochs> <seeds> CONFIG...   (tools/multi_gpu_emulation.py on one GPU)
   SH=$1; EP=$2; SD=$3; shift 3
