@@ -103,6 +103,8 @@ def _record(o, logs):
     options.last_kernel_used = int(o.kernel_used)
     options.last_launches = int(o.launches)
     options.last_streams_used = int(o.streams_used)
+    options.last_tile_ng = int(o.tile_ng)
+    options.last_tile_ahead = int(o.tile_ahead)
     options.last_phase_cycles = list(o.phase_cycles)
     options.last_logs = logs
 

@@ -65,6 +65,8 @@ class _Options(object):
         self.last_kernel_used = None  # 0 generic kernels, 1 lane-group tile kernel, 2 row-stream kernels
         self.last_launches = None
         self.last_streams_used = None
+        self.last_tile_ng = None     # interactions per wavefront pass of the tile kernel (4, 2, 1), 0 = another kernel ran
+        self.last_tile_ahead = None  # 1 = the steady-state (gather-ahead) tile kernel ran the last launch
         self.last_phase_cycles = None
         self.last_logs = None
 

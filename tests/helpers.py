@@ -89,3 +89,24 @@ def assert_states_equal(a, b, exact=True, rtol=1e-4, atol=1e-7):
             assert np.array_equal(x, y), "%s differs: max abs %g" % (n, np.abs(x - y).max())
         else:
             np.testing.assert_allclose(x, y, rtol=rtol, atol=atol, err_msg=n)
+
+
+def assert_states_within_ulps(a, b, ulps=1, min_exact=0.5):
+    """The bar for updates published as old + float32(new - old) (global_atomic_add_f32): the sum
+    reproduces `new` wherever the subtraction is exact (Sterbenz: new / 2 <= old <= 2 new) and is
+    within one float32 ulp of the larger of the two elsewhere -- an ABSOLUTE error that later updates
+    of the cell carry along even when its value shrinks.  So: every cell within `ulps` ulps of the
+    array's largest magnitude, and at least `min_exact` of the cells of every array bit-identical."""
+    from oracle.oracle import ARRAYS
+    for n in ARRAYS:
+        x, y = getattr(a, n), getattr(b, n)
+        assert x.shape == y.shape, n
+        if not x.size:
+            continue
+        top = np.float32(max(np.abs(x).max(), np.abs(y).max()))
+        tol = ulps * float(np.spacing(top))
+        err = np.abs(x.astype(np.float64) - y.astype(np.float64))
+        print("within_ulps %-28s max err %.2f ulp of %g, bit-identical %.4f" % (n, err.max() / float(np.spacing(top)), top, np.mean(x == y)))
+        assert err.max() <= tol, "%s: %d cells beyond %d ulp of %g, max abs %g" % (
+            n, int((err > tol).sum()), ulps, top, err.max())
+        assert np.mean(x == y) >= min_exact, "%s: only %.3f of the cells bit-identical" % (n, np.mean(x == y))

@@ -12,7 +12,13 @@ stream per shuffled position -- the rule both sides share):
     sequential, and weights, biases and accumulators must be BIT-EXACT;
   * four concurrent interactions per launch that share no row (checked in numpy from
     the shared PRNG rule): BIT-EXACT as well -- every lane group's update path;
-  * the generic one-interaction-per-wavefront kernel gives the same logs.
+  * the generic one-interaction-per-wavefront kernel gives the same logs;
+  * the SHIPPED steady-state kernel (warp_tile_ahead.hpp; atomic publication, `tile_ahead == 1`
+    asserted): conflict-free launches of one pass of one wavefront (four lane groups updating at
+    once) and of two passes of four wavefronts (the gather of pass t + 1 issued before pass t
+    publishes), and a sequential run over dense positives rows in which the first violator is
+    regularly one of the user's positives, so that the re-read branch performs non-zero updates
+    -- states within one float32 ulp of the oracle's, bit-identical where new - old is exact.
 """
 import numpy as np
 import pytest
@@ -210,6 +216,88 @@ def test_concurrent_disjoint_groups_bit_exact(fast, d, group, variant):
     assert np.array_equal(neg, o.neg)
     assert o.counters[2] > n // 4
     H.assert_states_equal(a, b, exact=True)
+
+
+def _conflict_free(nu, ni, n, per_launch, ms, rng, attempts=200):
+    """n interactions with distinct users and positives such that no launch of `per_launch` consecutive shuffled
+    positions reads or writes an item row another interaction of the launch writes."""
+    for _ in range(attempts):
+        users = rng.permutation(nu)[:n].astype(np.int32)
+        items = rng.permutation(ni)[:n].astype(np.int32)
+        coo = sp.coo_matrix((np.ones(n, np.float32), (users, items)), shape=(nu, ni), dtype=np.float32)
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        cands = _candidates(seeds[0], np.arange(n), ms, ni)
+        ok = True
+        for l0 in range(0, n, per_launch):
+            rows = [set(cands[j].tolist()) | {int(coo.col[shuffle[j]])} for j in range(l0, min(n, l0 + per_launch))]
+            if len(set().union(*rows)) != sum(len(r) for r in rows):
+                ok = False
+                break
+        if ok:
+            return coo, shuffle, seeds
+    raise AssertionError("no conflict-free arrangement found")
+
+
+@pytest.mark.parametrize("per_launch", [4, 32], ids=["one-pass", "four-waves-two-passes"])
+def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch):
+    """The kernel bench.py's headline runs on (fit_warp_tile_ahead_kernel: update_mode 0, debug 0 apart from the forced
+    lane-group width the session picks at full residency anyway), with NON-ZERO updates under concurrency: four lane
+    groups of a wavefront update in the same pass (speculative cU / cP / cN copies, the four-at-once bias cells);
+    with 32 positions per launch four wavefronts run two passes each, the second pass's rows requested before the
+    first publishes.  No two interactions of a launch share a row, so the result is the sequential oracle's."""
+    from lightfm_amd.options import options
+    d, ms = 64, 10
+    nu, ni, n = (400, 40000, 160) if per_launch == 4 else (800, 300000, 256)
+    coo, shuffle, seeds = _conflict_free(nu, ni, n, per_launch, ms, np.random.RandomState(23))
+    st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
+    _spread(st)
+    st.item_biases[:] = np.random.RandomState(3).randn(ni).astype(np.float32) * 0.3
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=n // per_launch, update_mode=0, debug=4, max_waves=16)
+    _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+    assert options.last_tile_ahead == 1 and options.last_tile_ng == 4, "the steady-state tile kernel did not run"
+    o = _orc_warp(coo, b, shuffle, seeds, coo.data)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled)
+    assert np.array_equal(neg, o.neg)
+    assert options.last_counters == o.counters
+    assert o.counters[2] > n // 4
+    assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    H.assert_states_within_ulps(a, b, ulps=4)
+
+
+def test_tile_ahead_reread_branch_updates_match_the_oracle(fast):
+    """Dense positives rows (a third of the catalogue per user) and near-zero scores: nearly every candidate violates
+    the margin, so the FIRST violator is one of the user's positives in about a third of the interactions; the choice
+    is then a later violator whose row the steady-state kernel re-reads from the table (warp_tile_ahead.hpp, `only_neg`)
+    instead of using its speculative copy.  One interaction per launch (sequential): states within an ulp of the
+    oracle's after two epochs.  That the branch ran is read off the counters: every position found a negative, so
+    each in_positives probe that hit (probes - updates) belongs to a position whose first violator was a positive."""
+    from lightfm_amd.options import options
+    nu, ni, d, ms = 24, 60, 64, 10
+    rng = np.random.RandomState(8)
+    dense = rng.rand(nu, ni) < 0.33
+    dense[:, 0] = True
+    coo = sp.coo_matrix(dense.astype(np.float32))
+    coo = sp.coo_matrix((coo.data.astype(np.float32), (coo.row.astype(np.int32), coo.col.astype(np.int32))),
+                        shape=(nu, ni), dtype=np.float32)
+    st = oracle.State(ni, nu, d, rng, max_sampled=ms)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=len(coo.data), update_mode=0, debug=4)
+    reread = 0
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+        assert options.last_tile_ahead == 1 and options.last_tile_ng == 4
+        o = _orc_warp(coo, b, shuffle, seeds, coo.data)
+        neg, sampled = options.last_logs
+        assert np.array_equal(sampled, o.sampled)
+        assert np.array_equal(neg, o.neg)
+        assert options.last_counters == o.counters
+        if (o.neg >= 0).all():  # positives visited, draws, updates, probes
+            reread += o.counters[3] - o.counters[2]
+    assert reread > len(coo.data) // 8, "the first violator was rarely a positive: the re-read branch is not exercised"
+    H.assert_states_within_ulps(a, b, ulps=4, min_exact=0.1)  # (every cell is updated dozens of times here)
 
 
 def test_tile_training_learns_like_the_oracle(fast):

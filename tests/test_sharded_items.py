@@ -24,14 +24,14 @@ POISON = np.float32(1e30)
 K = 4
 
 
-def _setup(frozen):
+def _setup(frozen, nu=2000, ni=3001, nnz=90000):
     from lightfm_amd import _native
     from lightfm_amd._lightfm_fast import CSRMatrix, FastLightFM
     from lightfm_amd.distributed import local_shard
     from lightfm_amd.lightfm import _Session
     assert _native.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
-    nu, ni, d = 2000, 3001, 64  # 3001 items over 4 owners: 751, 751, 751, 748 rows
-    coo = H.make_interactions(nu, ni, 90000, seed=31, zipf=0.7)
+    d = 64  # 3001 items over 4 owners: 751, 751, 751, 748 rows
+    coo = H.make_interactions(nu, ni, nnz, seed=31, zipf=0.7)
     rng = np.random.RandomState(13)
     st = oracle.State(ni, nu, d, rng, max_sampled=10)
     a = 3.0 / d ** 0.25
@@ -102,6 +102,62 @@ def test_frozen_weights_samples_exact_over_sharded_item_tables():
             assert o.counters[2] > n // 4
     finally:
         _close(sessions)
+
+
+def test_sharded_updates_match_the_unsharded_oracle():
+    """NON-ZERO updates through the SHARDED instantiation of the steady-state tile kernel: the K sessions run one
+    after the other, one interaction per launch (sequential), two epochs; the model assembled from the owners' rows
+    and the sessions' user rows equals the oracle's on the TRUE unsharded model run over the same shards in the same
+    order -- within one float32 ulp (publication is old + float32(new - old)), bit-identical where that is exact."""
+    from lightfm_amd._lightfm_fast import make_opts
+    from lightfm_amd.options import options
+    coo, st, sessions, parts, (nu, ni, d) = _setup(frozen=False, nu=240, ni=3001, nnz=1500)
+    ref = st.copy()
+    try:
+        rng = np.random.RandomState(77)
+        for epoch in range(2):
+            for j, (s, pt) in enumerate(zip(sessions, parts)):
+                shard = pt["shard"]
+                n = shard.nnz
+                shuffle = np.arange(n, dtype=np.int32)
+                rng.shuffle(shuffle)
+                seeds = rng.randint(0, np.iinfo(np.int32).max, size=1).astype(np.uint32)
+                s.upload_shuffle(shuffle)
+                options.set(mode="parallel", launches_per_epoch=n, update_mode=0, debug=0)
+                opts, logs = make_opts(n, want_log=True)
+                s.epoch("warp", 0.0, 0.0, 5, 10, seeds, opts)
+                assert opts.kernel_used == 1 and opts.tile_ng == 4 and opts.tile_ahead == 1 and opts.launches == n
+                # the oracle: the same shard against the global item tables and this session's slice of the user tables
+                b0, b1 = pt["range"]
+                view = object.__new__(oracle.State)
+                view.__dict__.update(ref.__dict__)
+                for name in oracle.ARRAYS:
+                    if name.startswith("user"):
+                        setattr(view, name, getattr(ref, name)[b0:b1])
+                o = oracle.Opts(n, rng_mode=1, log=True)
+                oracle.fit_warp(H.identity_features(ni), H.identity_features(b1 - b0), H.positives_csr(shard), shard.row,
+                                shard.col, shard.data, shard.data, shuffle, view, 0.0, 0.0, seeds, o)
+                neg, sampled = logs
+                assert np.array_equal(sampled, o.sampled), "epoch %d session %d: sample counts differ" % (epoch, j)
+                assert np.array_equal(neg, o.neg), "epoch %d session %d: negatives differ" % (epoch, j)
+                assert list(opts.counters) == o.counters
+        final = st.copy()
+        for j, (s, pt) in enumerate(zip(sessions, parts)):
+            s.sync_to_host(pt["struct"])
+            mine, own = pt["state"], pt["own"]
+            b0, b1 = pt["range"]
+            for name in ("item_embeddings", "item_embedding_gradients", "item_biases", "item_bias_gradients"):
+                arr = getattr(mine, name)
+                assert np.all(arr[~own] == POISON), "session %d wrote %s rows it does not own" % (j, name)
+                getattr(final, name)[own] = arr[own]
+            for name in oracle.ARRAYS:
+                if name.startswith("user"):
+                    getattr(final, name)[b0:b1] = getattr(mine, name)
+    finally:
+        _close(sessions)
+    assert not np.array_equal(final.item_embeddings, st.item_embeddings)
+    assert not np.array_equal(final.item_biases, st.item_biases)
+    H.assert_states_within_ulps(final, ref, ulps=4)
 
 
 def test_training_writes_only_the_owners_rows():
