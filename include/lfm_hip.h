@@ -309,10 +309,17 @@ int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode);
  * b, bG, all-reduced on the session's communication stream.  overlap != 0: the call returns once the exchange is enqueued; the next
  * segment trains while it runs, and its result is applied at the start of the next merge call or by
  * lfm_session_comm_merge_flush (call it before reading the tables: check_finite, sync_to_host, the end of
- * an epoch).  *bytes (may be NULL) = what this rank handed to RCCL.  Adagrad models only (LFM_EUNSUPPORTED
- * for adadelta: use lfm_session_comm_merge).  Same modes and the same arithmetic as the dense merge. */
+ * an epoch).  *bytes (may be NULL) = what this rank handed to RCCL.  Same modes and the same arithmetic as the dense merge
+ * (adadelta models carry their momentum tables too; LFM_MERGE_ADAGRAD means LFM_MERGE_MEAN for them, as there).
+ * Per side and merge the packed deltas of all kinds are ONE buffer: one pack launch, one all-reduce (two in
+ * LFM_MERGE_ADAGRAD mode: accumulators, then the rescaled embedding deltas), one apply launch.  Once a merge's union has
+ * covered >= 90 % of a side's rows (lfm_session_set_merge_dense_fraction) the following merges of that side skip the
+ * detection, the all-reduce of the byte maps and the compaction and carry every row: bit-identical (an untouched row's
+ * deltas are zeros), and what a small, fully touched table (ML-20M's 26 744 item rows) costs is then three to five
+ * launches instead of sixteen and a host round trip. */
 int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes);
 int lfm_session_comm_merge_flush(lfm_session *s);
+int lfm_session_set_merge_dense_fraction(lfm_session *s, float fraction);
 /* HOT rows: feature rows that many interactions of every rank update (the tag / genre rows of a hybrid model:
  * 16 of the 19 rows an interaction of BASELINE config C3 touches are among its 1 128 tag rows) tolerate far
  * shorter merge intervals than rows one interaction in thousands touches (measured on one GPU with 8 emulated
@@ -349,6 +356,29 @@ int lfm_sessions_merge_local_hot(lfm_session **sessions, int32_t k, int32_t side
  * adagrad, no regularisation, d <= 64, max_sampled = 10 (the steady-state tile kernel); lfm_session_epoch fails
  * with LFM_EUNSUPPORTED otherwise. */
 int lfm_sessions_share_items_local(lfm_session **sessions, int32_t k);
+
+/* ... and the multi-PROCESS form (one process per GPU; several processes may also share one GPU): every process
+ * exports the HIP IPC handles of its four item-side allocations (W, G, b, bG), the K exports travel over the job's
+ * rendezvous (lightfm_amd/distributed.py hands them round with torch.distributed / gloo, like the RCCL unique id),
+ * and lfm_session_share_items_ipc maps the other owners' allocations into this process (hipIpcOpenMemHandle: the
+ * same memory on one GPU, peer mappings over xGMI across the GPUs of a node) and wires the session's kernels to
+ * them exactly as lfm_sessions_share_items_local does.  all[my_rank] must be this process's own export.  The
+ * mappings are closed by lfm_session_destroy; every process keeps its session alive until all have finished
+ * training (a barrier of the rendezvous).  A sharded session's lfm_session_check_finite answers for the rows it
+ * owns; lfm_session_gather_shared_items copies the other owners' rows into the session's own tables (device to
+ * device) so that lfm_session_sync_to_host returns the whole model -- call it on every process between two
+ * barriers, after the last epoch.  At least two item rows per owner; same kernel scope as the local form. */
+#define LFM_IPC_HANDLE_BYTES 64
+typedef struct lfm_item_export {
+    char handle[4][LFM_IPC_HANDLE_BYTES]; /* hipIpcMemHandle_t of the allocations holding W, G, b, bG */
+    int64_t offset[4];                    /* of the table inside its allocation (0 with the library's pool) */
+    int64_t bytes[4];
+    int32_t n_items, d, device, reserved;
+    int64_t pid;
+} lfm_item_export;
+int lfm_session_export_items(lfm_session *s, lfm_item_export *out);
+int lfm_session_share_items_ipc(lfm_session *s, const lfm_item_export *all, int32_t k, int32_t my_rank);
+int lfm_session_gather_shared_items(lfm_session *s);
 
 #ifdef __cplusplus
 }

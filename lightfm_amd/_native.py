@@ -55,6 +55,13 @@ class LfmOpts(C.Structure):
                 ("streams_used", C.c_int32), ("tile_ahead", C.c_int32)]
 
 
+class LfmItemExport(C.Structure):
+    """include/lfm_hip.h: lfm_item_export -- the HIP IPC handles of a session's item-side allocations."""
+    _fields_ = [("handle", (C.c_char * 64) * 4), ("offset", C.c_int64 * 4), ("bytes", C.c_int64 * 4),
+                ("n_items", C.c_int32), ("d", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("pid", C.c_int64)]
+
+
 # every symbol include/lfm_hip.h declares (tests check the .so exports them all)
 EXPORTS = (
     "lfm_last_error", "lfm_last_kernel_ms", "lfm_device_count", "lfm_device_info",
@@ -67,11 +74,12 @@ EXPORTS = (
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
     "lfm_device_trim", "lfm_device_pool_stats",
-    "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush",
+    "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush", "lfm_session_set_merge_dense_fraction",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
     "lfm_session_comm_any", "lfm_session_comm_barrier", "lfm_sessions_merge_local",
     "lfm_sessions_share_items_local",
+    "lfm_session_export_items", "lfm_session_share_items_ipc", "lfm_session_gather_shared_items",
 )
 MERGE_SUM, MERGE_MEAN, MERGE_ADAGRAD = 0, 1, 2
 MERGE_MODES = {"sum": MERGE_SUM, "mean": MERGE_MEAN, "adagrad": MERGE_ADAGRAD}

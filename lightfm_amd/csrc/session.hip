@@ -9,7 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -368,7 +370,13 @@ struct lfm_session {
     hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
-    ItemShards shards = {};  // owner-sharded item tables (lfm_sessions_share_items_local); n = 0: this session's own tables
+    ItemShards shards = {};  // owner-sharded item tables (lfm_sessions_share_items_local / _ipc); n = 0: this session's own tables
+    // Lifetime of a sharing: the members of a one-process group hold one ShareGroup; a member that is destroyed (or whose
+    // tables are re-uploaded) marks it broken and the others' epochs then fail instead of addressing freed memory.
+    struct ShareGroup { bool broken = false; };
+    std::shared_ptr<ShareGroup> share;
+    int share_rank = -1, share_k = 0;       // this session's range of the sharded item rows
+    std::vector<void *> ipc_mappings;       // lfm_session_share_items_ipc: the peers' allocations mapped into this process
     DBuf<uint32_t> bloom;  // Bloom filter over the rows of `pos` (device.hpp: Bloom), built with the lookup
     bool bloom_valid = false;
     bool recs_valid = false;
@@ -391,12 +399,18 @@ struct lfm_session {
     struct PendingMerge {
         bool active = false, on_comm_stream = false;
         int sides = 0;
-        float wscale = 1.0f;
+        float wscale = 1.0f, ascale = 1.0f;  // what the summed deltas of the weights / of the accumulators are scaled by
         int64_t n_u[2] = {0, 0};
-        DBuf<int32_t> ids[2];     // the union of touched rows, ascending
-        DBuf<float> sum[2][4];    // packed deltas of W, G, b, bG: this rank's, then the sum over ranks
-        DBuf<float> loc[2][4];    // this rank's own packed deltas (unscaled)
+        DBuf<int32_t> ids[2];     // the union of touched rows, ascending (unused when the merge covers every row)
+        bool all_rows[2] = {false, false};  // this merge covers every row of the side: no id list
+        DBuf<float> sum[2];       // packed deltas of all kinds, one buffer (session.hip: FusedPlan): this rank's, then the sum over ranks
+        DBuf<float> loc[2];       // this rank's own packed deltas (unscaled)
     } pend;
+    // A merge whose union covered >= merge_dense_frac of a side's rows makes the NEXT merges of that side skip the detection,
+    // the OR-all-reduce of the byte maps and the compaction: every row travels (bit-identical result: an untouched row's
+    // deltas are zeros).  The union is the same on every rank, so every rank takes the same path.
+    bool merge_all_rows[2] = {false, false};
+    float merge_dense_frac = 0.9f;
 
     // LIGHTFM_AMD_VALIDATE=1 (debugging): checksums of the read-only device inputs at the end of the
     // previous epoch, by (address, bytes): see validate_inputs()
@@ -409,6 +423,8 @@ struct lfm_session {
     {
         // the buffers go back to the pool without any implicit synchronisation (hipFree had one)
         if (stream) (void)hipStreamSynchronize(stream);
+        if (share) share->broken = true;  // the other members must not train against this session's tables any more
+        for (void *m : ipc_mappings) (void)hipIpcCloseMemHandle(m);
         for (auto *s : shuffles) delete s;
         if (stream2) {
             (void)hipStreamSynchronize(stream2);
@@ -849,7 +865,7 @@ extern "C" int lfm_session_merge_begin(lfm_session *s, int32_t sides)
     for (int side = 0; side < 2; ++side)
         if ((sides >> side) & 1) {
             LFM_TRY(snapshot_side(s, side));
-            if (!s->adadelta) LFM_TRY(s->dirty[side].alloc((size_t)s->n_feat[side]));
+            LFM_TRY(s->dirty[side].alloc((size_t)s->n_feat[side]));
         }
     if (!s->comm_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
@@ -975,58 +991,89 @@ static int merge_group(lfm_session **ss, int k, int nranks_total, int sides, int
 // the local table gained between pack and apply stays in (table - snapshot) for the next merge.
 // flags[r] = 1 if row r of (W, G) or its (b, bG) cell differs from the snapshot; one wavefront per row
 __global__ void detect_dirty_kernel(const float *W, const float *sW, const float *G, const float *sG, const float *b, const float *sb,
-                                    const float *bG, const float *sbG, int64_t rows, int d, unsigned char *flags)
+                                    const float *bG, const float *sbG, const float *M, const float *sM, const float *bM,
+                                    const float *sbM, int64_t rows, int d, unsigned char *flags)
 {
     const int lane = threadIdx.x & 63;
     const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = w0; r < rows; r += nw) {
         bool diff = false;
         const size_t base = (size_t)r * d;
-        for (int c = lane; c < d; c += 64) diff |= (W[base + c] != sW[base + c]) | (G[base + c] != sG[base + c]);
-        if (lane == 0) diff |= (b[r] != sb[r]) | (bG[r] != sbG[r]);
+        for (int c = lane; c < d; c += 64) {
+            diff |= (W[base + c] != sW[base + c]) | (G[base + c] != sG[base + c]);
+            if (M) diff |= M[base + c] != sM[base + c];  // adadelta: the momentum tables travel too
+        }
+        if (lane == 0) {
+            diff |= (b[r] != sb[r]) | (bG[r] != sbG[r]);
+            if (bM) diff |= bM[r] != sbM[r];
+        }
         const unsigned long long any = __ballot(diff);
         if (lane == 0) flags[r] = any ? 1 : 0;
     }
 }
-__global__ void pack_delta_kernel(const float *tab, const float *snap, const int32_t *ids, int64_t n_u, int d, float *loc, float *sum)
+// ---- steps 3-5 on ONE buffer per side.  The packed deltas of all kinds of a side live in one allocation, kind after
+// kind: adagrad [G | bG | W | b], adadelta [G | bG | M | bM | W | b] (accumulators first: LFM_MERGE_ADAGRAD reduces them
+// before the weights), each kind n_u rows of w = d or 1 floats.  One pack, one (two) all-reduce(s), one apply per side
+// and merge -- the merge of a small table (ML-20M's 26 744 item rows: 14 MB) is bound by its launches, not its bytes.
+struct FusedSeg { float *tab, *snap; int64_t off; int w; float scale; };
+struct FusedPlan {
+    FusedSeg seg[6];
+    int nseg;
+    int64_t total, n_u;
+    const int32_t *ids;  // nullptr: every row (u is the row)
+    __device__ __forceinline__ int find(int64_t j) const
+    {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < 6; ++t)
+            if (t < nseg && j >= seg[t].off) q = t;
+        return q;
+    }
+};
+__global__ void pack_fused_kernel(FusedPlan p, float *loc, float *sum)
 {
-    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t0; j < total; j += st) {
-        const int64_t u = j / d;
-        const int c = (int)(j - u * d);
-        const size_t at = (size_t)ids[u] * d + c;
-        const float v = tab[at] - snap[at];
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t0; j < p.total; j += st) {
+        const FusedSeg &g = p.seg[p.find(j)];
+        const int64_t r = j - g.off, u = r / g.w;
+        const int c = (int)(r - u * g.w);
+        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * g.w + c;
+        const float v = g.tab[at] - g.snap[at];
         loc[j] = v;
         sum[j] = v;
     }
 }
-// LFM_MERGE_ADAGRAD on packed rows: dW *= sqrt((G0 + dG_rank / 2) / (G0 + dG_all / 2)), G0 from the snapshot
-__global__ void rescale_packed_kernel(float *dW, const float *snapG, const int32_t *ids, const float *dg_rank, const float *dg_all,
-                                      int64_t n_u, int d)
+// LFM_MERGE_ADAGRAD: dW *= sqrt((G0 + dG_rank / 2) / (G0 + dG_all / 2)), G0 from the snapshot; the accumulator segments
+// (G at seg[0], bG at seg[1]) have been reduced, the weight segments (W = seg[nseg - 2], b = seg[nseg - 1]) not yet
+__global__ void rescale_fused_kernel(FusedPlan p, float *sum, const float *loc)
 {
-    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t0; j < total; j += st) {
-        const int64_t u = j / d;
-        const int c = (int)(j - u * d);
-        const float g0 = snapG[(size_t)ids[u] * d + c];
-        const float num = g0 + 0.5f * dg_rank[j], den = g0 + 0.5f * dg_all[j];
-        if (den > 0.0f && num >= 0.0f && den > num) dW[j] *= sqrtf(num / den);
+    const int64_t w0 = p.seg[p.nseg - 2].off, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = w0 + t0; j < p.total; j += st) {
+        const int q = j >= p.seg[p.nseg - 1].off ? 1 : 0;  // 0: W against G, 1: b against bG
+        const FusedSeg &gw = p.seg[p.nseg - 2 + q], &ga = p.seg[q];
+        const int64_t r = j - gw.off, u = r / gw.w;
+        const int c = (int)(r - u * gw.w);
+        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * gw.w + c;
+        const float g0 = ga.snap[at];
+        const int64_t ja = ga.off + r;
+        const float num = g0 + 0.5f * loc[ja], den = g0 + 0.5f * sum[ja];
+        if (den > 0.0f && num >= 0.0f && den > num) sum[j] *= sqrtf(num / den);
     }
 }
 // table += scale * sum - local ; snapshot += scale * sum   (rows of U).  exact: nothing trained since the pack
 // (synchronous merge): table := snapshot := snapshot + scale * sum, bit-identical on every rank.
-__global__ void apply_packed_kernel(float *tab, float *snap, const int32_t *ids, const float *sum, const float *loc, float scale,
-                                    int64_t n_u, int d, int exact)
+__global__ void apply_fused_kernel(FusedPlan p, const float *sum, const float *loc, int exact)
 {
-    const int64_t total = n_u * d, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t0; j < total; j += st) {
-        const int64_t u = j / d;
-        const int c = (int)(j - u * d);
-        const size_t at = (size_t)ids[u] * d + c;
-        const float s = sum[j] * scale;
-        const float v = snap[at] + s;
-        tab[at] = exact ? v : tab[at] + (s - loc[j]);
-        snap[at] = v;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = t0; j < p.total; j += st) {
+        const FusedSeg &g = p.seg[p.find(j)];
+        const int64_t r = j - g.off, u = r / g.w;
+        const int c = (int)(r - u * g.w);
+        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * g.w + c;
+        const float sv = sum[j] * g.scale;
+        const float v = g.snap[at] + sv;
+        g.tab[at] = exact ? v : g.tab[at] + (sv - loc[j]);
+        g.snap[at] = v;
     }
 }
 struct BytePack { unsigned char *p[16]; };
@@ -1040,7 +1087,27 @@ __global__ void local_or_kernel(BytePack xs, int k, int64_t n)
     }
 }
 
-static const int SPARSE_KINDS[4] = {0, 1, 3, 4};  // W, G, b, bG (adagrad models)
+// the kinds a sparse merge carries, in the fused buffer's order (accumulators first), and the plan of a side
+static FusedPlan fused_plan(lfm_session *s, int side, int64_t n_u, const int32_t *ids, float wscale, float ascale)
+{
+    static const int ADAGRAD_KINDS[4] = {1, 4, 0, 3};        // G, bG, W, b
+    static const int ADADELTA_KINDS[6] = {1, 4, 2, 5, 0, 3};  // G, bG, M, bM, W, b
+    FusedPlan p;
+    memset(&p, 0, sizeof(p));
+    p.nseg = s->adadelta ? 6 : 4;
+    p.n_u = n_u;
+    p.ids = ids;
+    int64_t off = 0;
+    for (int q = 0; q < p.nseg; ++q) {
+        const int kind = s->adadelta ? ADADELTA_KINDS[q] : ADAGRAD_KINDS[q];
+        const bool is_weight = kind == 0 || kind == 3;
+        p.seg[q] = FusedSeg{s->tab[side][kind].p, s->snap[side][kind].p, off, kind < 3 ? s->d : 1, is_weight ? wscale : ascale};
+        off += n_u * p.seg[q].w;
+    }
+    p.total = off;
+    return p;
+}
+static int64_t fused_row_floats(const lfm_session *s) { return (s->adadelta ? 3 : 2) * ((int64_t)s->d + 1); }
 
 // step 5 of a merge whose exchange may still be in flight
 static int complete_pending(lfm_session *s, bool exact)
@@ -1051,13 +1118,8 @@ static int complete_pending(lfm_session *s, bool exact)
         if (!((s->pend.sides >> side) & 1)) continue;
         const int64_t n_u = s->pend.n_u[side];
         if (n_u == 0) continue;
-        for (int q = 0; q < 4; ++q) {
-            const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;
-            const bool is_weight = kind == 0 || kind == 3;
-            apply_packed_kernel<<<grid_for(n_u * d), 256, 0, s->stream>>>(s->tab[side][kind].p, s->snap[side][kind].p, s->pend.ids[side].p,
-                                                                         s->pend.sum[side][q].p, s->pend.loc[side][q].p,
-                                                                         is_weight ? s->pend.wscale : 1.0f, n_u, d, exact ? 1 : 0);
-        }
+        const FusedPlan p = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, s->pend.wscale, s->pend.ascale);
+        apply_fused_kernel<<<grid_for(p.total), 256, 0, s->stream>>>(p, s->pend.sum[side].p, s->pend.loc[side].p, exact ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     s->pend.active = false;
@@ -1073,7 +1135,7 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
     if (use_rccl && !r) return fail(LFM_ECOMM, "librccl.so not available");
     if (k > 16) return fail(LFM_EINVAL, "at most 16 local sessions per merge group");
     if (mode < 0 || mode > 2) return fail(LFM_EINVAL, "unknown merge mode");
-    if (s0->adadelta) return fail(LFM_EUNSUPPORTED, "the sparse merge covers adagrad models (adadelta: lfm_session_comm_merge)");
+    if (s0->adadelta && mode == LFM_MERGE_ADAGRAD) mode = LFM_MERGE_MEAN;  // moving averages: no squared-gradient sums (as merge_group)
     int64_t bytes = 0;
     // local groups run on sessions[0]'s stream; the others' streams are drained first
     hipStream_t st = s0->stream;
@@ -1088,15 +1150,21 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         ss[i]->stream = own;
         LFM_TRY(rc);
     }
+    const float wscale = mode == LFM_MERGE_MEAN ? 1.0f / (float)nranks_total : 1.0f;
+    const float ascale = s0->adadelta ? wscale : 1.0f;  // adadelta's accumulators are moving averages: averaged like the weights
+    const int64_t row_floats = fused_row_floats(s0);
+    FusedPlan plans[16][2];
     for (int side = 0; side < 2; ++side) {
         if (!((sides >> side) & 1)) continue;
         const int64_t nf = s0->n_feat[side];
         for (int i = 0; i < k; ++i) {
             if (!((ss[i]->snap_sides >> side) & 1) || !ss[i]->dirty[side].p)
                 return fail(LFM_EINVAL, "sparse merge without lfm_session_merge_begin");
-            if (ss[i]->n_feat[side] != nf || ss[i]->d != s0->d) return fail(LFM_EINVAL, "sessions differ in shape");
+            if (ss[i]->n_feat[side] != nf || ss[i]->d != s0->d || ss[i]->adadelta != s0->adadelta)
+                return fail(LFM_EINVAL, "sessions differ in shape");
         }
         if (nf == 0) continue;
+        const bool all_rows = !hot_only && s0->merge_all_rows[side];
         if (hot_only) {
             // the given rows (identical on every rank by contract): no detection, no union, no compaction
             for (int i = 0; i < k; ++i) {
@@ -1104,56 +1172,64 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
                 const size_t nh = s->hot_ids[side].n;
                 if (nh != s0->hot_ids[side].n) return fail(LFM_EINVAL, "sessions differ in their hot rows");
                 s->pend.n_u[side] = (int64_t)nh;
+                s->pend.all_rows[side] = false;
                 if (nh) {
                     LFM_TRY(s->pend.ids[side].reserve(nh));
                     HIP_TRY(hipMemcpyAsync(s->pend.ids[side].p, s->hot_ids[side].p, nh * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
                 }
             }
+        } else if (all_rows) {
+            // an earlier union covered (nearly) the whole table: every row travels, nothing is detected, OR-ed or compacted
+            for (int i = 0; i < k; ++i) {
+                ss[i]->pend.n_u[side] = nf;
+                ss[i]->pend.all_rows[side] = true;
+            }
         } else {
-        // 1. rows that differ from the snapshot
-        for (int i = 0; i < k; ++i) {
-            lfm_session *s = ss[i];
-            const int dgrid = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (nf + 3) / 4));
-            detect_dirty_kernel<<<dgrid, 256, 0, st>>>(s->tab[side][0].p, s->snap[side][0].p, s->tab[side][1].p, s->snap[side][1].p,
-                                                       s->tab[side][3].p, s->snap[side][3].p, s->tab[side][4].p, s->snap[side][4].p,
-                                                       nf, s->d, s->dirty[side].p);
-        }
-        // 2. union of the maps
-        if (use_rccl) {
-            NCCL_TRY(r->AllReduce(s0->dirty[side].p, s0->dirty[side].p, (size_t)nf, ncclUint8, ncclMax, s0->comm, st));
-            bytes += nf;
-        } else if (k > 1) {
-            BytePack pk;
-            for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->dirty[side].p;
-            local_or_kernel<<<grid_for(nf), 256, 0, st>>>(pk, k, nf);
-        }
-        // ... compacted (identical on every rank: same map, ascending order)
-        for (int i = 0; i < k; ++i) {
-            lfm_session *s = ss[i];
-            LFM_TRY(s->pend.ids[side].reserve((size_t)nf));
-            int64_t n_u = 0;
-            hipError_t e = compact_flagged_rows(s->dirty[side].p, nf, s->pend.ids[side].p, &n_u, st);
-            if (e != hipSuccess) return fail(LFM_ENODEV, std::string("compact_flagged_rows: ") + hipGetErrorString(e));
-            s->pend.n_u[side] = n_u;
-        }
-        }
-        for (int i = 0; i < k; ++i) {
-            lfm_session *s = ss[i];
-            const int64_t n_u = s->pend.n_u[side];
-            // 3. pack
-            for (int q = 0; q < 4 && n_u; ++q) {
-                const int kind = SPARSE_KINDS[q], d = kind < 3 ? s->d : 1;
-                LFM_TRY(s->pend.sum[side][q].reserve((size_t)n_u * d));
-                LFM_TRY(s->pend.loc[side][q].reserve((size_t)n_u * d));
-                pack_delta_kernel<<<grid_for(n_u * d), 256, 0, st>>>(s->tab[side][kind].p, s->snap[side][kind].p, s->pend.ids[side].p, n_u, d,
-                                                                     s->pend.loc[side][q].p, s->pend.sum[side][q].p);
+            // 1. rows that differ from the snapshot
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                const int dgrid = (int)std::max<int64_t>(1, std::min<int64_t>(8192, (nf + 3) / 4));
+                detect_dirty_kernel<<<dgrid, 256, 0, st>>>(s->tab[side][0].p, s->snap[side][0].p, s->tab[side][1].p, s->snap[side][1].p,
+                                                           s->tab[side][3].p, s->snap[side][3].p, s->tab[side][4].p, s->snap[side][4].p,
+                                                           s->adadelta ? s->tab[side][2].p : nullptr, s->adadelta ? s->snap[side][2].p : nullptr,
+                                                           s->adadelta ? s->tab[side][5].p : nullptr, s->adadelta ? s->snap[side][5].p : nullptr,
+                                                           nf, s->d, s->dirty[side].p);
+            }
+            // 2. union of the maps
+            if (use_rccl) {
+                NCCL_TRY(r->AllReduce(s0->dirty[side].p, s0->dirty[side].p, (size_t)nf, ncclUint8, ncclMax, s0->comm, st));
+                bytes += nf;
+            } else if (k > 1) {
+                BytePack pk;
+                for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->dirty[side].p;
+                local_or_kernel<<<grid_for(nf), 256, 0, st>>>(pk, k, nf);
+            }
+            // ... compacted (identical on every rank: same map, ascending order)
+            for (int i = 0; i < k; ++i) {
+                lfm_session *s = ss[i];
+                LFM_TRY(s->pend.ids[side].reserve((size_t)nf));
+                int64_t n_u = 0;
+                hipError_t e = compact_flagged_rows(s->dirty[side].p, nf, s->pend.ids[side].p, &n_u, st);
+                if (e != hipSuccess) return fail(LFM_ENODEV, std::string("compact_flagged_rows: ") + hipGetErrorString(e));
+                s->pend.n_u[side] = n_u;
+                s->pend.all_rows[side] = false;
+                // (the union is the same on every rank: all take the same path from the next merge on)
+                if ((double)n_u >= (double)s->merge_dense_frac * (double)nf) s->merge_all_rows[side] = true;
             }
         }
-        HIP_TRY(hipGetLastError());
         const int64_t n_u = s0->pend.n_u[side];
         for (int i = 1; i < k; ++i)
             if (ss[i]->pend.n_u[side] != n_u) return fail(LFM_ECORRUPT, "local merge group: the sessions' unions differ");
-        if (use_rccl) bytes += n_u * (2 * (int64_t)s0->d + 2) * (int64_t)sizeof(float);
+        // 3. pack: one launch for all kinds
+        for (int i = 0; i < k && n_u; ++i) {
+            lfm_session *s = ss[i];
+            LFM_TRY(s->pend.sum[side].reserve((size_t)(n_u * row_floats)));
+            LFM_TRY(s->pend.loc[side].reserve((size_t)(n_u * row_floats)));
+            plans[i][side] = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, wscale, ascale);
+            pack_fused_kernel<<<grid_for(plans[i][side].total), 256, 0, st>>>(plans[i][side], s->pend.loc[side].p, s->pend.sum[side].p);
+        }
+        HIP_TRY(hipGetLastError());
+        if (use_rccl) bytes += n_u * row_floats * (int64_t)sizeof(float);
     }
     // 4. the exchange: RCCL on the communication stream (overlaps the next segment), local groups in place
     hipStream_t cs = st;
@@ -1162,44 +1238,30 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         HIP_TRY(hipEventRecord(s0->ev_pack, st));
         HIP_TRY(hipStreamWaitEvent(cs, s0->ev_pack, 0));
     }
-    auto reduce = [&](int side, std::initializer_list<int> qs) -> int {
-        const int64_t n_u = s0->pend.n_u[side];
-        if (n_u == 0) return LFM_OK;
+    auto reduce = [&](int side, int64_t off, int64_t cnt) -> int {  // floats [off, off + cnt) of the side's fused buffer
+        if (cnt <= 0) return LFM_OK;
         if (use_rccl) {
-            if (r->GroupStart) NCCL_TRY(r->GroupStart());
-            for (int q : qs) {
-                const size_t cnt = (size_t)n_u * (SPARSE_KINDS[q] < 3 ? s0->d : 1);
-                NCCL_TRY(r->AllReduce(s0->pend.sum[side][q].p, s0->pend.sum[side][q].p, cnt, ncclFloat, ncclSum, s0->comm, cs));
-            }
-            if (r->GroupEnd) NCCL_TRY(r->GroupEnd());
+            NCCL_TRY(r->AllReduce(s0->pend.sum[side].p + off, s0->pend.sum[side].p + off, (size_t)cnt, ncclFloat, ncclSum, s0->comm, cs));
         } else if (k > 1) {
-            for (int q : qs) {
-                const int64_t cnt = n_u * (SPARSE_KINDS[q] < 3 ? s0->d : 1);
-                PtrPack pk;
-                for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->pend.sum[side][q].p;
-                local_allreduce_kernel<<<grid_for(cnt), 256, 0, cs>>>(pk, k, cnt);
-            }
+            PtrPack pk;
+            for (int i = 0; i < k; ++i) pk.p[i] = ss[i]->pend.sum[side].p + off;
+            local_allreduce_kernel<<<grid_for(cnt), 256, 0, cs>>>(pk, k, cnt);
         }
         return LFM_OK;
     };
-    float wscale = 1.0f;
     for (int side = 0; side < 2; ++side) {
         if (!((sides >> side) & 1) || s0->n_feat[side] == 0) continue;
+        const int64_t n_u = s0->pend.n_u[side];
+        if (n_u == 0) continue;
+        const int64_t total = n_u * row_floats;
         if (mode == LFM_MERGE_ADAGRAD) {
-            LFM_TRY(reduce(side, {1, 3}));  // accumulators (G, bG) first
-            for (int i = 0; i < k; ++i) {
-                lfm_session *s = ss[i];
-                const int64_t n_u = s->pend.n_u[side];
-                if (!n_u) continue;
-                rescale_packed_kernel<<<grid_for(n_u * s->d), 256, 0, cs>>>(s->pend.sum[side][0].p, s->snap[side][1].p, s->pend.ids[side].p,
-                                                                           s->pend.loc[side][1].p, s->pend.sum[side][1].p, n_u, s->d);
-                rescale_packed_kernel<<<grid_for(n_u), 256, 0, cs>>>(s->pend.sum[side][2].p, s->snap[side][4].p, s->pend.ids[side].p,
-                                                                    s->pend.loc[side][3].p, s->pend.sum[side][3].p, n_u, 1);
-            }
-            LFM_TRY(reduce(side, {0, 2}));
+            const int64_t acc = n_u * ((int64_t)s0->d + 1);  // [G | bG] first ...
+            LFM_TRY(reduce(side, 0, acc));
+            for (int i = 0; i < k; ++i)  // ... then the embedding deltas, rescaled with every rank's squared gradients
+                rescale_fused_kernel<<<grid_for(total - acc), 256, 0, cs>>>(plans[i][side], ss[i]->pend.sum[side].p, ss[i]->pend.loc[side].p);
+            LFM_TRY(reduce(side, acc, total - acc));
         } else {
-            LFM_TRY(reduce(side, {0, 1, 2, 3}));
-            if (mode == LFM_MERGE_MEAN) wscale = 1.0f / (float)nranks_total;
+            LFM_TRY(reduce(side, 0, total));
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1208,6 +1270,7 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         ss[i]->pend.active = true;
         ss[i]->pend.sides = sides;
         ss[i]->pend.wscale = wscale;
+        ss[i]->pend.ascale = ascale;
         ss[i]->pend.on_comm_stream = use_rccl;
     }
     if (!overlap) {
@@ -1221,6 +1284,16 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (bytes_out) *bytes_out = bytes;
+    return LFM_OK;
+}
+
+// From which share of a side's rows in a merge's union the following merges of that side carry every row without
+// detecting (default 0.9; > 1: never, <= 0: from the first merge on).  The same value on every rank.
+extern "C" int lfm_session_set_merge_dense_fraction(lfm_session *s, float fraction)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    s->merge_dense_frac = fraction;
+    for (int side = 0; side < 2; ++side) s->merge_all_rows[side] = fraction <= 0.0f;
     return LFM_OK;
 }
 
@@ -1348,27 +1421,48 @@ extern "C" int lfm_sessions_merge_local(lfm_session **sessions, int32_t k, int32
 
 // Owner-sharded item tables over K sessions of ONE device (device.hpp: ItemShards): session j owns the item rows
 // [j * rps, (j + 1) * rps), rps = ceil(n_items / K), and every session's epoch kernels gather from and publish to
-// the owner's tables.  The one-device form of the multi-GPU decomposition for item sides too large to replicate
-// and merge (DESIGN.md "Multi-GPU": C4): there the K base pointers are peer mappings of the owners' memory.
+// the owner's tables.  The one-process form of the multi-GPU decomposition for item sides too large to replicate
+// and merge (DESIGN.md "Multi-GPU": C4); lfm_session_share_items_ipc below is the multi-process form.
+static int shard_geometry(uint32_t n_items, int k, uint32_t *rps, uint32_t *magic)
+{
+    if (k < 1 || k > 8) return fail(LFM_EINVAL, "1 to 8 owners");
+    *rps = (n_items + (uint32_t)k - 1) / (uint32_t)k;
+    // (rows_per_shard = 1 would make magic = 2^32 / 1 + 1 wrap to 1: every row would map to owner 0)
+    if (*rps < 2) return fail(LFM_EINVAL, "owner-sharded item tables need at least two item rows per owner");
+    if ((uint64_t)(*rps) * (uint64_t)(k - 1) >= (uint64_t)n_items)
+        return fail(LFM_EINVAL, "owner-sharded item tables: the last owner's row range would be empty (fewer owners, please)");
+    *magic = (uint32_t)((1ull << 32) / (uint64_t)(*rps)) + 1u;
+    return LFM_OK;
+}
+
+static int shareable(const lfm_session *s)
+{
+    if (!s || s->scoring_only || s->adadelta || !s->itf.identity || s->comm)
+        return fail(LFM_EINVAL, "sharing needs a training session with an identity item side, adagrad, no communicator");
+    return LFM_OK;
+}
+
 extern "C" int lfm_sessions_share_items_local(lfm_session **sessions, int32_t k)
 {
     if (!sessions || k < 1 || k > 8) return fail(LFM_EINVAL, "1 to 8 sessions");
     lfm_session *s0 = sessions[0];
     for (int i = 0; i < k; ++i) {
         lfm_session *s = sessions[i];
-        if (!s || s->device != s0->device || s->scoring_only || s->n_feat[0] != s0->n_feat[0] || s->d != s0->d ||
-            s->adadelta || !s->itf.identity || s->comm)
-            return fail(LFM_EINVAL, "sharing needs training sessions of one device with the same identity item side, adagrad, no communicator");
+        LFM_TRY(shareable(s));
+        if (s->device != s0->device || s->n_feat[0] != s0->n_feat[0] || s->d != s0->d)
+            return fail(LFM_EINVAL, "sharing needs sessions of one device with the same item side");
+        if (s->share || !s->ipc_mappings.empty()) return fail(LFM_EINVAL, "a session's item tables can be shared once");
     }
+    uint32_t rps = 0, magic = 0;
+    LFM_TRY(shard_geometry((uint32_t)s0->n_feat[0], k, &rps, &magic));
     const uint32_t n_items = (uint32_t)s0->n_feat[0];
-    if (n_items < (uint32_t)k) return fail(LFM_EINVAL, "fewer item rows than sessions");
-    const uint32_t rps = (n_items + (uint32_t)k - 1) / (uint32_t)k;
+    auto group = std::make_shared<lfm_session::ShareGroup>();
     for (int i = 0; i < k; ++i) {
         ItemShards &sh = sessions[i]->shards;
         memset(&sh, 0, sizeof(sh));
         sh.n = k;
         sh.rows_per_shard = rps;
-        sh.magic = (uint32_t)((1ull << 32) / (uint64_t)rps) + 1u;
+        sh.magic = magic;
         for (int j = 0; j < 8; ++j) {
             lfm_session *owner = sessions[std::min(j, k - 1)];
             const size_t first = (size_t)std::min<uint32_t>((uint32_t)j * rps, n_items);
@@ -1377,7 +1471,123 @@ extern "C" int lfm_sessions_share_items_local(lfm_session **sessions, int32_t k)
             sh.b[j] = owner->tab[0][3].p + first;
             sh.bG[j] = owner->tab[0][4].p + first;
         }
+        sessions[i]->share = group;
+        sessions[i]->share_rank = i;
+        sessions[i]->share_k = k;
     }
+    return LFM_OK;
+}
+
+// ---- the multi-PROCESS form: every process exports its four item-side allocations as HIP IPC handles, the handles travel
+// over the job's rendezvous (like the RCCL unique id), and every process maps the other owners' allocations: on one
+// GPU they are the same memory, across the GPUs of a node they are peer mappings over xGMI (hipIpcOpenMemHandle enables
+// peer access lazily).  The tables of large models are allocated uncached (table_alloc_flags), so a float atomic from
+// any process or device is performed at the owner's memory.  A pool block is one runtime allocation (pool.hpp), so
+// a table's pointer is its allocation's base; the offset is exported anyway and checked.
+static const int SHARED_KINDS[4] = {0, 1, 3, 4};  // W, G, b, bG
+
+extern "C" int lfm_session_export_items(lfm_session *s, lfm_item_export *out)
+{
+    if (!s || !out) return fail(LFM_EINVAL, "null argument");
+    LFM_TRY(shareable(s));
+    static_assert(sizeof(hipIpcMemHandle_t) <= LFM_IPC_HANDLE_BYTES, "handle size");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    memset(out, 0, sizeof(*out));
+    for (int q = 0; q < 4; ++q) {
+        float *p = s->tab[0][SHARED_KINDS[q]].p;
+        if (!p) return fail(LFM_EINVAL, "item tables not resident");
+        void *base = nullptr;
+        size_t size = 0;
+        HIP_TRY(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p));
+        hipIpcMemHandle_t h;
+        HIP_TRY(hipIpcGetMemHandle(&h, base));
+        memcpy(out->handle[q], &h, sizeof(h));
+        out->offset[q] = (int64_t)((char *)p - (char *)base);
+        out->bytes[q] = (int64_t)(tab_count(s, 0, SHARED_KINDS[q]) * sizeof(float));
+    }
+    out->n_items = s->n_feat[0];
+    out->d = s->d;
+    out->device = s->device;
+    out->pid = (int64_t)getpid();
+    return LFM_OK;
+}
+
+extern "C" int lfm_session_share_items_ipc(lfm_session *s, const lfm_item_export *all, int32_t k, int32_t my_rank)
+{
+    if (!s || !all) return fail(LFM_EINVAL, "null argument");
+    LFM_TRY(shareable(s));
+    if (my_rank < 0 || my_rank >= k) return fail(LFM_EINVAL, "rank outside [0, k)");
+    if (s->share || !s->ipc_mappings.empty()) return fail(LFM_EINVAL, "a session's item tables can be shared once");
+    uint32_t rps = 0, magic = 0;
+    LFM_TRY(shard_geometry((uint32_t)s->n_feat[0], k, &rps, &magic));
+    for (int j = 0; j < k; ++j)
+        if (all[j].n_items != s->n_feat[0] || all[j].d != s->d)
+            return fail(LFM_EINVAL, "an exported item side has another shape than this session's");
+    if (all[my_rank].pid != (int64_t)getpid())
+        return fail(LFM_EINVAL, "all[my_rank] is not this process's export");
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t n_items = (uint32_t)s->n_feat[0];
+    ItemShards sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.n = k;
+    sh.rows_per_shard = rps;
+    sh.magic = magic;
+    float **dst[4] = {sh.W, sh.G, sh.b, sh.bG};
+    std::vector<void *> mapped;
+    auto undo = [&] { for (void *m : mapped) (void)hipIpcCloseMemHandle(m); };
+    for (int j = 0; j < k; ++j) {
+        const size_t first = (size_t)std::min<uint32_t>((uint32_t)j * rps, n_items);
+        for (int q = 0; q < 4; ++q) {
+            float *base;
+            if (j == my_rank) {
+                base = s->tab[0][SHARED_KINDS[q]].p;
+            } else {
+                hipIpcMemHandle_t h;
+                memcpy(&h, all[j].handle[q], sizeof(h));
+                void *m = nullptr;
+                hipError_t e = hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    undo();
+                    return fail(LFM_ENODEV, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+                }
+                mapped.push_back(m);
+                base = (float *)((char *)m + all[j].offset[q]);
+            }
+            dst[q][j] = base + first * (q < 2 ? (size_t)s->d : (size_t)1);
+        }
+    }
+    for (int j = k; j < 8; ++j)
+        for (int q = 0; q < 4; ++q) dst[q][j] = dst[q][k - 1];
+    s->shards = sh;
+    s->ipc_mappings = mapped;
+    s->share_rank = my_rank;
+    s->share_k = k;
+    return LFM_OK;
+}
+
+// After training: the owners' rows copied into this session's own (otherwise stale) item tables, device to device through
+// the mappings, so that check_finite / sync_to_host / predict see the whole model.  All processes call it between two
+// barriers of their rendezvous (nobody trains while rows are copied).
+extern "C" int lfm_session_gather_shared_items(lfm_session *s)
+{
+    if (!s) return fail(LFM_EINVAL, "null session");
+    if (s->shards.n <= 0 || s->share_rank < 0) return fail(LFM_EINVAL, "the session's item tables are not owner-sharded");
+    if (s->share && s->share->broken) return fail(LFM_EINVAL, "a session of the sharing group has been destroyed");
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t n_items = (uint32_t)s->n_feat[0], rps = s->shards.rows_per_shard;
+    float *const *src[4] = {s->shards.W, s->shards.G, s->shards.b, s->shards.bG};
+    for (int j = 0; j < s->shards.n; ++j) {
+        if (j == s->share_rank) continue;
+        const size_t first = (size_t)std::min<uint32_t>((uint32_t)j * rps, n_items);
+        const size_t rows = (size_t)std::min<uint32_t>(rps, n_items - (uint32_t)first);
+        for (int q = 0; q < 4; ++q) {
+            const size_t w = q < 2 ? (size_t)s->d : (size_t)1;
+            HIP_TRY(hipMemcpyAsync(s->tab[0][SHARED_KINDS[q]].p + first * w, src[q][j], rows * w * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return LFM_OK;
 }
 
@@ -1547,6 +1757,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (!s) return fail(LFM_EINVAL, "null session");
     if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session (lfm_session_create_scoring) cannot train");
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);  // (left running only by an epoch that failed half-way)
+    if (s->share && s->share->broken)
+        return fail(LFM_EINVAL, "a session this one shares item tables with has been destroyed: its rows are gone");
     if (loss < 0 || loss > 3) return fail(LFM_EINVAL, "unknown loss");
     if (slot < 0 || slot >= (int)s->shuffles.size() || s->shuffles[slot]->n != (size_t)s->n)
         return fail(LFM_EINVAL, "shuffle slot not uploaded");
@@ -1949,8 +2161,15 @@ extern "C" int lfm_session_check_finite(lfm_session *s)
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemsetAsync(s->flag.p, 0, sizeof(int), s->stream));
     for (int side = 0; side < 2; ++side) {
-        HIP_TRY(launch_nonfinite(s->tab[side][0].p, (int64_t)tab_count(s, side, 0), s->flag.p, s->stream));
-        HIP_TRY(launch_nonfinite(s->tab[side][3].p, (int64_t)tab_count(s, side, 3), s->flag.p, s->stream));
+        int64_t first = 0, rows = s->n_feat[side];
+        if (side == 0 && s->shards.n > 0 && s->share_rank >= 0) {
+            // owner-sharded item tables: this session answers for the rows it owns (the others' copies here are stale;
+            // their owners check them, and the host driver combines the answers)
+            first = std::min<int64_t>((int64_t)s->share_rank * s->shards.rows_per_shard, rows);
+            rows = std::min<int64_t>(s->shards.rows_per_shard, rows - first);
+        }
+        HIP_TRY(launch_nonfinite(s->tab[side][0].p + first * s->d, rows * s->d, s->flag.p, s->stream));
+        HIP_TRY(launch_nonfinite(s->tab[side][3].p + first, rows, s->flag.p, s->stream));
     }
     int f = 0;
     HIP_TRY(hipMemcpyAsync(&f, s->flag.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));

@@ -196,8 +196,15 @@ class DistributedFit(object):
 
     def __init__(self, model, interactions, rank, world, device=0, dist=None, policy=None,
                  host_shuffle=False, bounds=None, global_n=None, item_features=None, user_features=None,
-                 local_ids=False):
-        """interactions: the WHOLE interaction matrix (every rank cuts its own user range from it,
+                 local_ids=False, item_tables="replicated"):
+        """item_tables: "replicated" (default: every rank holds the item tables, merged over RCCL) or "owner"
+        (owner-sharded, include/lfm_hip.h: lfm_session_share_items_ipc -- the item rows are cut into `world`
+        contiguous ranges, range r lives with rank r, and every rank's kernels gather from and publish to the
+        owner's memory through HIP IPC mappings: no replicas, no merges, no RCCL; for item sides too large to
+        merge at a useful cadence, BASELINE config C4.  Parallel WARP, identity features on both sides, adagrad,
+        no regularisation, no_components <= 64 and a multiple of 4, max_sampled = 10).
+
+        interactions: the WHOLE interaction matrix (every rank cuts its own user range from it,
         boundaries planned from the row counts) -- or, with `bounds` and `global_n`, only THIS rank's
         rows of it: a matrix of the full shape whose entries all lie in users [bounds[rank],
         bounds[rank + 1]) (a rank of a large job loads its range from its own data source; bounds =
@@ -211,6 +218,14 @@ class DistributedFit(object):
         self.model, self.rank, self.world, self.dist = model, rank, world, dist
         self.policy = policy or MergePolicy()
         self.host_shuffle = host_shuffle
+        if item_tables not in ("replicated", "owner"):
+            raise ValueError("item_tables must be 'replicated' or 'owner'")
+        self.owner_sharded = item_tables == "owner" and world > 1
+        if self.owner_sharded and (item_features is not None or user_features is not None or model.loss != "warp"
+                                   or model.learning_schedule != "adagrad" or model.item_alpha or model.user_alpha
+                                   or model.no_components > 64 or model.no_components % 4 or model.max_sampled != 10):
+            raise NotImplementedError("owner-sharded item tables: parallel WARP with identity features, adagrad, no "
+                                      "regularisation, no_components <= 64 (a multiple of 4), max_sampled = 10")
         coo = interactions.tocoo()
         coo = sp.coo_matrix((np.ascontiguousarray(coo.data, dtype=np.float32),
                              (np.ascontiguousarray(coo.row, dtype=np.int32),
@@ -276,7 +291,15 @@ class DistributedFit(object):
         self.merges, self.merge_bytes = 0, 0
         self.hot = [hot_rows(item_features, self.policy.hot_share, 2.0),
                     hot_rows(user_features if self.shared_users else None, self.policy.hot_share, 1.0)]
-        if world > 1:
+        if self.owner_sharded:
+            # every rank's export to every rank (the rendezvous plane), then the peers' allocations are mapped
+            import torch
+            mine = torch.frombuffer(bytearray(self.session.export_items()), dtype=torch.uint8).clone()
+            blobs = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(blobs, mine)
+            self.session.share_items_ipc([bytes(b.numpy().tobytes()) for b in blobs], rank)
+            dist.barrier()  # nobody trains before every rank has its mappings
+        elif world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
             if rank == 0:
@@ -299,13 +322,15 @@ class DistributedFit(object):
         m = self.model
         n = self.shard.nnz
         history = int(getattr(m, "_trained_interactions", 0))  # interactions of ALL ranks so far
-        if self.world == 1:  # nothing to merge: the whole epoch in one call, exactly LightFM.fit_partial's epoch
+        if self.world == 1 or self.owner_sharded:
+            # nothing to merge: the whole epoch in one call, exactly LightFM.fit_partial's epoch (owner-sharded item
+            # tables: all ranks train against ONE copy of every row -- plain Hogwild across the ranks)
             fr, kinds = np.array([0.0, 1.0]), ["none"]
         else:
             fr, kinds = merge_plan(history, self.global_n, self.world, self.policy, self.n_replicated_rows,
                                    self.has_hot)
         pos = segment_positions(fr, n)
-        sparse = self.policy.sparse and m.learning_schedule == "adagrad"
+        sparse = self.policy.sparse
         stats = []
         for j in range(len(pos) - 1):
             opts, _ = make_opts()
@@ -326,7 +351,7 @@ class DistributedFit(object):
             self.merges += int(kinds[j] != "none")
             if pos[j + 1] > pos[j]:
                 stats.append(opts)
-        if sparse and self.world > 1:
+        if sparse and self.world > 1 and not self.owner_sharded:
             self.session.comm_merge_flush()  # the last exchange lands before anything reads the tables
         m._trained_interactions = history + self.global_n
         return stats
@@ -349,10 +374,14 @@ class DistributedFit(object):
             seeds = np.ascontiguousarray(m.random_state.randint(
                 0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
         stats = self.run_epoch(seeds)
-        bad = not self.session.check_finite()
-        if self.world > 1:
+        bad = not self.session.check_finite()  # (owner-sharded: the item rows this rank owns + its users)
+        if self.owner_sharded:
+            bad = self._any(bad)
+        elif self.world > 1:
             bad = self.session.comm_any(bad)
         if bad:
+            if self.owner_sharded:
+                self._collect_items()
             self.session.sync_to_host(self.struct)
             raise ValueError("Not all estimated parameters are finite, your model may have diverged.")
         return stats
@@ -361,12 +390,30 @@ class DistributedFit(object):
         stats = []
         for _ in range(epochs):
             stats.extend(self.epoch(num_threads))
+        if self.owner_sharded:
+            self._collect_items()
         self.session.sync_to_host(self.struct)
         return stats
 
+    def _any(self, flag):
+        """max over ranks of a flag on the rendezvous plane (owner-sharded jobs have no RCCL communicator)."""
+        import torch
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t[0]))
+
+    def _collect_items(self):
+        """Owner-sharded item tables, after training: every rank copies the other owners' rows into its own
+        tables (device to device through the mappings) -- between two barriers, so nobody trains meanwhile."""
+        self.dist.barrier()
+        self.session.gather_shared_items()
+        self.dist.barrier()
+
     def barrier(self):
         """Device work of this rank done and every rank here (bench.py's timed region)."""
-        if self.world > 1:
+        if self.owner_sharded:
+            self.dist.barrier()  # (lfm_session_epoch returns with the rank's stream drained)
+        elif self.world > 1:
             self.session.comm_barrier()
 
     def gather_users(self):
@@ -387,4 +434,6 @@ class DistributedFit(object):
                     self.dist.broadcast(torch.from_numpy(a[b0:b1]), src=r)
 
     def close(self):
+        if self.owner_sharded and self.session.handle:
+            self.dist.barrier()  # an owner's tables stay mapped in the peers until every rank is done with them
         self.session.close()

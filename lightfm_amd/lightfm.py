@@ -131,6 +131,11 @@ class _Session(object):
         N.check(N.lib().lfm_session_comm_merge_sparse(self.handle, sides, mode, int(bool(overlap)), C.byref(nbytes)))
         return nbytes.value
 
+    def set_merge_dense_fraction(self, fraction):
+        """From which share of a side's rows in a merge's union the next sparse merges carry every row without detecting
+        them (default 0.9; > 1 never, <= 0 always)."""
+        N.check(N.lib().lfm_session_set_merge_dense_fraction(self.handle, C.c_float(fraction)))
+
     def comm_merge_flush(self):
         N.check(N.lib().lfm_session_comm_merge_flush(self.handle))
 
@@ -169,6 +174,25 @@ class _Session(object):
         the item rows [j * rps, (j + 1) * rps), rps = ceil(n_items / K); every session trains against the owners' rows."""
         arr = (C.c_void_p * len(sessions))(*[s.handle for s in sessions])
         N.check(N.lib().lfm_sessions_share_items_local(arr, len(sessions)))
+
+    def export_items(self):
+        """The HIP IPC handles of this session's item-side allocations as bytes (lfm_session_export_items)."""
+        ex = N.LfmItemExport()
+        N.check(N.lib().lfm_session_export_items(self.handle, C.byref(ex)))
+        return bytes(bytearray(ex))
+
+    def share_items_ipc(self, exports, my_rank):
+        """Owner-sharded item tables over K PROCESSES (lfm_session_share_items_ipc): `exports` = every rank's
+        export_items() bytes in rank order, exports[my_rank] this process's own."""
+        arr = (N.LfmItemExport * len(exports))()
+        for j, blob in enumerate(exports):
+            if len(blob) != C.sizeof(N.LfmItemExport):
+                raise ValueError("export %d has %d bytes, expected %d" % (j, len(blob), C.sizeof(N.LfmItemExport)))
+            C.memmove(C.byref(arr[j]), blob, len(blob))
+        N.check(N.lib().lfm_session_share_items_ipc(self.handle, arr, len(exports), my_rank))
+
+    def gather_shared_items(self):
+        N.check(N.lib().lfm_session_gather_shared_items(self.handle))
 
     @staticmethod
     def merge_local_flush(sessions):

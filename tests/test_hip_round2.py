@@ -413,6 +413,77 @@ def test_hot_rows_merge_between_full_merges():
             s.close()
 
 
+_ITEM_TABLES = ("item_embeddings", "item_embedding_gradients", "item_embedding_momentum", "item_biases",
+                "item_bias_gradients", "item_bias_momentum")
+
+
+@pytest.mark.parametrize("schedule,mode", [("adagrad", "sum"), ("adagrad", "mean"), ("adagrad", "adagrad"),
+                                           ("adadelta", "sum"), ("adadelta", "mean"), ("adadelta", "adagrad")])
+def test_merge_flavours_agree_from_identical_states(schedule, mode):
+    """The dense merge, the sparse merge (detected rows) and the sparse merge over ALL rows (what follows a union of
+    >= 90 % of a table: no detection, no OR, no compaction -- lfm_session_set_merge_dense_fraction) applied to the SAME
+    snapshot and the SAME trained replicas (lfm_session_load_model puts them back): the all-rows merge is bit-identical
+    to the detected-rows merge, both equal the dense merge.  adadelta: the sparse merge carries the momentum tables too."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import make_opts
+    from lightfm_amd.distributed import local_shard
+    from lightfm_amd.lightfm import _Session
+    K, nu, ni, d = 3, 240, 400, 32
+    coo = H.make_interactions(nu, ni, 5000, seed=12, zipf=1.1)   # (a long tail: many rows stay untouched)
+    sessions, structs, trained = [], [], []
+    names = [n for n in _ITEM_TABLES if schedule == "adadelta" or "momentum" not in n]
+    try:
+        for r in range(K):
+            shard, _ = local_shard(coo, r, K)
+            m = LightFM(no_components=d, loss="warp", random_state=2, learning_schedule=schedule)
+            m._initialize(d, ni, nu)
+            s, st = _session(m, ni, nu, shard)
+            start = {n: getattr(m, n).copy() for n in _ITEM_TABLES}
+            s.device_shuffle(10 + r, 20 + r)
+            o, _ = make_opts()
+            o.history = 1 << 30
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([5 + r], np.uint32), o)
+            s.sync_to_host(st)
+            trained.append({n: getattr(m, n).copy() for n in _ITEM_TABLES})
+            sessions.append(s)
+            structs.append((m, st))
+        results = {}
+        for flavour in ("dense", "sparse", "allrows"):
+            for r, ((m, st), s) in enumerate(zip(structs, sessions)):
+                for n in _ITEM_TABLES:
+                    getattr(m, n)[...] = start[n]
+                s.load_model(st)
+                s.set_merge_dense_fraction(0.0 if flavour == "allrows" else 2.0)
+                s.merge_begin(1)            # the interval starts at the common initial state ...
+                for n in _ITEM_TABLES:
+                    getattr(m, n)[...] = trained[r][n]
+                s.load_model(st)            # ... and every replica holds what it trained
+            if flavour == "dense":
+                _Session.merge_local(sessions, 1, N.MERGE_MODES[mode])
+            else:
+                _Session.merge_local_sparse(sessions, 1, N.MERGE_MODES[mode])
+            out = []
+            for (m, st), s in zip(structs, sessions):
+                s.sync_to_host(st)
+                out.append({n: getattr(m, n).copy() for n in names})
+            for other in out[1:]:
+                for n in names:
+                    np.testing.assert_array_equal(other[n], out[0][n])
+            results[flavour] = out[0]
+    finally:
+        for s in sessions:
+            s.close()
+    touched = np.zeros(ni, bool)
+    for t in trained:
+        touched |= np.any(t["item_embedding_gradients"] != start["item_embedding_gradients"], axis=1)
+    assert 0.05 < touched.mean() < 0.9, touched.mean()
+    for n in names:
+        np.testing.assert_array_equal(results["allrows"][n], results["sparse"][n], err_msg=n)
+        np.testing.assert_allclose(results["sparse"][n], results["dense"][n], rtol=2e-6, atol=1e-7, err_msg=n)
+        assert np.array_equal(results["sparse"][n][~touched], start[n][~touched]), n
+    assert not np.array_equal(results["sparse"]["item_embeddings"], start["item_embeddings"])
+
+
 def test_sparse_merge_carries_what_training_adds_while_the_exchange_is_in_flight():
     """The overlapped exchange: a second segment trains between the merge call and the flush.  What it adds to
     the local tables must survive the late application (table += sum - local delta) and travel with the NEXT

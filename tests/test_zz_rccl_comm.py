@@ -70,6 +70,40 @@ def test_single_rank_communicator_roundtrip():
     assert np.isfinite(m.item_embeddings).all()
 
 
+def test_merge_switches_to_all_rows_after_a_covering_union():
+    """Default threshold: the first merge detects; its union covers the whole (small, dense) table, so the second merge
+    travels as all rows -- visible in the bytes a one-rank communicator hands to RCCL: no byte map any more."""
+    from lightfm_amd import LightFM, _native as N
+    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
+    from lightfm_amd.lightfm import _Session
+    from tests import helpers as H
+    nu, ni, d = 300, 64, 32
+    coo = H.make_interactions(nu, ni, 8000, seed=5, zipf=0.3)
+    m = LightFM(no_components=d, loss="warp", random_state=2)
+    m._initialize(d, ni, nu)
+    st = m._get_lightfm_data()
+    s = _Session(st, CSRMatrix(H.identity_features(ni)), CSRMatrix(H.identity_features(nu)))
+    s.set_interactions(None, np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col), coo.data, coo.data)
+    s.build_positives(nu, ni)
+    try:
+        uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
+        N.check(N.lib().lfm_comm_unique_id(uid))
+        s.comm_init(uid, 0, 1)
+        sent = []
+        for e in range(3):
+            s.device_shuffle(3 + e, 4)
+            o, _ = make_opts()
+            o.history = 1 << 30
+            s.epoch("warp", 0.0, 0.0, 5, 10, np.array([9 + e], np.uint32), o)
+            sent.append(s.comm_merge_sparse(1, N.MERGE_ADAGRAD, overlap=False))
+        assert s.check_finite()
+    finally:
+        s.close()
+    row = (2 * d + 2) * 4
+    assert sent[0] == ni + ni * row, sent      # the byte map + every row (all were touched)
+    assert sent[1] == ni * row and sent[2] == ni * row, sent
+
+
 def test_deterministic_device_inputs_after_rccl_in_process():
     """every dying process of round 2 had initialised RCCL earlier in its life, and two of them first
     failed deterministic tests that read freshly built index arrays.  With librccl loaded and a communicator
