@@ -47,6 +47,24 @@ _NOT_FINITE = ("Not all estimated parameters are finite, your model may have div
                "Try decreasing the learning rate or normalising feature values and sample weights")
 
 
+def _printed_epochs(n):
+    for epoch in range(n):
+        print("Epoch {}".format(epoch))
+        yield epoch
+
+
+def _pair_ids(user_ids, item_ids):
+    """predict()'s id arguments as two int32 arrays of one length.  Accepted like the reference (LFM:821-840): one
+    int user id for many items, lists / tuples, integer arrays of any width."""
+    if isinstance(user_ids, int):
+        user_ids = np.full(len(item_ids), user_ids, dtype=np.int32)
+    pair = [np.asarray(v, dtype=np.int32) if isinstance(v, (list, tuple)) else v for v in (user_ids, item_ids)]
+    if len(pair[0]) != len(pair[1]):
+        raise ValueError("Expected the number of user IDs (%d) to equal the number of item IDs (%d)"
+                         % (len(pair[0]), len(pair[1])))
+    return [v if v.dtype == np.int32 else v.astype(np.int32) for v in pair]
+
+
 class _Session(object):
     """RAII wrapper of lfm_session (include/lfm_hip.h)."""
 
@@ -485,18 +503,15 @@ class LightFM(object):
 
     @staticmethod
     def _progress(n, verbose):
-        """LFM:474-492."""
-        if not verbose:
-            return range(n)
-        try:
-            from tqdm import trange
-            return trange(n, desc="Epoch")
-        except ImportError:
-            def verbose_range():
-                for i in range(n):
-                    print("Epoch {}".format(i))
-                    yield i
-            return verbose_range()
+        """The epoch counter of fit_partial: silent, a tqdm bar where tqdm is importable, otherwise one printed
+        line per epoch (what LFM:474-492 offers)."""
+        if verbose:
+            try:
+                import tqdm
+            except ImportError:
+                return _printed_epochs(n)
+            return tqdm.trange(n, desc="Epoch")
+        return range(n)
 
     # -------------------------------------------------------------------- fit
 
@@ -612,22 +627,7 @@ class LightFM(object):
         """Scores for (user, item) PAIRS (LFM:761-872)."""
         self._check_initialized()
 
-        if isinstance(user_ids, int):
-            user_ids = np.repeat(np.int32(user_ids), len(item_ids))
-        if isinstance(user_ids, (list, tuple)):
-            user_ids = np.array(user_ids, dtype=np.int32)
-        if isinstance(item_ids, (list, tuple)):
-            item_ids = np.array(item_ids, dtype=np.int32)
-
-        if len(user_ids) != len(item_ids):
-            raise ValueError(
-                f"Expected the number of user IDs ({len(user_ids)}) to equal the number"
-                f" of item IDs ({len(item_ids)})")
-
-        if user_ids.dtype != np.int32:
-            user_ids = user_ids.astype(np.int32)
-        if item_ids.dtype != np.int32:
-            item_ids = item_ids.astype(np.int32)
+        user_ids, item_ids = _pair_ids(user_ids, item_ids)
         if num_threads < 1:
             raise ValueError("Number of threads must be 1 or larger.")
         if user_ids.min() < 0 or item_ids.min() < 0:

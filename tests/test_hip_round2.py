@@ -428,8 +428,8 @@ def test_merge_flavours_agree_from_identical_states(schedule, mode):
     from lightfm_amd._lightfm_fast import make_opts
     from lightfm_amd.distributed import local_shard
     from lightfm_amd.lightfm import _Session
-    K, nu, ni, d = 3, 240, 400, 32
-    coo = H.make_interactions(nu, ni, 5000, seed=12, zipf=1.1)   # (a long tail: many rows stay untouched)
+    K, nu, ni, d = 3, 240, 20000, 32
+    coo = H.make_interactions(nu, ni, 5000, seed=12, zipf=1.1)   # (a long catalogue: many rows stay untouched)
     sessions, structs, trained = [], [], []
     names = [n for n in _ITEM_TABLES if schedule == "adadelta" or "momentum" not in n]
     try:

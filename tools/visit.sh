@@ -698,6 +698,14 @@ r3d)
   EMU_SHAPE=c4s EMU_EPOCHS=3 EMU_SEEDS=1,2 timeout 1200 python tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:overlap > $OUT/emu_c4s.txt 2>&1; grep -a "K=" $OUT/emu_c4s.txt
   tail -3 $OUT/emu_c4s.txt | cut -c1-300
   ;;
+r5b)
+  # round 5: multi-process owner-sharded item tables (HIP IPC, K processes on the one GPU), fused / all-rows / adadelta merges,
+  # one-GPU merge overhead at the ML-20M shape
+  timeout 900 $PYT tests/test_sharded_items_ipc.py tests/test_sharded_items.py tests/test_hip_round2.py tests/test_zz_rccl_comm.py -m gpu -q -x \
+     -k "ipc or sharded or merge or communicator or rccl" > $OUT/tests.log 2>&1
+  tail -15 $OUT/tests.log
+  timeout 300 python3 tools/merge_overhead.py 12 > $OUT/merge_overhead.txt 2>&1; cat $OUT/merge_overhead.txt | tail -8
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
