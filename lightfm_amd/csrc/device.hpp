@@ -38,7 +38,9 @@ struct DCsr {
 struct DModel {
     float *W[2], *G[2], *M[2], *b[2], *bG[2], *bM[2];
     int32_t n_feat[2];
-    int32_t d;
+    int32_t d;       // floats per embedding row ON THE DEVICE: no_components rounded up to a multiple of 4 (session.hip:
+                     // padded components are zeros in W / M and ones in G; their products, gradients and updates are zeros)
+    int32_t d_real;  // no_components: what the learning-rate average of the regularisation scales counts (PYX:640-649)
     int32_t adadelta;
     float lr, rho, eps;
     int32_t max_sampled;
@@ -525,8 +527,9 @@ __device__ __forceinline__ void update_row(const DCsr &f, int row, int side, con
             int c = lane + WAVE * q;
             if (c < d) {
                 double g = gcoef * (double)x[q];
-                lr_comp[q] += cell_update(m.W[side] + base + c, m.G[side] + base + c,
-                                          m.M[side] + base + c, w, g, h, alpha, atomic);
+                const double lr = cell_update(m.W[side] + base + c, m.G[side] + base + c,
+                                              m.M[side] + base + c, w, g, h, alpha, atomic);
+                if (c < m.d_real) lr_comp[q] += lr;  // (padded components are no cells of the reference's model)
             }
         }
     }
@@ -593,7 +596,7 @@ __device__ __forceinline__ void update_row_batched(const DCsr &f, int row, int s
                             double lr;
                             cell_math(oW[j][q], oG[j][q], oM[j][q], w, gcoef * (double)x[q], h, alpha, nW,
                                       nG, nM, lr);
-                            lr_comp[q] += lr;
+                            if (c < m.d_real) lr_comp[q] += lr;
                             publish_cell(m.W[side] + base[j] + c, m.G[side] + base[j] + c, m.M[side] + base[j] + c,
                                          oW[j][q], oG[j][q], oM[j][q], nW, nG, nM, w, gcoef * (double)x[q], h, alpha,
                                          atomic ? 0 : 1);
@@ -772,7 +775,7 @@ __device__ __forceinline__ double rows_update_parallel(const DModel &m, const Ro
                 double lr;
                 cell_math(oW[k][q], oG[k][q], oM[k][q], (double)cw[k], gc * (double)x[q].pick(r), h, al, nW, nG,
                           nM, lr);
-                if (e0 + k < total && lane + WAVE * q < d) lr_acc += lr;
+                if (e0 + k < total && lane + WAVE * q < m.d_real) lr_acc += lr;
                 vW[k][q] = atomic ? __fsub_rn(nW, oW[k][q]) : nW;
                 vG[k][q] = atomic ? __fsub_rn(nG, oG[k][q]) : nG;
                 vM[k][q] = atomic ? __fsub_rn(nM, oM[k][q]) : nM;
@@ -1011,8 +1014,8 @@ __device__ __forceinline__ void warp_update(double loss, const FitArgs &a, int u
         update_row_batched<NC>(a.usf, user, 1, a.m, diff, loss, loss, a.user_alpha, atomic, lane, lrb[2], lrc[2]);
     }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
-        double avg = pre_summed ? lrb[0] : sum_lr<NC, 3>(lrb, lrc, a.m.d, a.serial != 0, lane);
-        int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
+        double avg = pre_summed ? lrb[0] : sum_lr<NC, 3>(lrb, lrc, a.m.d_real, a.serial != 0, lane);
+        int cells = (a.m.d_real + 1) * (row_len(a.usf, user) + row_len(a.itf, pos) + row_len(a.itf, neg));
         avg /= (double)cells;
         apply_scale_step(a, sc, avg, lane);
     }
@@ -1045,8 +1048,8 @@ __device__ __forceinline__ void pair_update(double loss, const FitArgs &a, int u
         update_row_batched<NC>(a.usf, user, 1, a.m, I.v, loss, loss, a.user_alpha, atomic, lane, lrb[1], lrc[1]);
     }
     if (a.item_alpha != 0.0 || a.user_alpha != 0.0) {
-        double avg = pre_summed ? lrb[0] : sum_lr<NC, 2>(lrb, lrc, a.m.d, a.serial != 0, lane);
-        int cells = (a.m.d + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
+        double avg = pre_summed ? lrb[0] : sum_lr<NC, 2>(lrb, lrc, a.m.d_real, a.serial != 0, lane);
+        int cells = (a.m.d_real + 1) * (row_len(a.usf, user) + row_len(a.itf, item));
         avg /= (double)cells;
         apply_scale_step(a, sc, avg, lane);
     }

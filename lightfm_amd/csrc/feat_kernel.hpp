@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     // PYX:640-649 after an update: lr_sum = this lane's share of the cells' learning rates, T = entries updated
     auto scale_step = [&](double lr_sum, int T) {
         if constexpr (REG) {
-            const double avg = wave_sum(lr_sum) / ((double)(d + 1) * (double)max(T, 1));
+            const double avg = wave_sum(lr_sum) / ((double)(a.m.d_real + 1) * (double)max(T, 1));
             if (um != 2) reg.add(RegScale::log1p_f32((float)(alpha_i * avg)), RegScale::log1p_f32((float)(alpha_u * avg)));
         }
     };
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                             float nW, nG, nM;
                             double lr;
                             cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, st_ ? alpha_u : alpha_i, nW, nG, nM, lr);
-                            if constexpr (REG) lr_sum += lr;
+                            if constexpr (REG) lr_sum += c < a.m.d_real ? lr : 0.0;
                             publish(Wp + c, nW, oW, um);
                             publish(Gp + c, nG, oG, um);
                         }
@@ -744,5 +744,42 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
         if (c3) atomicAdd(a.counters + 3, c3);
     }
 }
+
+// host side: picks the instantiation of a loss (feat_kernels.hip: NC = 1, 2; feat_kernels_wide.hip: NC = 4)
+template <int NC>
+inline hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                                 int *grid_used, bool timed)
+{
+    void (*kernel)(FitArgs) = nullptr;
+    if (timed && a.item_alpha == 0.0 && a.user_alpha == 0.0) {  // profiling builds (per-phase shader clocks), the two BASELINE losses only
+        if (loss == LFM_LOSS_BPR_ID) kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, true>;
+        else if (loss == LFM_LOSS_WARP_KOS_ID) kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, true>;
+    }
+    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
+    if (!kernel && reg) switch (loss) {  // lazy L2 regularisation (device.hpp: RegScale)
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, true>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, true>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, true>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, true>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (!kernel) switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (cus > 0) {  // only resident workgroups: every wavefront runs its grid-stride loop from the start
+        const int per_cu = occupancy_cached(kernel, block, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, block, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_feat_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                                int *grid_used);
 
 }  // namespace lfm

@@ -11,7 +11,7 @@ namespace lfm {
 // (160 KiB LDS): many rows in flight per wavefront against many wavefronts.
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p)
 {
-    if (d < 4 || d > 128 || (d & 3) != 0 || max_sampled < 0) return false;
+    if (d < 4 || d > 256 || (d & 3) != 0 || max_sampled < 0) return false;
     FeatPlan g;
     g.ts = d + 4;
     g.pair_cap = 0;
@@ -83,44 +83,12 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     return true;
 }
 
-template <int NC>
-static hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
-                                 int *grid_used, bool timed)
-{
-    void (*kernel)(FitArgs) = nullptr;
-    if (timed && a.item_alpha == 0.0 && a.user_alpha == 0.0) {  // profiling builds (per-phase shader clocks), the two BASELINE losses only
-        if (loss == LFM_LOSS_BPR_ID) kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, true>;
-        else if (loss == LFM_LOSS_WARP_KOS_ID) kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, true>;
-    }
-    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
-    if (!kernel && reg) switch (loss) {  // lazy L2 regularisation (device.hpp: RegScale)
-    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, true>; break;
-    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, true>; break;
-    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, true>; break;
-    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, true>; break;
-    default: return hipErrorInvalidValue;
-    }
-    if (!kernel) switch (loss) {
-    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC>; break;
-    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC>; break;
-    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC>; break;
-    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC>; break;
-    default: return hipErrorInvalidValue;
-    }
-    if (cus > 0) {  // only resident workgroups: every wavefront runs its grid-stride loop from the start
-        const int per_cu = occupancy_cached(kernel, block, smem);
-        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
-    }
-    if (grid_used) *grid_used = grid;
-    kernel<<<grid, block, smem, st>>>(a);
-    return hipGetLastError();
-}
-
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used, bool timed)
 {
     if (a.m.d <= 64) return launch_feat_nc<1>(loss, a, grid, block, smem, st, cus, grid_used, false);
     if (a.m.d <= 128) return launch_feat_nc<2>(loss, a, grid, block, smem, st, cus, grid_used, timed);
+    if (a.m.d <= 256) return launch_fit_feat_wide(loss, a, grid, block, smem, st, cus, grid_used);  // feat_kernels_wide.hip
     return hipErrorInvalidValue;
 }
 

@@ -350,7 +350,8 @@ struct lfm_session {
     // model: [side][kind] with kind 0..5 = W,G,M,b,bG,bM ; side 0 item, 1 user
     DBuf<float> tab[2][6];
     int32_t n_feat[2] = {0, 0};
-    int32_t d = 0, adadelta = 0, max_sampled = 0;
+    int32_t d = 0, adadelta = 0, max_sampled = 0;  // d: floats per embedding row ON THE DEVICE (a multiple of 4, see create_session)
+    int32_t d_host = 0;                             // no_components: the row length of the caller's arrays
     float lr = 0, rho = 0, eps = 0;
     bool scoring_only = false;  // lfm_session_create_scoring: only W and b of both sides are resident
     DBuf<double> scales;      // [2]
@@ -455,6 +456,7 @@ struct lfm_session {
             m.n_feat[s] = n_feat[s];
         }
         m.d = d;
+        m.d_real = d_host;
         m.adadelta = adadelta;
         m.lr = lr;
         m.rho = rho;
@@ -482,6 +484,38 @@ static bool kind_used(const lfm_session *s, int kind)
 {
     if (s->scoring_only) return kind == 0 || kind == 3;  // scoring reads embeddings and biases only
     return s->adadelta || (kind != 2 && kind != 5);
+}
+
+// Embedding tables between the caller's [n_feat, no_components] arrays and the device's [n_feat, d] rows.  d =
+// no_components rounded up to a multiple of 4 floats, so that EVERY width runs the 16-byte-vectorised production
+// kernels (the reference's default is no_components = 10, LFM:191).  A padded component is 0 in W (and in adadelta's
+// M) and 1 in G: its product in a score is +0 (the sequential float32 sum is unchanged), every gradient of it is
+// loss * 0, so W stays 0 and G stays 1 whatever the schedule and the L2 penalty (0 * (1 + alpha lr) = 0); the
+// learning-rate average of the regularisation scales counts no_components cells (DModel::d_real).  The arrays that
+// come back are the caller's shape again.
+static int upload_table(lfm_session *s, int side, int kind, const float *host)
+{
+    DBuf<float> &t = s->tab[side][kind];
+    if (kind >= 3 || s->d == s->d_host) return t.upload(host, tab_count(s, side, kind));
+    const size_t rows = (size_t)s->n_feat[side];
+    LFM_TRY(t.alloc(rows * s->d));
+    if (!rows) return LFM_OK;
+    if (kind == 1) HIP_TRY(hipMemsetD32(t.p, 0x3f800000, rows * s->d));  // 1.0f
+    else HIP_TRY(hipMemset(t.p, 0, rows * s->d * sizeof(float)));
+    HIP_TRY(hipMemcpy2D(t.p, (size_t)s->d * sizeof(float), host, (size_t)s->d_host * sizeof(float),
+                        (size_t)s->d_host * sizeof(float), rows, hipMemcpyHostToDevice));
+    return LFM_OK;
+}
+
+static int download_table(lfm_session *s, int side, int kind, float *host)
+{
+    DBuf<float> &t = s->tab[side][kind];
+    if (kind >= 3 || s->d == s->d_host) return t.download(host);
+    const size_t rows = (size_t)s->n_feat[side];
+    if (rows)
+        HIP_TRY(hipMemcpy2D(host, (size_t)s->d_host * sizeof(float), t.p, (size_t)s->d * sizeof(float),
+                            (size_t)s->d_host * sizeof(float), rows, hipMemcpyDeviceToHost));
+    return LFM_OK;
 }
 
 static int validate_model(const lfm_model *m, bool scoring = false)
@@ -569,7 +603,8 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
     }
     s->n_feat[0] = model->n_item_feat;
     s->n_feat[1] = model->n_user_feat;
-    s->d = model->d;
+    s->d_host = model->d;
+    s->d = (model->d + 3) / 4 * 4;
     s->adadelta = model->adadelta;
     s->max_sampled = model->max_sampled;
     s->lr = model->lr;
@@ -590,7 +625,7 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
             s->tab[side][k].flags = (big_tables && ((table_alloc_mask() >> k) & 1)) ? table_alloc_flags() : 0;
     for (int side = 0; side < 2 && rc == LFM_OK; ++side)
         for (int k = 0; k < 6 && rc == LFM_OK; ++k)
-            if (kind_used(s, k)) guard(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
+            if (kind_used(s, k)) guard(upload_table(s, side, k, host_tab(model, side, k)));
     double sc[2] = {model->item_scale, model->user_scale}, zero[2] = {0.0, 0.0};
     if (rc == LFM_OK) guard(s->scales.upload(sc, 2));
     if (rc == LFM_OK) guard(s->reg_log.upload(zero, 2));
@@ -2180,13 +2215,13 @@ extern "C" int lfm_session_check_finite(lfm_session *s)
 extern "C" int lfm_session_sync_to_host(lfm_session *s, lfm_model *model)
 {
     if (!s || !model) return fail(LFM_EINVAL, "null argument");
-    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
+    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d_host)
         return fail(LFM_EINVAL, "model shape differs from the session's");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int side = 0; side < 2; ++side)
         for (int k = 0; k < 6; ++k)
-            if (kind_used(s, k)) LFM_TRY(s->tab[side][k].download(host_tab(model, side, k)));
+            if (kind_used(s, k)) LFM_TRY(download_table(s, side, k, host_tab(model, side, k)));
     double sc[2];
     LFM_TRY(s->scales.download(sc));
     model->item_scale = sc[0];
@@ -2197,14 +2232,14 @@ extern "C" int lfm_session_sync_to_host(lfm_session *s, lfm_model *model)
 extern "C" int lfm_session_load_model(lfm_session *s, const lfm_model *model)
 {
     if (!s || !model) return fail(LFM_EINVAL, "null argument");
-    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d)
+    if (model->n_item_feat != s->n_feat[0] || model->n_user_feat != s->n_feat[1] || model->d != s->d_host)
         return fail(LFM_EINVAL, "model shape differs from the session's");
     LFM_TRY(validate_model(model, s->scoring_only));
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int side = 0; side < 2; ++side)
         for (int k = 0; k < 6; ++k)
-            if (kind_used(s, k)) LFM_TRY(s->tab[side][k].upload(host_tab(model, side, k), tab_count(s, side, k)));
+            if (kind_used(s, k)) LFM_TRY(upload_table(s, side, k, host_tab(model, side, k)));
     double sc[2] = {model->item_scale, model->user_scale};
     LFM_TRY(s->scales.upload(sc, 2));
     return LFM_OK;
@@ -2270,7 +2305,10 @@ extern "C" int lfm_session_representations(lfm_session *s, int32_t side, const l
     LFM_TRY(dbias.alloc((size_t)features->rows));
     HIP_TRY(launch_rep_rows(f.view(), s->tab[side][0].p, s->tab[side][3].p, s->d, s->d, demb.p, s->stream, 0, dbias.p));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    LFM_TRY(demb.download(embeddings));
+    if (s->d == s->d_host) LFM_TRY(demb.download(embeddings));
+    else if (features->rows)  // the caller's rows are no_components wide
+        HIP_TRY(hipMemcpy2D(embeddings, (size_t)s->d_host * sizeof(float), demb.p, (size_t)s->d * sizeof(float),
+                            (size_t)s->d_host * sizeof(float), (size_t)features->rows, hipMemcpyDeviceToHost));
     return dbias.download(biases);
 }
 

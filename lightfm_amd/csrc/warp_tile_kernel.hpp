@@ -635,15 +635,15 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             oWr[q][2] = Ur;
                             cell_math(Pr, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, ia,
                                       nWr[q][0], nGr[q][0], nMr[q][0], lr);
-                            if (REG && c < d) lr_acc += lr;
+                            if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);  // one cell's float64 chain at a time: registers
                             cell_math(Nr, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, ia,
                                       nWr[q][1], nGr[q][1], nMr[q][1], lr);
-                            if (REG && c < d) lr_acc += lr;
+                            if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
                             cell_math(Ur, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, ua,
                                       nWr[q][2], nGr[q][2], nMr[q][2], lr);
-                            if (REG && c < d) lr_acc += lr;
+                            if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
                         }
                         float bnW, bnG, bnM;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         if constexpr (REG) {
                             // avg_learning_rate of PYX:640-646: the 3 (d + 1) cells of three identity rows
                             if (lane < 3) lr_acc += lr;
-                            avg_lr[gg] = unif((float)(wave_sum(lr_acc) / (double)(3 * (d + 1))));
+                            avg_lr[gg] = unif((float)(wave_sum(lr_acc) / (double)(3 * (a.m.d_real + 1))));
                         }
                         // keep the arithmetic above one block: nothing of it may sink below a publication
 #pragma unroll

@@ -105,6 +105,12 @@ FROZEN = [
     ("d32-wide-rows", 80, 60, 1500, 32, 10, 0, "wide", "id", False),
     ("d64-identity", 150, 100, 3000, 64, 10, 0, "id", "id", True),
     ("d20-user-tags-only", 90, 70, 1200, 20, 12, 5, "id", "tagsonly", False),
+    # widths that are no multiple of 4 (rows padded on the device) and 128 < d <= 256 (four components per lane)
+    ("d10-tags", 150, 100, 3000, 10, 10, 0, "tags", "id", True),
+    ("d30-tagsonly-both", 120, 90, 2500, 30, 10, 0, "tagsonly", "tags", False),
+    ("d50-tags", 100, 80, 2000, 50, 10, 0, "tags", "id", False),
+    ("d200-tags", 100, 80, 2000, 200, 10, 0, "tags", "id", True),
+    ("d256-tagsonly-both", 60, 50, 900, 256, 10, 0, "tagsonly", "tags", False),
 ]
 
 
@@ -135,6 +141,7 @@ def test_frozen_weights_samples_exact(fast, case, loss, kernel):
     assert options.last_counters == o.counters
     assert o.counters[2] > 0, "no update: the case does not exercise the update path"
     H.assert_states_equal(a, st, exact=True)
+    assert options.last_kernel_used == (0 if kernel == "generic" else 2), (kernel, options.last_kernel_used)
 
 
 SEQ = [
@@ -144,6 +151,9 @@ SEQ = [
     ("d20-tags-ms20", 20, 20, "tags", "tags"),
     ("d32-wide", 32, 6, "wide", "id"),
     ("d128-identity", 128, 10, "id", "id"),
+    ("d10-tags", 10, 10, "tags", "id"),
+    ("d50-tags-both", 50, 10, "tags", "tags"),
+    ("d200-tags", 200, 10, "tags", "id"),
 ]
 
 
@@ -177,6 +187,7 @@ def test_one_interaction_per_launch_matches_the_oracle(fast, case, loss, update_
             assert np.array_equal(neg, o.neg)
         assert options.last_counters == o.counters
     assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    assert options.last_kernel_used == 2, "the row-stream kernels did not run"
     if update_mode == 1 and loss in ("warp", "warp-kos"):
         H.assert_states_equal(a, b, exact=True)
     elif update_mode == 1:

@@ -97,6 +97,12 @@ FROZEN = [
     ("longrows", 12, 6000, 30000, 64, 10, 0, False),
     ("two-items", 50, 2, 60, 64, 10, 0, False),
     ("d256-ms10", 60, 90, 1500, 256, 10, 0, False),
+    # widths that are no multiple of 4 (the reference's default is 10): rows padded on the device, production kernels
+    ("d10-ms10", 150, 100, 3000, 10, 10, 0, True),
+    ("d30-ms10", 150, 100, 3000, 30, 10, 0, False),
+    ("d50-ms12", 90, 70, 1200, 50, 12, 0, True),
+    ("d200-ms10", 60, 90, 1500, 200, 10, 0, False),
+    ("d1-ms5", 40, 30, 400, 1, 5, 0, False),
 ]
 
 
@@ -106,7 +112,7 @@ def test_frozen_weights_samples_exact(fast, case, kernel):
     from lightfm_amd.options import options
     _, nu, ni, nnz, d, ms, fb, ratings = case
     ng = {"generic": 0, "tile-auto": 0, "tile-ng4": 4, "tile-ng4-regs": 4 | REGS, "tile-ng2": 2, "tile-ng1": 1}[kernel]
-    if ((ng & 7) == 4 and d > 64) or (ng == 2 and d > 128):
+    if ((ng & 7) == 4 and d > 64) or ((ng & 7) == 2 and d > 128) or ((ng & 7) == 1 and d > 128):
         pytest.skip("row wider than the lane group covers: the session falls back to fewer per wave")
     coo = H.make_interactions(nu, ni, nnz, seed=17, ratings=ratings, zipf=0.6)
     rng = np.random.RandomState(9)
@@ -127,11 +133,17 @@ def test_frozen_weights_samples_exact(fast, case, kernel):
     assert options.last_counters == o.counters
     assert o.counters[2] > 0 or ni <= 2, "no violator found: the case does not exercise the update path"
     H.assert_states_equal(a, st, exact=True)
+    dp = (d + 3) // 4 * 4  # floats per row on the device
+    if kernel == "generic":
+        assert options.last_kernel_used == 0
+    elif kernel == "tile-auto":  # every width runs a production kernel: the tile kernel up to 128, the row-stream kernels to 256
+        assert options.last_kernel_used == (1 if dp <= 128 else 2), (d, options.last_kernel_used)
 
 
 SEQ = [("d64-adagrad", 64, "adagrad", 10), ("d32-adadelta", 32, "adadelta", 6),
        ("d128-adagrad", 128, "adagrad", 10), ("d20-adagrad", 20, "adagrad", 20),
-       ("d200-adagrad", 200, "adagrad", 10)]
+       ("d200-adagrad", 200, "adagrad", 10), ("d10-adagrad", 10, "adagrad", 10), ("d50-adagrad", 50, "adagrad", 10),
+       ("d30-adadelta", 30, "adadelta", 10)]
 
 
 @pytest.mark.parametrize("case", SEQ, ids=[c[0] for c in SEQ])
@@ -146,7 +158,7 @@ def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode, ng):
     one float32 ulp of the largest weight."""
     from lightfm_amd.options import options
     _, d, sched, ms = case
-    if ((ng & 7) == 4 and d > 64) or (ng == 2 and d > 128):
+    if ((ng & 7) == 4 and d > 64) or ((ng & 7) in (1, 2) and d > 128):
         pytest.skip("row wider than the lane group covers")
     coo = H.make_interactions(40, 30, 260, seed=3, ratings=True)
     rng = np.random.RandomState(4)
@@ -163,6 +175,7 @@ def test_one_interaction_per_launch_is_bit_exact(fast, case, update_mode, ng):
         assert np.array_equal(neg, o.neg)
         assert options.last_counters == o.counters
     assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    assert options.last_kernel_used == 1 and options.last_tile_ng == (ng & 7), "the forced tile kernel did not run"
     if update_mode == 1:
         H.assert_states_equal(a, b, exact=True)
     else:
