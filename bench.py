@@ -16,33 +16,35 @@ offline; lightfm_amd/synthetic.py):
   c5shard       one GPU's row shard of configs[4]: 6.25 M users x 10 M items x 250 M interactions,
                 warp-kos (k=5, n=10), no_components=128, item-feature CSR of 1 M embedding rows, avg 8 nnz
 
-A "step" is `epochs_per_step` EPOCHS of ONE continuing training run (reported in `config`; chosen
-during warm-up so that the K timed steps last >= ~6 s): every epoch is what LightFM.fit_partial
-does per epoch -- the keyed on-device shuffle, the kernel seeds, one pass of the hot path over all
-interactions through the C ABI (include/lfm_hip.h: lfm_session_epoch), the on-device finite
-check.  Inputs (weights, COO, positives lookup) are resident in HBM before the timed region.
+A "step" is ONE EPOCH of a FRESH fit (`--epochs-per-step` > 1 groups epochs): W warm-up epochs (the first ramps
+the concurrency up), then exactly K timed epochs between barrier + synchronisation -- with the driver's
+`--steps 20 --warmup 5` epochs 6..25 of a model that starts from its random initialisation, the regime a user's
+`LightFM.fit` runs in (nearly every interaction still finds a violator and updates).  At N = 1 the measurement is
+repeated on three fresh fits and `value` is the MEDIAN fit (`config.fresh_fits` lists all three); `config` also
+carries `epochs_2_11` (the same fits' epochs 2..11) and `steady_state` (the last fit continued for a few seconds:
+the regime of round 4's headline, fewer updates per interaction).  Every epoch is what LightFM.fit_partial does
+per epoch -- the keyed on-device shuffle, the kernel seeds, one pass of the hot path over all interactions through
+the C ABI (include/lfm_hip.h: lfm_session_epoch), the on-device finite check.  Inputs (weights, COO, positives
+lookup) are resident in HBM before the timed region.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU).  c2 / c3 default to STRONG scaling:
 ONE ML-20M-shaped COO sharded row-wise (by user) over the N ranks, user tables partitioned (a
 rank allocates only its own users' rows), item tables replicated and merged by RCCL all-reduce
 of their deltas at the cadence of lightfm_amd/distributed.py (merge_schedule), inside the timed
 region; `--scaling weak` gives every rank its own full-size shard instead.  c4shard / c5shard
-are per-GPU shards by definition (weak).  torch.distributed (gloo) is used only to hand the RCCL
-unique id to the ranks, for the barriers and for the max-over-ranks of the elapsed time.
+are per-GPU shards by definition (weak); `--item-tables owner` runs them with owner-sharded item tables
+(HIP IPC peer mappings, no merges).  torch.distributed (gloo) is used only to hand the RCCL
+unique id (or the IPC handles) to the ranks, for the barriers and for the max-over-ranks of the elapsed time.
 
-Besides the contract fields the JSON line carries `roofline` (dominant kernel, algorithmic bytes
-per SURVEY.md 8(d), HIP-event launch times), `cpu_baseline` (the reference's own compiled
-Cython/OpenMP path on this box's host cores, N = 1 only), `quality` (precision@10 of this
-backend and of the reference trained on the same data, N = 1, c2 / c3) and `end_to_end_fit`
-(LightFM.fit through the public API, uploads and downloads included).
-
-At N = 1 with no --config the line also carries `extra_configs`: short timed legs of the other
-BASELINE shapes (c3, c4shard, and c5shard at its full per-GPU size) run after c2 in the same
-process, each with its own `value` and `roofline` (--no-extra skips them; --extra picks).
-`roofline.traffic` is the HBM traffic per launch of the dominant kernel taken from the committed
-rocprofv3 --pmc summary of the same command (profiles/traffic.json names the source file per
-config and kernel; counters cannot be collected inside this run), null when the committed
-summary is of another kernel.
+The line stays below 8 KB (the driver keeps `config`, `roofline`, `cpu_baseline` and a 9 KB tail of stdout): numbers
+are rounded to 5 significant digits, prose lives in profiles/README.md ("bench line").  Besides the contract fields:
+`roofline` (dominant kernel, algorithmic bytes per SURVEY.md 8(d), HIP-event launch times, committed counter
+traffic), `cpu_baseline` (the reference's own compiled Cython/OpenMP path on this box's host cores, N = 1 only) and,
+inside `config`: `quality` (precision@10 of this backend and of the reference on the same data), `end_to_end_fit`
+(LightFM.fit through the public API, uploads and downloads included) and `legs` -- short measurements of the
+other BASELINE shapes (c3, c4shard, c5shard at its full per-GPU size), of the reference's DEFAULT width
+(`c2_d10`: no_components = 10, rows padded to 12 floats on the device) and of `predict_ranks` (all users x all items
+of the ML-20M shape on the matrix cores), each with its own value, roofline and cpu baseline (--no-extra skips them).
 
 Prints ONE JSON line (rank 0).
 """
@@ -61,6 +63,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak, /opt/skills/guides/cdna_hip_programming.md (quick-reference table)
 ATOMIC_PEAK_GOPS = 320.0  # global_atomic_add_f32 lanes per second, measured (tools/membench.hip)
 MAX_SAMPLED = 10
 KNOBS = ("update_mode", "first_batch", "launches_per_epoch", "max_waves", "warp_kernel", "feat_kernel", "debug",
@@ -84,6 +87,27 @@ CONFIGS = {
                           "items x %d interactions, loss=warp-kos (k=5, n=10), no_components=128, item-feature "
                           "CSR over 1M embedding rows, avg 8 nnz/row"),
 }
+
+
+def rnd(x, digits=5):
+    """The line's numbers at 5 significant digits (it has to stay below 8 KB)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        if x == 0.0:
+            return 0.0
+        return float("%.*g" % (digits, x))
+    if isinstance(x, (np.floating,)):
+        return rnd(float(x), digits)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: rnd(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rnd(v, digits) for v in x]
+    return x
 
 
 def rep_bytes(f, d):
@@ -181,11 +205,11 @@ def extra_cpu_leg(name, env, pieces):
     own workload over the full item-side tables."""
     train, feats, n_users, n_items = pieces["train"], pieces["feats"], pieces["n_users"], pieces["n_items"]
     frac = {"c3": 16, "c4shard": 50, "c5shard": 200}.get(name, 50)
+    name = name if name in CONFIGS else "c2"
     nu = max(1000, n_users // frac)
     sub = head_users(train, nu, n_items)
     cpu, _ = reference_leg(name, sub, None, feats, 2, env.log,
-                           "the first %d users' %d interactions of this workload (1/%d row sub-sample) over the full "
-                           "item-side tables" % (nu, sub.nnz, frac))
+                           "first %d users (%d interactions, 1/%d row sub-sample), full item side" % (nu, sub.nnz, frac))
     return cpu
 
 
@@ -217,9 +241,7 @@ def reference_leg(cfg_name, train, test, feats, epochs, log, sample_note, thread
         % (threads, train.nnz / native, train.nnz / wall, time.time() - t0))
     cpu = {"value": train.nnz / native, "unit": "interactions/s", "cores": threads, "kind": "reference",
            "with_host_prologue": train.nnz / wall, "host_cpus": ncpu,
-           "sample": sample_note + "; reference v1.17 Cython/OpenMP build (-O2 -ffast-math -march=x86-64-v3 "
-                     "-fopenmp), native epoch call only (with_host_prologue adds its per-epoch tocsr + "
-                     "shuffle), mean of epochs 2..%d" % epochs}
+           "sample": sample_note + "; native epoch call, mean of epochs 2..%d" % epochs}
     p_ref = precision_at_10(m, train, test, feats) if test is not None else None
     return cpu, p_ref
 
@@ -249,16 +271,21 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--fits", type=int, default=3, help="N = 1: fresh fits measured; value = the median fit")
+    ap.add_argument("--steady-seconds", type=float, default=4.0, help="N = 1: the last fit continued this long (config.steady_state)")
+    ap.add_argument("--no-components", type=int, default=None, help="override the config's no_components")
+    ap.add_argument("--item-tables", choices=("replicated", "owner"), default="replicated",
+                    help="N > 1, identity WARP configs: owner-sharded item tables over HIP IPC instead of RCCL merges")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="default: c2, followed at N = 1 by short legs of c3 / c4shard / c5shard (extra_configs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs of the default run")
-    ap.add_argument("--extra", default="c3,c4shard,c5shard", help="which extra legs (comma separated)")
+    ap.add_argument("--extra", default="ranks,c2_d10,c3,c4shard,c5shard", help="which extra legs (comma separated)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the interactions (debug)")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="debug, N = 1: run rank 0's row shard of a K-way strong-scaling split on this one GPU")
-    ap.add_argument("--epochs-per-step", type=int, default=0, help="0 = calibrate so the timed region is >= ~6 s")
+    ap.add_argument("--epochs-per-step", type=int, default=1, help="epochs of the fresh fit per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-fit", action="store_true")
@@ -293,19 +320,41 @@ class Env(object):
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale, want_test, early_epochs=3):
-    """Builds the workload `name`, makes its inputs resident, warms up, times `steps` steps and returns
-    (contract fields + roofline of this config, the pieces the reporting-only legs need)."""
+def kernel_label(loss, d, stats_last, reg, options):
+    """Name of the epoch kernel a run's launches used (as rocprofv3 prints it)."""
     from lightfm_amd import _native as N
-    from lightfm_amd._lightfm_fast import CSRMatrix, make_opts
+    ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
+    dp = (d + 3) // 4 * 4
+    if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):
+        return "fit_warp_tile_ahead_kernel<10, false>"
+    if used == 1:
+        return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
+            64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
+            "true" if reg else "false")
+    if used == 2:
+        return "fit_feat_kernel<%d, %d, false, %s>" % (N.LOSS_IDS[loss], 1 if dp <= 64 else (2 if dp <= 128 else 4),
+                                                       "true" if reg else "false")  # <loss id, NC, TIMED, REG>
+    return "fit_%s_kernel (generic)" % loss.replace("-", "_")
+
+
+def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_seconds=0.0, scale=1.0, want_test=False,
+               d_override=None):
+    """Builds the workload `name`, makes its inputs resident and measures `fits` FRESH fits: `warmup` untimed steps, then
+    exactly `steps` steps between barriers (a step = `epochs_per_step` epochs).  Returns (contract fields + roofline of
+    the median fit, the pieces the reporting-only legs need)."""
+    from lightfm_amd import _native as N
     from lightfm_amd.distributed import DistributedFit, MergePolicy
-    from lightfm_amd.lightfm import LightFM, _Session
+    from lightfm_amd.lightfm import LightFM
     from lightfm_amd.options import options
     args, rank, world, dist, log = env.args, env.rank, env.world, env.dist, env.log
     cfg = CONFIGS[name]
     scaling = args.scaling or cfg["default_scaling"]
     if world == 1:
         scaling = cfg["default_scaling"]
+        if args.emulate_shard <= 1:
+            pass
+    else:
+        fits = 1  # one communicator per process
     policy = MergePolicy()
     if args.merge_mode:
         policy.mode = args.merge_mode
@@ -314,6 +363,7 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
     if args.merge_max:
         policy.merge_max = args.merge_max
     policy.overlap = bool(args.merge_overlap)
+    policy.sparse = not args.merge_dense
     dev_name, cus, hbm = N.device_info(env.local_rank)
 
     t0 = time.time()
@@ -337,187 +387,200 @@ def run_config(name, env, steps, warmup, epochs_per_step, target_seconds, scale,
         train, _ = local_shard(train, 0, args.emulate_shard, rebase=True)
         n_users, global_n, test = train.shape[0], train.nnz, None
     log("%s: %d interactions (%d x %d) ready in %.1fs" % (name, train.nnz, n_users, n_items, time.time() - t0))
-    loss, d = cfg["loss"], cfg["d"]
-    n_item_feat = feats.shape[1] if feats is not None else n_items
+    loss, d = cfg["loss"], (d_override or cfg["d"])
+    n_local = train.nnz
+    eps = max(1, epochs_per_step)
+    rows = np.ascontiguousarray(train.row, dtype=np.int32)
+    owner = args.item_tables == "owner" and world > 1 and feats is None and loss == "warp"
+
+    def all_max(x):
+        if world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def all_sum(x):
+        if world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0])
 
     # The epoch loop is the product's: lightfm_amd.distributed.DistributedFit (at N = 1 an epoch of it is exactly an
     # epoch of LightFM.fit_partial: device shuffle, seeds, one lfm_session_epoch, the on-device finite check; at
     # N > 1 segments + RCCL merges of the replicated tables, hot rows at their own cadence).  This rank's shard
     # carries LOCAL user ids, and only its own users' rows exist anywhere (host or device).
-    model = LightFM(no_components=d, loss=loss, random_state=10 + rank, max_sampled=MAX_SAMPLED,
-                    item_alpha=args.item_alpha, user_alpha=args.user_alpha)
-    policy.sparse = not args.merge_dense
-    fit = DistributedFit(model, train, rank, world, device=env.local_rank, dist=dist, policy=policy,
-                         global_n=global_n, item_features=feats, local_ids=True)
-    session = fit.session
-    hot = fit.hot[0]
-    rows = np.ascontiguousarray(train.row, dtype=np.int32)
-    log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))
+    runs, steady, fit, model = [], None, None, None
+    for f in range(max(1, fits)):
+        if fit is not None:
+            fit.close()
+        model = LightFM(no_components=d, loss=loss, random_state=10 + rank + 100 * f, max_sampled=MAX_SAMPLED,
+                        item_alpha=args.item_alpha, user_alpha=args.user_alpha)
+        fit = DistributedFit(model, train, rank, world, device=env.local_rank, dist=dist, policy=policy,
+                             global_n=global_n, item_features=feats, local_ids=True,
+                             item_tables="owner" if owner else "replicated")
+        if f == 0:
+            log("%s: setup done in %.1fs on %s (%d CUs)" % (name, time.time() - t0, dev_name, cus))
+        stats, walls = [], []
 
-    n_local = train.nnz
-    all_stats = []
+        def epoch():
+            t1 = time.perf_counter()
+            try:
+                stats.extend(fit.epoch())  # (returns with the rank's stream drained)
+            except ValueError:
+                raise SystemExit("model diverged")
+            walls.append(time.perf_counter() - t1)
 
-    def epoch():
-        try:
-            all_stats.extend(fit.epoch())
-        except ValueError:
-            raise SystemExit("model diverged")
+        def barrier():
+            if world > 1:
+                fit.barrier()
+                dist.barrier()
 
-    def barrier():
-        if world > 1:
-            fit.barrier()
-            dist.barrier()
+        for _ in range(warmup * eps):
+            epoch()
+        barrier()
+        n_warm = len(stats)
+        merges0, mbytes0 = fit.merges, fit.merge_bytes
+        t_start = time.perf_counter()
+        for _ in range(steps * eps):
+            epoch()
+        barrier()
+        elapsed = all_max(time.perf_counter() - t_start)
+        timed = stats[n_warm:]
+        total_pos = all_sum(float(sum(st.counters[0] for st in timed)))
+        run = dict(elapsed=elapsed, stats=timed, total_pos=total_pos, value=total_pos / elapsed,
+                   merges=fit.merges - merges0, merge_bytes=fit.merge_bytes - mbytes0)
+        if world == 1 and len(walls) >= 11:  # epochs 2..11 of this fresh fit (wall time per epoch, every epoch ends synchronised)
+            run["epochs_2_11"] = 10.0 * n_local / sum(walls[1:11])
+        runs.append(run)
+        log("%s fit %d: %.4g interactions/s over epochs %d..%d" % (name, f, run["value"], warmup * eps + 1, (warmup + steps) * eps))
+    # steady state: the last fit continued (round 4's headline regime: most interactions no longer update)
+    if steady_seconds > 0 and world == 1:
+        t1 = time.perf_counter()
+        n_ep = 0
+        while time.perf_counter() - t1 < 0.4 * steady_seconds:
+            fit.epoch()
+            n_ep += 1
+        first = (warmup + steps) * eps + n_ep + 1
+        t1 = time.perf_counter()
+        ss, n_ss = [], 0
+        while time.perf_counter() - t1 < 0.6 * steady_seconds:
+            ss.extend(fit.epoch())
+            n_ss += 1
+        dt = time.perf_counter() - t1
+        pos = float(sum(st.counters[0] for st in ss))
+        steady = {"value": pos / dt, "epochs": "%d..%d" % (first, first + n_ss - 1), "ms_per_epoch": dt * 1e3 / max(1, n_ss),
+                  "updates_per_interaction": float(sum(st.counters[2] for st in ss)) / max(1.0, pos),
+                  "kernel_frac": algorithmic_frac(loss, ss, d, feats, rows, n_users, n_local * n_ss)}
 
-    # warm-up: the first epoch ramps the concurrency up.  The epochs right after it are timed on their own
-    # (`early_epochs`: the regime of a short fit -- what the quality leg and the CPU baseline run -- where nearly
-    # every interaction still finds a violator and updates); their duration also calibrates epochs_per_step.
-    eps = max(1, epochs_per_step)
-    epoch()
-    barrier()
-    all_stats.clear()
-    t1 = time.perf_counter()
-    for _ in range(early_epochs):
-        epoch()
-    barrier()
-    t_early = time.perf_counter() - t1
-    t_epoch = t_early / early_epochs
-    early_pos = float(sum(st.counters[0] for st in all_stats))
-    early = {"epochs": "2..%d of the same run" % (1 + early_epochs), "seconds": t_early,
-             "updates_per_interaction": float(sum(st.counters[2] for st in all_stats)) / max(1.0, early_pos)}
-    if epochs_per_step <= 0:
-        eps = int(min(64, max(1, math.ceil(target_seconds / max(1, steps) / max(t_epoch, 1e-4)))))
-        if world > 1:
-            import torch
-            te = torch.tensor([eps], dtype=torch.int64)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            eps = int(te[0])
-    for _ in range(max(0, warmup * eps - 1 - early_epochs)):
-        epoch()
-    barrier()  # lfm_session_epoch / check_finite synchronise the session's stream before returning
-    all_stats.clear()
-    merges0, mbytes0 = fit.merges, fit.merge_bytes
-    epoch0 = int(getattr(model, "_trained_interactions", 0)) // max(1, global_n)
-    t_start = time.perf_counter()
-    for _ in range(steps * eps):
-        epoch()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    stats = list(all_stats)
-    local_pos = float(sum(s.counters[0] for s in stats))
-    if world > 1:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        cnt = torch.tensor([local_pos], dtype=torch.float64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_pos = float(cnt[0])
-        e = torch.tensor([early_pos], dtype=torch.float64)
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        early_pos = float(e[0])
-        e = torch.tensor([early["seconds"]], dtype=torch.float64)
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        early["seconds"] = float(e[0])
-    else:
-        total_pos = local_pos
-    early["value"] = early_pos / early["seconds"]
-    early["unit"] = "interactions/s"
+    order = sorted(range(len(runs)), key=lambda q: runs[q]["value"])
+    med = runs[order[len(order) // 2]]
+    stats, elapsed, total_pos = med["stats"], med["elapsed"], med["total_pos"]
 
-    # roofline of the dominant kernel (the epoch kernel of the loss), this rank
-    kernel_s = sum(s.kernel_ms for s in stats) / 1e3
-    counters = [sum(s.counters[i] for s in stats) for i in range(4)]
-    pos_csr_lens = np.bincount(rows, minlength=n_users)
-    lens = pos_csr_lens[rows]
-    mean_probe = float(np.mean(8 + 4 * np.ceil(np.log2(lens + 1.0))))
-    f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
+    # roofline of the dominant kernel (the epoch kernel of the loss), this rank, the median fit
+    kernel_s = sum(st.kernel_ms for st in stats) / 1e3
+    counters = [sum(st.counters[i] for st in stats) for i in range(4)]
     n_epochs = steps * eps
-    n_examples = float(n_local) * n_epochs
-    alg = algorithmic_bytes(loss, counters, d, 1.0, f_i, mean_probe, n_examples,
-                            mean_kos_pos=float(np.mean(np.minimum(10, lens))))
-    launches = sum(int(s.launches) for s in stats)
-    ng, used = int(stats[-1].tile_ng), int(stats[-1].kernel_used)
+    alg = algorithmic_total(loss, counters, d, feats, rows, n_users, float(n_local) * n_epochs)
+    f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
+    launches = sum(int(st.launches) for st in stats)
     reg = bool(args.item_alpha or args.user_alpha)
-    if used == 1 and int(getattr(stats[-1], "tile_ahead", 0)):
-        kernel_name = "fit_warp_tile_ahead_kernel<10, false>"
-    elif used == 1:
-        kernel_name = "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
-            64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
-            "true" if reg else "false")
-    elif used == 2:
-        kernel_name = "fit_feat_kernel<%d, %d, false, %s>" % (N.LOSS_IDS[loss], 1 if d <= 64 else 2,
-                                                              "true" if reg else "false")  # <loss id, NC, TIMED, REG>
-    else:
-        kernel_name = "fit_%s_kernel (generic)" % loss.replace("-", "_")
+    kernel_name = kernel_label(loss, d, stats[-1], reg, options)
     achieved = alg / kernel_s / 1e9
-    traffic, traffic_source, traffic_extra = committed_traffic(name, kernel_name, counters[0] / max(1, launches))
+    traffic, traffic_source, traffic_extra = committed_traffic(name if d_override is None else name + "_d%d" % d, kernel_name,
+                                                               counters[0] / max(1, launches))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
                 "algorithmic_bytes_per_interaction": alg / max(1.0, counters[0]),
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches / n_epochs,
-                "avg_launch_note": "HIP events around each epoch's launches on the session's stream / launches.  Consecutive "
-                                   "full-size launches alternate between two streams and overlap by the earlier one's draining "
-                                   "tail: rocprofv3's per-kernel durations include that wait; the union of their intervals / "
-                                   "launches (profiles/*_kernel_stats.txt) is the comparable figure",
                 "kernel_time_fraction_of_step": kernel_s / elapsed,
-                "interactions_per_wavefront_pass": ng, "interactions_in_flight": int(stats[-1].in_flight),
+                "interactions_in_flight": int(stats[-1].in_flight),
                 "draws_per_interaction": counters[1] / max(1.0, counters[0]),
                 "updates_per_interaction": counters[2] / max(1.0, counters[0])}
     if traffic is not None:
         roofline["traffic_over_algorithmic"] = traffic / (alg / launches)
-        roofline["traffic_profiled_run"] = traffic_extra
-
+        if "traffic_over_algorithmic_profiled" in traffic_extra:
+            roofline["traffic_over_algorithmic_profiled"] = traffic_extra["traffic_over_algorithmic_profiled"]
     # Second ceiling of the update-heavy configurations: every updated cell is published with one
     # global_atomic_add_f32 per table (W, G), and the chip executes a fixed ~320 G of them per second
-    # whatever the table size or allocation (tools/membench.hip, profiles/r02_membench.txt: 10 G
-    # 128-B line-ops/s = 1.28 TB/s of atomic payload; round 3: the rate is per DWORD, a 64-bit CAS or a
-    # float64 add costs two -- profiles/r03_membench_atomics.txt).  Reported next to the HBM roofline.
-    n_upd = counters[2] if loss != "logistic" else n_examples
+    # (tools/membench.hip, profiles/r02_membench.txt; profiles/README.md "bench line").
+    n_upd = counters[2] if loss != "logistic" else float(n_local) * n_epochs
     rows_upd = (1.0 + 2.0 * f_i) if loss != "logistic" else (1.0 + f_i)
     atomics = float(n_upd) * rows_upd * (d + 1) * 2.0
     roofline["atomic_unit"] = {"achieved": atomics / kernel_s / 1e9, "peak": ATOMIC_PEAK_GOPS, "unit": "G float atomics/s",
                                "frac": atomics / kernel_s / 1e9 / ATOMIC_PEAK_GOPS,
-                               "atomics_per_interaction": atomics / max(1.0, counters[0]),
-                               "peak_source": "measured on this chip by tools/membench.hip (profiles/r02_membench.txt)"}
-    if options.feat_kernel == 2 and used == 2:  # profiling build of the row-stream kernel
-        ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
+                               "atomics_per_interaction": atomics / max(1.0, counters[0])}
+    if options.feat_kernel == 2 and int(stats[-1].kernel_used) == 2:  # profiling build of the row-stream kernel
+        ph = np.sum([list(st.phase_cycles) for st in stats], axis=0).astype(np.float64)
         roofline["phase_cycles_per_interaction"] = dict(zip(
             ("sampling", "entry_lists", "rep_gather", "rep_reduce", "score", "update_gather", "update_math_publish",
              "tail"), [round(float(x) / max(1.0, counters[0]), 1) for x in ph]))
-    if options.warp_kernel == 2 and used == 1:  # profiling build: per-phase shader cycles per wavefront pass
-        ph = np.sum([list(s.phase_cycles) for s in stats], axis=0).astype(np.float64)
-        passes = counters[0] / float(max(1, ng))
+    if options.warp_kernel == 2 and int(stats[-1].kernel_used) == 1:  # profiling build: per-phase shader cycles per wavefront pass
+        ph = np.sum([list(st.phase_cycles) for st in stats], axis=0).astype(np.float64)
+        passes = counters[0] / float(max(1, int(stats[-1].tile_ng)))
         roofline["phase_cycles_per_pass"] = dict(zip(
             ("head", "gather", "score", "lookup", "acc_loads", "update", "tail", "unused"),
             [round(float(x) / passes, 1) for x in ph]))
-    session.close()
+    hot = fit.hot[0]
+    fit.close()
 
     par = ("1 GPU" if world == 1 else
-           "%s scaling over %d GPUs: %s; item tables merged over RCCL (%s; %s), %.1f merges per epoch, %.1f MB "
-           "exchanged per rank and merge"
+           "%s scaling over %d GPUs: %s; %s"
            % (scaling, world,
               "one COO row-sharded by user" if scaling == "strong" else "every rank its own full-size row shard",
-              policy.mode, "dense all-reduce, synchronous" if args.merge_dense else
-              "all-reduce over the compacted union of the rows touched since the last merge%s%s"
-              % (", overlapped with the next segment" if policy.overlap else ", synchronous",
-                 "; %d hot rows merged every %d interactions" % (len(hot), world << 17) if len(hot) else ""),
-              (fit.merges - merges0) / float(n_epochs),
-              (fit.merge_bytes - mbytes0) / 1e6 / max(1, fit.merges - merges0)))
+              "item tables owner-sharded over HIP IPC peer mappings (no replicas, no merges)" if owner else
+              "item tables merged over RCCL (%s; %s), %.1f merges per epoch, %.1f MB exchanged per rank and merge"
+              % (policy.mode, "dense all-reduce, synchronous" if args.merge_dense else
+                 "all-reduce over the compacted union of the rows touched since the last merge (all rows once a union "
+                 "covered 90 %% of them)%s%s"
+                 % (", overlapped with the next segment" if policy.overlap else ", synchronous",
+                    "; %d hot rows merged every %d interactions" % (len(hot), world << 17) if len(hot) else ""),
+                 med["merges"] / float(n_epochs), med["merge_bytes"] / 1e6 / max(1, med["merges"]))))
+    first_timed = warmup * eps + 1
     result = {
         "value": total_pos / elapsed, "unit": "interactions/s", "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed * 1e3 / steps,
         "config": {"workload": cfg["label"] % (global_n if scaling == "strong" or world == 1 else n_local),
                    "name": name, "epochs_per_step": eps, "ms_per_epoch": elapsed * 1e3 / n_epochs,
-                   "timed_epochs": "epochs %d..%d of one continuing training run" % (epoch0 + 1, epoch0 + n_epochs),
+                   "timed_epochs": "%d..%d of a fresh fit" % (first_timed, first_timed + n_epochs - 1),
                    "parallelism": par, "device": dev_name},
-        "roofline": roofline, "scaling": scaling, "early_epochs": early,
+        "roofline": roofline, "scaling": scaling,
     }
+    if d_override is not None:
+        result["config"]["workload"] = result["config"]["workload"].replace("no_components=%d" % cfg["d"], "no_components=%d" % d)
+    if len(runs) > 1:
+        result["config"]["fresh_fits"] = [r["value"] for r in runs]
+    e211 = [r["epochs_2_11"] for r in runs if "epochs_2_11" in r]
+    if e211:
+        result["config"]["epochs_2_11"] = float(np.median(e211))
+    if steady:
+        result["config"]["steady_state"] = steady
     if scale != 1.0:
         result["config"]["scale"] = scale
     if args.item_alpha or args.user_alpha:
         result["config"]["item_alpha"], result["config"]["user_alpha"] = args.item_alpha, args.user_alpha
     pieces = dict(train=train, test=test, feats=feats, n_users=n_users, n_items=n_items, loss=loss, d=d, cfg=cfg)
     return result, pieces
+
+
+def algorithmic_total(loss, counters, d, feats, rows, n_users, n_examples):
+    """SURVEY.md 8(d)'s bytes of the interactions a set of epochs processed."""
+    lens = np.bincount(rows, minlength=n_users)[rows]
+    mean_probe = float(np.mean(8 + 4 * np.ceil(np.log2(lens + 1.0))))
+    f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
+    return algorithmic_bytes(loss, counters, d, 1.0, f_i, mean_probe, n_examples,
+                             mean_kos_pos=float(np.mean(np.minimum(10, lens))))
+
+
+def algorithmic_frac(loss, stats, d, feats, rows, n_users, n_examples):
+    """Fraction of the HBM roofline of a list of epochs (algorithmic bytes / HIP-event kernel time / 8 TB/s)."""
+    counters = [sum(st.counters[i] for st in stats) for i in range(4)]
+    kernel_s = sum(st.kernel_ms for st in stats) / 1e3
+    return algorithmic_total(loss, counters, d, feats, rows, n_users, n_examples) / kernel_s / 1e9 / HBM_PEAK_GBS
 
 
 def reporting_legs(name, env, pieces, want_quality):
@@ -531,13 +594,11 @@ def reporting_legs(name, env, pieces, want_quality):
     q_epochs = 3
     # the quality / CPU legs of c3 run on a row sub-sample (the reference needs ~10 us per
     # interaction there); c2 on the full COO
-    q_train, q_test, q_note = train, test, "the full %d-interaction COO of this workload" % train.nnz
+    q_train, q_test, q_note = train, test, "full COO (%d interactions)" % train.nnz
     if name == "c3":
         nu = n_users // 8
-
         q_train, q_test = head_users(train, nu, n_items), (head_users(test, nu, n_items) if test is not None else None)
-        q_note = ("the first %d users' %d interactions of this workload (1/8 row sub-sample), full item-side "
-                  "tables" % (nu, q_train.nnz))
+        q_note = "first %d users (%d interactions, 1/8 row sub-sample), full item side" % (nu, q_train.nnz)
     if want_quality and q_test is not None:
         q_seeds = (7, 8, 9)
         p = []
@@ -545,11 +606,8 @@ def reporting_legs(name, env, pieces, want_quality):
             m = LightFM(no_components=d, loss=loss, random_state=seed, max_sampled=MAX_SAMPLED)
             m.fit(q_train, item_features=feats, epochs=q_epochs)
             p.append(precision_at_10(m, q_train, q_test, feats))
-        quality = {"epochs": q_epochs, "precision_at_10": float(np.mean(p)), "precision_at_10_seeds": p,
-                   "seeds": list(q_seeds), "eval_users": int(len(np.unique(q_test.row))), "data": q_note,
-                   "metric": "precision_at_k(k=10) of lightfm/evaluation.py:14-87 on a held-out 5 percent of "
-                             "the same synthetic process; mean over %d seeds of %d-epoch fits (the reference: one fit, "
-                             "seed 7, its 16-thread Hogwild)" % (len(q_seeds), q_epochs)}
+        quality = {"epochs": q_epochs, "precision_at_10": float(np.mean(p)), "seeds": p,
+                   "eval_users": int(len(np.unique(q_test.row))), "data": q_note}
     if not args.no_cpu_baseline:
         try:
             if cfg["shape"] == "ml-20m":
@@ -563,18 +621,13 @@ def reporting_legs(name, env, pieces, want_quality):
                     nu = max(1000, n_users // (16 if name == "c2" else 64))
                     sub = head_users(q_train, nu, n_items) if nu < q_train.shape[0] else q_train
                     cpu["thread_scaling"] = thread_scaling(name, sub, feats, log, sorted({1, min(16, ncpu), ncpu}))
-                    cpu["thread_scaling_sample"] = ("epoch 2 of a fresh fit on the first %d users' %d interactions, "
-                                                    "threads -> interactions/s" % (nu, sub.nnz))
             else:
                 # C4 / C5 shards: a row sub-sample (1/50 of the users, their interactions, the
                 # full item-side tables), SURVEY.md 8(d)
                 nu = max(1000, n_users // 50)
-                keep = train.row < nu
-                sub = sp.coo_matrix((train.data[keep], (train.row[keep], train.col[keep])),
-                                    shape=(nu, n_items), dtype=np.float32)
+                sub = head_users(train, nu, n_items)
                 cpu, _ = reference_leg(name, sub, None, feats, 3, log,
-                                       "the first %d users' %d interactions of this shard (1/50 row sub-"
-                                       "sample) over the full item-side tables" % (nu, sub.nnz))
+                                       "first %d users (%d interactions, 1/50 row sub-sample), full item side" % (nu, sub.nnz))
         except Exception as e:  # the baseline is reporting only; never fail the bench on it
             log("cpu_baseline failed: %r" % (e,))
     if not args.no_fit and cfg["shape"] == "ml-20m":
@@ -583,10 +636,87 @@ def reporting_legs(name, env, pieces, want_quality):
         t1 = time.perf_counter()
         m.fit(train, item_features=feats, epochs=fit_epochs)
         dt = time.perf_counter() - t1
-        fit = {"value": train.nnz * fit_epochs / dt, "unit": "interactions/s", "epochs": fit_epochs,
-               "seconds": dt, "what": "LightFM.fit(train, epochs=%d) through the public API: host coercion, "
-               "uploads, device positives build, epochs, finite checks, download" % fit_epochs}
+        fit = {"value": train.nnz * fit_epochs / dt, "epochs": fit_epochs, "seconds": dt}
     return quality, cpu, fit
+
+
+def ranks_leg(env, pieces):
+    """predict_ranks (PYX:1232-1323) of EVERY user with test interactions against all items of the
+    ML-20M shape, on a model LightFM.fit trained -- the dense predict-all-items path on the matrix cores.  roofline: the
+    2 * users * items * d flops of the score matrix against the dense fp32 matrix peak; cpu_baseline: the reference's
+    own predict_ranks on a user sub-sample, 16 threads."""
+    from lightfm_amd import _native as N
+    from lightfm_amd.lightfm import LightFM
+    train, test, n_users, n_items = pieces["train"], pieces["test"], pieces["n_users"], pieces["n_items"]
+    if test is None:
+        return None
+    d = 64
+    m = LightFM(no_components=d, loss="warp", random_state=1, max_sampled=MAX_SAMPLED)
+    m.fit(train, epochs=2)
+    test_csr, train_csr = test.tocsr().astype(np.float32), train.tocsr().astype(np.float32)
+    users = int(np.count_nonzero(np.diff(test_csr.indptr)))
+    walls, kms = [], []
+    for _ in range(4):
+        t1 = time.perf_counter()
+        ranks = m.predict_rank(test_csr, train_interactions=train_csr, check_intersections=False)
+        walls.append(time.perf_counter() - t1)
+        kms.append(float(N.lib().lfm_last_kernel_ms()))
+    pairs = float(users) * n_items
+    k_ms, wall = float(np.median(kms[1:])), float(np.median(walls[1:]))
+    leg = {"name": "predict_ranks", "metric": "user-item scores ranked/s (predict_ranks, ML-20M shape, no_components=64)",
+           "value": pairs / (k_ms * 1e-3), "unit": "scores/s", "kernel_ms": k_ms, "call_ms": wall * 1e3,
+           "users": users, "items": n_items, "test_interactions": int(test_csr.nnz),
+           "roofline": {"bound": "mfma", "achieved": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "frac_of_call": 2.0 * d * pairs / wall / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "ranks_mfma3_kernel + test_scores / sortedness passes (HIP events around the call's kernels)"}}
+    if not env.args.no_cpu_baseline:
+        try:
+            from oracle import oracle
+            if oracle.ref_available("fast"):
+                ref = oracle.ref_module("fast")
+                nu = 1500
+                sub_test, sub_train = test_csr[:nu].tocsr(), train_csr[:nu].tocsr()
+                threads = min(16, os.cpu_count() or 1)
+                fl = ref.FastLightFM(m.item_embeddings, m.item_embedding_gradients, m.item_embedding_momentum, m.item_biases,
+                                     m.item_bias_gradients, m.item_bias_momentum,
+                                     np.ascontiguousarray(m.user_embeddings[:nu]), np.ascontiguousarray(m.user_embedding_gradients[:nu]),
+                                     np.ascontiguousarray(m.user_embedding_momentum[:nu]), np.ascontiguousarray(m.user_biases[:nu]),
+                                     np.ascontiguousarray(m.user_bias_gradients[:nu]), np.ascontiguousarray(m.user_bias_momentum[:nu]),
+                                     d, 0, m.learning_rate, m.rho, m.epsilon, m.max_sampled)
+                eye_i = sp.identity(n_items, dtype=np.float32, format="csr")
+                eye_u = sp.identity(nu, dtype=np.float32, format="csr")
+                out = np.zeros(sub_test.nnz, np.float32)
+                t1 = time.perf_counter()
+                ref.predict_ranks(ref.CSRMatrix(eye_i), ref.CSRMatrix(eye_u), ref.CSRMatrix(sub_test), ref.CSRMatrix(sub_train),
+                                  out, fl, threads)
+                dt = time.perf_counter() - t1
+                scored = float(np.count_nonzero(np.diff(sub_test.indptr))) * n_items
+                assert np.array_equal(out, ranks.data[:sub_test.nnz]), "predict_ranks differs from the reference's"
+                leg["cpu_baseline"] = {"value": scored / dt, "unit": "scores/s", "cores": threads, "kind": "reference",
+                                       "sample": "first %d users (%d with test interactions), ranks equal this backend's" % (
+                                           nu, int(np.count_nonzero(np.diff(sub_test.indptr))))}
+                leg["speedup_vs_cpu_baseline"] = leg["value"] / leg["cpu_baseline"]["value"]
+        except Exception as e:  # reporting only
+            env.log("predict_ranks cpu_baseline failed: %r" % (e,))
+    return leg
+
+
+def compact_leg(r, cpu=None):
+    """An extra leg's measurement in a few hundred bytes."""
+    ro = r["roofline"]
+    out = {"value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
+           "workload": r["config"]["workload"], "timed_epochs": r["config"]["timed_epochs"],
+           "roofline": {k: ro[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                                           "algorithmic_bytes_per_interaction", "updates_per_interaction", "draws_per_interaction",
+                                           "traffic_over_algorithmic") if k in ro}}
+    out["roofline"]["atomic_unit_frac"] = ro["atomic_unit"]["frac"]
+    if "steady_state" in r["config"]:
+        out["steady_state"] = r["config"]["steady_state"]
+    if cpu:
+        out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+        out["speedup_vs_cpu_baseline"] = r["value"] / cpu["value"]
+    return out
 
 
 def main():
@@ -611,40 +741,61 @@ def main():
     name = args.config or "c2"
     cfg = CONFIGS[name]
     want_quality = world == 1 and not args.no_quality and cfg["shape"] == "ml-20m" and args.emulate_shard <= 1
-    result, pieces = run_config(name, env, args.steps, args.warmup, args.epochs_per_step, 6.0, args.scale, want_quality)
+    want_ranks = world == 1 and args.config is None and not args.no_extra and not tuned
+    result, pieces = run_config(name, env, args.steps, args.warmup, args.epochs_per_step, fits=args.fits,
+                                steady_seconds=args.steady_seconds, scale=args.scale, want_test=want_quality or want_ranks,
+                                d_override=args.no_components)
 
-    extras = []
+    legs = {}
     if world == 1 and args.config is None and not args.no_extra and not tuned:
-        # the other BASELINE shapes, short legs timed the same way (contract: barrier + sync around K steps)
-        plans = {"c3": dict(steps=3, warmup=1, target=2.5), "c4shard": dict(steps=3, warmup=1, target=1.5),
-                 "c5shard": dict(steps=2, warmup=1, target=0.0, early=1)}
-        for extra in [e for e in args.extra.split(",") if e in plans and e != name]:
+        # reporting legs that share c2's COO first (the generated workload is cached)
+        wanted = [e for e in args.extra.split(",") if e]
+        if "ranks" in wanted:
+            try:
+                leg = ranks_leg(env, pieces)
+                if leg:
+                    legs["predict_ranks"] = leg
+            except BaseException as e:
+                env.log("predict_ranks leg failed: %r" % (e,))
+                legs["predict_ranks"] = {"error": repr(e)}
+        # the other BASELINE shapes and the reference's default width, short legs timed the same way
+        plans = {"c2_d10": dict(cfg="c2", steps=5, warmup=2, d=10), "c3": dict(cfg="c3", steps=5, warmup=2, steady=2.0),
+                 "c4shard": dict(cfg="c4shard", steps=5, warmup=2, steady=1.5), "c5shard": dict(cfg="c5shard", steps=2, warmup=1)}
+        for extra in [e for e in wanted if e in plans and e != name]:
             try:
                 pl = plans[extra]
-                r, pc = run_config(extra, env, pl["steps"], pl["warmup"], 0 if pl["target"] else 1, pl["target"], 1.0,
-                                   False, early_epochs=pl.get("early", 3))
-                leg = {"name": extra, "metric": "positive interactions/sec/epoch (%s, %s)" % (CONFIGS[extra]["loss"], extra),
-                       "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
-                       "ms_per_step": r["ms_per_step"], "config": r["config"], "roofline": r["roofline"],
-                       "early_epochs": r["early_epochs"]}
-                if not args.no_cpu_baseline:  # the reference on a bounded row sub-sample of THIS leg's workload
+                r, pc = run_config(pl["cfg"], env, pl["steps"], pl["warmup"], 1, fits=1, steady_seconds=pl.get("steady", 0.0),
+                                   d_override=pl.get("d"), want_test=(CONFIGS[pl["cfg"]]["shape"] == "ml-20m"))
+                cpu = None
+                if not args.no_cpu_baseline and extra != "c2_d10":  # the reference on a bounded row sub-sample of THIS leg's workload
                     try:
-                        leg["cpu_baseline"] = extra_cpu_leg(extra, env, pc)
-                        if leg["cpu_baseline"]:
-                            leg["speedup_vs_cpu_baseline"] = r["value"] / leg["cpu_baseline"]["value"]
+                        cpu = extra_cpu_leg(extra, env, pc)
                     except Exception as e:  # reporting only
                         env.log("cpu_baseline of %s failed: %r" % (extra, e))
-                extras.append(leg)
+                legs[extra] = compact_leg(r, cpu)
             except BaseException as e:  # an extra leg never takes the contract line down
                 env.log("extra config %s failed: %r" % (extra, e))
-                extras.append({"name": extra, "error": repr(e)})
+                legs[extra] = {"error": repr(e)}
         env.cache.clear()
 
     quality, cpu, fit = None, None, None
     if rank == 0 and world == 1:
+        if name != "c2" or "c2" not in str(env.cache.keys()):
+            pass
         quality, cpu, fit = reporting_legs(name, env, pieces, want_quality)
 
     if rank == 0:
+        config = result["config"]
+        if quality:
+            config["quality"] = quality
+        if fit:
+            config["end_to_end_fit"] = fit
+        if legs:
+            config["legs"] = legs
+        if tuned:
+            config["non_default_options"] = tuned
+        if cpu:
+            config["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
         out = {
             "metric": "positive interactions/sec/epoch (WARP, ML-20M)" if name == "c2" else
                       "positive interactions/sec/epoch (%s, %s)" % (cfg["loss"], name),
@@ -652,20 +803,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": result["ms_per_step"],
             "higher_is_better": True, "scaling": result["scaling"] if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": result["config"],
+            "config": config,
             "roofline": result["roofline"],
-            "early_epochs": result["early_epochs"],
             "cpu_baseline": cpu,
-            "quality": quality,
-            "end_to_end_fit": fit,
         }
-        if extras:
-            out["extra_configs"] = extras
-        if tuned:
-            out["config"]["non_default_options"] = tuned
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
-        print(json.dumps(out), flush=True)
+        line = json.dumps(rnd(out), separators=(",", ":"))
+        if len(line) > 8000:
+            env.log("bench line is %d bytes (> 8000): the driver's stdout tail may cut it" % len(line))
+        print(line, flush=True)
     if world > 1:
         env.dist.destroy_process_group()
 

@@ -47,6 +47,31 @@ _NOT_FINITE = ("Not all estimated parameters are finite, your model may have div
                "Try decreasing the learning rate or normalising feature values and sample weights")
 
 
+class _Stages(object):
+    """LIGHTFM_AMD_TIMING=1: wall time of the stages of fit_partial on stderr (tools/fit_timing.py)."""
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("LIGHTFM_AMD_TIMING", "0") not in ("", "0")
+        self.marks = []
+        if self.on:
+            import time
+            self.clock = time.perf_counter
+            self.t = self.clock()
+
+    def mark(self, name):
+        if self.on:
+            now = self.clock()
+            self.marks.append((name, now - self.t))
+            self.t = now
+
+    def report(self):
+        if self.on:
+            import sys
+            print("[lightfm_amd timing] " + ", ".join("%s %.1f ms" % (n, 1e3 * dt) for n, dt in self.marks),
+                  file=sys.stderr, flush=True)
+
+
 def _printed_epochs(n):
     for epoch in range(n):
         print("Epoch {}".format(epoch))
@@ -527,6 +552,7 @@ class LightFM(object):
     def fit_partial(self, interactions, user_features=None, item_features=None,
                     sample_weight=None, epochs=1, num_threads=1, verbose=False):
         """Resume training from the current state (LFM:560-666)."""
+        self._stages = stages = _Stages()
         interactions = interactions.tocoo()
         if interactions.dtype != CYTHON_DTYPE:
             interactions.data = interactions.data.astype(CYTHON_DTYPE)
@@ -549,9 +575,11 @@ class LightFM(object):
             raise ValueError("Incorrect number of features in user_features")
         if num_threads < 1:
             raise ValueError("Number of threads must be 1 or larger.")
+        stages.mark("host checks")
 
         self._run_epochs(item_features, user_features, interactions, sample_weight_data,
                          num_threads, epochs, verbose)
+        stages.report()
         return self
 
     def _run_epochs(self, item_features, user_features, interactions, sample_weight, num_threads,
@@ -578,16 +606,20 @@ class LightFM(object):
         device_shuffle = (options.device_shuffle and options.mode == "parallel"
                           and not getattr(self, "_shared_random_state", False))
 
+        stages = getattr(self, "_stages", None) or _Stages()
         model = self._get_lightfm_data()
         session = _Session(model, CSRMatrix(item_features), CSRMatrix(user_features))
+        stages.mark("session + tables")
         try:
             if loss == "warp-kos" and positives is not None:
                 session.set_interactions(positives, rows, None, None, None)
             else:
                 session.set_interactions(positives, rows, cols, data, sample_weight)
+            stages.mark("interactions upload")
             if needs_lookup and positives is None:
                 # the same matrix (sorted rows, duplicates merged) built on the device from the COO
                 session.build_positives(interactions.shape[0], interactions.shape[1])
+            stages.mark("positives")
             self._last_epoch_stats = []
             for _ in self._progress(epochs, verbose=verbose):
                 if device_shuffle:
@@ -617,7 +649,9 @@ class LightFM(object):
                 if not session.check_finite():  # LFM:664
                     session.sync_to_host(model)
                     raise ValueError(_NOT_FINITE)
+                stages.mark("epoch")
             session.sync_to_host(model)
+            stages.mark("download")
         finally:
             session.close()
 
