@@ -674,28 +674,34 @@ def ranks_leg(env, pieces):
         try:
             from oracle import oracle
             if oracle.ref_available("fast"):
-                ref = oracle.ref_module("fast")
-                nu = 1500
-                sub_test, sub_train = test_csr[:nu].tocsr(), train_csr[:nu].tocsr()
                 threads = min(16, os.cpu_count() or 1)
-                fl = ref.FastLightFM(m.item_embeddings, m.item_embedding_gradients, m.item_embedding_momentum, m.item_biases,
-                                     m.item_bias_gradients, m.item_bias_momentum,
-                                     np.ascontiguousarray(m.user_embeddings[:nu]), np.ascontiguousarray(m.user_embedding_gradients[:nu]),
-                                     np.ascontiguousarray(m.user_embedding_momentum[:nu]), np.ascontiguousarray(m.user_biases[:nu]),
-                                     np.ascontiguousarray(m.user_bias_gradients[:nu]), np.ascontiguousarray(m.user_bias_momentum[:nu]),
-                                     d, 0, m.learning_rate, m.rho, m.epsilon, m.max_sampled)
                 eye_i = sp.identity(n_items, dtype=np.float32, format="csr")
-                eye_u = sp.identity(nu, dtype=np.float32, format="csr")
-                out = np.zeros(sub_test.nnz, np.float32)
-                t1 = time.perf_counter()
-                ref.predict_ranks(ref.CSRMatrix(eye_i), ref.CSRMatrix(eye_u), ref.CSRMatrix(sub_test), ref.CSRMatrix(sub_train),
-                                  out, fl, threads)
-                dt = time.perf_counter() - t1
-                scored = float(np.count_nonzero(np.diff(sub_test.indptr))) * n_items
-                assert np.array_equal(out, ranks.data[:sub_test.nnz]), "predict_ranks differs from the reference's"
-                leg["cpu_baseline"] = {"value": scored / dt, "unit": "scores/s", "cores": threads, "kind": "reference",
-                                       "sample": "first %d users (%d with test interactions), ranks equal this backend's" % (
-                                           nu, int(np.count_nonzero(np.diff(sub_test.indptr))))}
+
+                def reference_ranks(kind, nu):
+                    """The reference's predict_ranks over the first nu users: (ranks, seconds, users with test interactions)."""
+                    ref = oracle.ref_module(kind)
+                    sub_test, sub_train = test_csr[:nu].tocsr(), train_csr[:nu].tocsr()
+                    fl = ref.FastLightFM(m.item_embeddings, m.item_embedding_gradients, m.item_embedding_momentum, m.item_biases,
+                                         m.item_bias_gradients, m.item_bias_momentum,
+                                         *[np.ascontiguousarray(getattr(m, n_)[:nu]) for n_ in (
+                                             "user_embeddings", "user_embedding_gradients", "user_embedding_momentum", "user_biases",
+                                             "user_bias_gradients", "user_bias_momentum")],
+                                         d, 0, m.learning_rate, m.rho, m.epsilon, m.max_sampled)
+                    out = np.zeros(sub_test.nnz, np.float32)
+                    t1 = time.perf_counter()
+                    ref.predict_ranks(ref.CSRMatrix(eye_i), ref.CSRMatrix(sp.identity(nu, dtype=np.float32, format="csr")),
+                                      ref.CSRMatrix(sub_test), ref.CSRMatrix(sub_train), out, fl, threads)
+                    return out, time.perf_counter() - t1, int(np.count_nonzero(np.diff(sub_test.indptr)))
+
+                # timed: the default-flag build users get (-ffast-math: its dot products may round differently);
+                # compared: the strict build (the parity oracle) on a smaller sample -- ranks must be identical
+                out, dt, scored_users = reference_ranks("fast", 1500)
+                leg["cpu_baseline"] = {"value": float(scored_users) * n_items / dt, "unit": "scores/s", "cores": threads,
+                                       "kind": "reference", "sample": "first 1500 users (%d with test interactions)" % scored_users,
+                                       "ranks_equal_to_fast_build": float(np.mean(out == ranks.data[:len(out)]))}
+                if oracle.ref_available("strict"):
+                    out, _, _ = reference_ranks("strict", 400)
+                    leg["cpu_baseline"]["ranks_identical_to_strict_build"] = bool(np.array_equal(out, ranks.data[:len(out)]))
                 leg["speedup_vs_cpu_baseline"] = leg["value"] / leg["cpu_baseline"]["value"]
         except Exception as e:  # reporting only
             env.log("predict_ranks cpu_baseline failed: %r" % (e,))

@@ -157,6 +157,10 @@ int lfm_device_info(int device, char *name, int32_t *cus, int64_t *hbm_bytes);
  * *released, may be NULL); lfm_device_pool_stats reports the bytes held / currently unused.  No
  * counterpart in the reference (host memory is numpy's). */
 int lfm_device_trim(int64_t *released);
+/* Host-side helper of the Python class (no device involved): ONE multi-threaded pass over a float32 array that
+ * answers what LFM:383-386 (np.array_equiv(data, 1.0)) and LFM:447-472 / 617-625 (isfinite(sum)) ask in two to
+ * three numpy passes.  *all_ones = every value == 1.0f; *finite = no inf / nan and the sum inside float32 range. */
+int lfm_host_scan_f32(const float *p, int64_t n, int32_t *all_ones, int32_t *finite);
 int lfm_device_pool_stats(int64_t *reserved, int64_t *cached);
 
 /* ------------------------------------------------------------------------

@@ -73,7 +73,7 @@ EXPORTS = (
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
-    "lfm_device_trim", "lfm_device_pool_stats",
+    "lfm_device_trim", "lfm_device_pool_stats", "lfm_host_scan_f32",
     "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush", "lfm_session_set_merge_dense_fraction",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
@@ -144,6 +144,16 @@ def require(a, dtype, ndim, name):
     if not a.flags.c_contiguous:
         raise ValueError("ndarray is not C-contiguous (%s)" % name)
     return a
+
+
+def host_scan(a):
+    """(all values == 1.0, all finite with a finite float32 sum) of a C-contiguous float32 array in one pass
+    (lfm_host_scan_f32); numpy when the library has not been built (host-side validation only)."""
+    if a.dtype == np.float32 and a.flags.c_contiguous and os.path.exists(LIB_PATH):
+        ones, fin = C.c_int32(), C.c_int32()
+        check(lib().lfm_host_scan_f32(f32p(a), C.c_int64(a.size), C.byref(ones), C.byref(fin)))
+        return bool(ones.value), bool(fin.value)
+    return bool(np.array_equiv(a, 1.0)), bool(np.isfinite(np.sum(a)))
 
 
 def device_trim():

@@ -537,9 +537,11 @@ __global__ __launch_bounds__(64, KSTEPS > 32 ? 1 : 2) void ranks_mfma2_kernel(Ra
 //   * eps of a score is the bound of ITS octet of items (max over 8 items, x (1 + 1 / (2 (d + 2))) for the roundings
 //     of s -/+ eps): one instruction per score instead of eight; the band is re-decided with the reference's
 //     sequential dot (PYX:1317-1319), computed by the whole wavefront, so the ranks are the reference's integers;
-//   * a work item = (32-user tile, pass, segment of the item table): partial counts are integers < 2^24
-//     published with float atomics (exact), segments are dispatched segment-major so that the wavefronts
-//     resident at one time walk the same ~1 MB of the table.
+//   * a work item = (32-user tile, pass, segment of the item table): partial counts are integers, published with
+//     float atomics -- exact, in any order, while a rank stays below 2^24 (catalogues of up to 16.7 M items; beyond
+//     that the sums round like the reference's own float32 `rank += 1.0`, PYX:1321, which stops counting at 2^24,
+//     but their rounding then depends on the order of the atomics); segments (< 2^26 items each) are dispatched
+//     segment-major so that the wavefronts resident at one time walk the same ~1 MB of the table.
 // LDS 12.3 KB and <= 168 VGPRs per wavefront: three wavefronts per SIMD (d <= 64).
 // max over the aligned group of eight lanes, in all eight
 __device__ __forceinline__ float octet_max(float v)

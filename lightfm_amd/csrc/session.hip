@@ -13,6 +13,7 @@
 
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -52,6 +53,49 @@ extern "C" const char *lfm_last_error(void) { return g_err.c_str(); }
 
 static thread_local float g_kernel_ms = 0.0f;
 extern "C" float lfm_last_kernel_ms(void) { return g_kernel_ms; }
+
+// Host-side input scan of LightFM.fit_partial (LFM:383-386, 447-472 and 617-625 test the interaction values for "all
+// ones" and for finiteness with two or three numpy passes over 80 MB at the ML-20M shape -- a quarter of a 10-epoch
+// fit once the epochs run on the GPU): ONE multi-threaded pass.  *all_ones = every value == 1.0f; *finite = every
+// value finite and their float64 sum inside the float32 range (the reference's test is isfinite(float32 sum)).
+extern "C" int lfm_host_scan_f32(const float *p, int64_t n, int32_t *all_ones, int32_t *finite)
+{
+    if (n < 0 || (n && !p) || !all_ones || !finite) return fail(LFM_EINVAL, "bad scan arguments");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())),
+                                                            n / (1 << 20)));
+    std::vector<double> sums((size_t)T, 0.0);
+    std::vector<int> ones((size_t)T, 1), fin((size_t)T, 1);
+    auto work = [&](int t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        double acc = 0.0;
+        uint32_t not_one = 0u, bad = 0u;
+        for (int64_t j = lo; j < hi; ++j) {
+            const float v = p[j];
+            uint32_t bits;
+            memcpy(&bits, &v, 4);
+            not_one |= bits ^ 0x3f800000u;
+            bad |= ((bits & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;  // inf or nan
+            acc += (double)v;
+        }
+        sums[(size_t)t] = acc;
+        ones[(size_t)t] = not_one == 0u;
+        fin[(size_t)t] = bad == 0u;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    double total = 0.0;
+    int o = 1, f = 1;
+    for (int t = 0; t < T; ++t) {
+        total += sums[(size_t)t];
+        o &= ones[(size_t)t];
+        f &= fin[(size_t)t];
+    }
+    *all_ones = o;
+    *finite = (f && fabs(total) <= 3.4028234663852886e38) ? 1 : 0;
+    return LFM_OK;
+}
 
 extern "C" int lfm_device_count(void)
 {
@@ -2432,6 +2476,7 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     // tests compare all four
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
     int mfma_mode = mfma_env == nullptr ? 3 : atoi(mfma_env);
+    if (mfma_mode < 0 || mfma_mode > 3) mfma_mode = 3;  // anything but the four documented values: the default kernel
     // the MFMA sweeps mask train positives by walking each user's train row alongside the item tiles: they
     // need ascending column indices (tocsr() of a COO gives them; a CSR handed in by the caller may not).
     // Unsorted rows run the scalar kernel, whose lookup is the reference's binary search.  Checked on the

@@ -356,6 +356,11 @@ class LightFM(object):
         return lock
 
     def _drop_scoring_session(self):
+        if self.__dict__.get("_scoring_owner") == threading.get_ident():
+            # called from INSIDE this thread's own `with _scoring_session(...)` block (e.g. fit_partial from a scoring
+            # callback): the session in use is closed when the block ends, not under it -- and nobody deadlocks
+            self.__dict__["_scoring_drop_pending"] = True
+            return
         with self._scoring_lock():  # never under a predict call that is using it
             cached = self.__dict__.pop("_scoring", None)
             if cached is not None:
@@ -402,10 +407,23 @@ class LightFM(object):
                     self.__dict__["_scoring"] = cached
                 else:
                     cached[0].set_features(itf, usf)
+                self.__dict__["_scoring_owner"] = threading.get_ident()
                 yield cached[0]
             finally:
+                self.__dict__.pop("_scoring_owner", None)
+                if self.__dict__.pop("_scoring_drop_pending", False):
+                    stale = self.__dict__.pop("_scoring", None)
+                    if stale is not None:
+                        stale[0].close()
                 lock.release()
             return
+        if not options.cache_scoring_session and lock.acquire(False):
+            try:  # caching was switched off after a session had been kept: its device memory goes back now
+                stale = self.__dict__.pop("_scoring", None)
+                if stale is not None:
+                    stale[0].close()
+            finally:
+                lock.release()
         session = _Session(self._get_lightfm_data(), itf, usf, scoring=True)
         try:
             yield session
@@ -416,6 +434,8 @@ class LightFM(object):
         state = dict(self.__dict__)
         state.pop("_scoring", None)  # a device handle
         state.pop("_scoring_mutex", None)
+        state.pop("_scoring_owner", None)
+        state.pop("_scoring_drop_pending", None)
         return state
 
     def __del__(self):
@@ -430,19 +450,17 @@ class LightFM(object):
 
     def _initialize(self, no_components, no_item_features, no_user_features):
         """LFM:281-312 -- item table drawn first, then the user table."""
+        start = np.ones if self.learning_schedule == "adagrad" else np.zeros  # accumulators: 1 (adagrad) / 0
         for side, rows in (("item", no_item_features), ("user", no_user_features)):
-            emb = ((self.random_state.rand(rows, no_components) - 0.5) / no_components).astype(
-                np.float32)
-            setattr(self, side + "_embeddings", emb)
-            setattr(self, side + "_embedding_gradients", np.zeros_like(emb))
-            setattr(self, side + "_embedding_momentum", np.zeros_like(emb))
+            draw = self.random_state.rand(rows, no_components)  # float64; the two steps below in place: the same
+            draw -= 0.5                                         # values as ((rand - 0.5) / d).astype(float32)
+            draw /= no_components                               # without two temporaries of the table's size
+            setattr(self, side + "_embeddings", draw.astype(np.float32))
+            setattr(self, side + "_embedding_gradients", start((rows, no_components), dtype=np.float32))
+            setattr(self, side + "_embedding_momentum", np.zeros((rows, no_components), dtype=np.float32))
             setattr(self, side + "_biases", np.zeros(rows, dtype=np.float32))
-            setattr(self, side + "_bias_gradients", np.zeros(rows, dtype=np.float32))
+            setattr(self, side + "_bias_gradients", start(rows, dtype=np.float32))
             setattr(self, side + "_bias_momentum", np.zeros(rows, dtype=np.float32))
-        if self.learning_schedule == "adagrad":
-            for side in ("item", "user"):
-                getattr(self, side + "_embedding_gradients")[...] += 1
-                getattr(self, side + "_bias_gradients")[...] += 1
 
     def _construct_feature_matrices(self, n_users, n_items, user_features, item_features):
         """LFM:314-363."""
@@ -491,7 +509,7 @@ class LightFM(object):
     def _process_sample_weight(self, interactions, sample_weight):
         """LFM:381-420."""
         if sample_weight is None:
-            if np.array_equiv(interactions.data, 1.0):
+            if self._scan(interactions.data)[0]:   # np.array_equiv(data, 1.0), LFM:383-386
                 return interactions.data  # aliases Y, like the reference
             return np.ones_like(interactions.data, dtype=CYTHON_DTYPE)
 
@@ -521,8 +539,19 @@ class LightFM(object):
             if not np.isfinite(np.sum(parameter)):
                 raise ValueError(_NOT_FINITE)
 
+    def _scan(self, data):
+        """(all ones, finite) of an input array: one pass of the native helper, remembered per array for the call (the
+        interaction values are asked about three times: LFM:383-386, 617-625)."""
+        seen = getattr(self, "_scanned", None)
+        if seen is not None and seen[0] is data:
+            return seen[1]
+        answer = N.host_scan(data) if isinstance(data, np.ndarray) and data.size >= (1 << 16) else (
+            bool(np.array_equiv(data, 1.0)), bool(np.isfinite(np.sum(data))))
+        self._scanned = (data, answer)
+        return answer
+
     def _check_input_finite(self, data):
-        if not np.isfinite(np.sum(data)):
+        if not self._scan(data)[1]:
             raise ValueError("Not all input values are finite. "
                              "Check the input for NaNs and infinite values.")
 
@@ -553,6 +582,7 @@ class LightFM(object):
                     sample_weight=None, epochs=1, num_threads=1, verbose=False):
         """Resume training from the current state (LFM:560-666)."""
         self._stages = stages = _Stages()
+        self._scanned = None
         interactions = interactions.tocoo()
         if interactions.dtype != CYTHON_DTYPE:
             interactions.data = interactions.data.astype(CYTHON_DTYPE)
@@ -576,6 +606,7 @@ class LightFM(object):
         if num_threads < 1:
             raise ValueError("Number of threads must be 1 or larger.")
         stages.mark("host checks")
+        self._scanned = None  # (holds a reference to the caller's array)
 
         self._run_epochs(item_features, user_features, interactions, sample_weight_data,
                          num_threads, epochs, verbose)

@@ -104,6 +104,21 @@ for name, c in pmc.items():
         summary["hbm_bytes_per_launch"] = 2 * f + w
         summary["fetch_bytes_per_launch_raw"] = f
         summary["write_bytes_per_launch"] = w
+        # Calibrated by request size (round 5): FETCH_SIZE tallies EVERY memory-side read request at 64 B, so doubling it is
+        # right for 128-byte requests only.  With the request-size counters of the same command: read bytes = 128 n_128 +
+        # 32 n_32 + 64 (n - n_128 - n_32); the write side keeps WRITE_SIZE (64-byte / 32-byte write requests; a float
+        # atomic travels as a write request).
+        if all(k in c for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
+            n = c["TCC_EA0_RDREQ_sum"]["per_launch"]
+            n32, n128 = c["TCC_EA0_RDREQ_32B_sum"]["per_launch"], c["TCC_EA0_RDREQ_128B_sum"]["per_launch"]
+            rd = 128.0 * n128 + 32.0 * n32 + 64.0 * max(0.0, n - n128 - n32)
+            summary["read_requests_per_launch"] = {"all": n, "32B": n32, "128B": n128, "64B": max(0.0, n - n128 - n32)}
+            summary["read_bytes_per_launch_calibrated"] = rd
+            summary["hbm_bytes_per_launch_calibrated"] = rd + w
+            if "TCC_EA0_WRREQ_sum" in c and "TCC_EA0_WRREQ_64B_sum" in c:
+                nw, nw64 = c["TCC_EA0_WRREQ_sum"]["per_launch"], c["TCC_EA0_WRREQ_64B_sum"]["per_launch"]
+                summary["write_requests_per_launch"] = {"all": nw, "64B": nw64, "atomic": c.get("TCC_EA0_ATOMIC_sum", {}).get("per_launch")}
+                summary["write_bytes_per_launch_by_requests"] = 64.0 * nw64 + 32.0 * max(0.0, nw - nw64)
 json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True)[:3000])

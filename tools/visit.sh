@@ -706,6 +706,30 @@ r5b)
   tail -15 $OUT/tests.log
   timeout 300 python3 tools/merge_overhead.py 12 > $OUT/merge_overhead.txt 2>&1; cat $OUT/merge_overhead.txt | tail -8
   ;;
+r5e)
+  # end-to-end fit stages after the native input scan; gather-ahead staleness A/B; overlapped-exchange study with
+  # 10 seeds per arm; kernel traces + counters (incl. request sizes) of c2 and the C4 shard on the round-5 bench semantics
+  LIGHTFM_AMD_TIMING=1 timeout 300 python3 - > $OUT/fit_timing.txt 2>&1 <<'PY'
+import time, sys
+sys.path.insert(0, ".")
+from lightfm_amd import LightFM, synthetic
+data = synthetic.named("ml-20m")
+for rep in range(3):
+    m = LightFM(no_components=64, loss="warp", random_state=3)
+    t = time.perf_counter(); m.fit(data, epochs=10); dt = time.perf_counter() - t
+    print("fit(10 epochs) %.1f ms = %.1f M interactions/s" % (1e3 * dt, data.nnz * 10 / dt / 1e6), flush=True)
+m = LightFM(no_components=64, loss="warp", random_state=3)
+t = time.perf_counter(); m.fit(data, epochs=20); dt = time.perf_counter() - t
+print("fit(20 epochs) %.1f ms = %.1f M interactions/s" % (1e3 * dt, data.nnz * 20 / dt / 1e6), flush=True)
+PY
+  cat $OUT/fit_timing.txt | cut -c1-400
+  timeout 600 python3 tools/ahead_staleness.py 12 10 > $OUT/ahead_staleness.txt 2>&1; grep -a "x" $OUT/ahead_staleness.txt | tail -12
+  EMU_SHAPE=c2 EMU_SEEDS=1,2,3,4,5,6,7,8,9,10 timeout 900 python3 tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:sparse \
+     8:adagrad:4:16384:4194304:sparse 8:adagrad:4:16384:4194304:overlap 8:adagrad:4:16384:0:overlap > $OUT/emu_c2_10seeds.txt 2>&1
+  grep -a "K=" $OUT/emu_c2_10seeds.txt
+  bash tools/profile2.sh r05_c2 --config c2
+  bash tools/profile2.sh r05_c4shard --config c4shard
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
