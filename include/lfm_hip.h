@@ -250,6 +250,10 @@ int lfm_session_upload_shuffle(lfm_session *s, int32_t slot, const int32_t *shuf
  * network with cycle walking): replaces the host-side random_state.shuffle(arange(n)) of
  * LFM:689-690 + the upload when the caller only needs *a* uniform shuffle, not numpy's. */
 int lfm_session_device_shuffle(lfm_session *s, int32_t slot, uint32_t key0, uint32_t key1);
+/* ... the same, written on a stream of the session's own WHILE the epoch of another slot runs: call it for epoch e + 1's
+ * slot before lfm_session_epoch of epoch e; the epoch that uses the slot waits for it (LightFM.fit_partial alternates
+ * two slots). */
+int lfm_session_device_shuffle_ahead(lfm_session *s, int32_t slot, uint32_t key0, uint32_t key1);
 /* The same permutation computed on the host (no device needed); and a slot's content. */
 int lfm_shuffle_permutation(int32_t *out, int64_t n, uint32_t key0, uint32_t key1);
 int lfm_session_download_shuffle(lfm_session *s, int32_t slot, int32_t *out, int64_t n);

@@ -68,7 +68,7 @@ EXPORTS = (
     "lfm_fit_warp", "lfm_fit_bpr", "lfm_fit_logistic", "lfm_fit_warp_kos",
     "lfm_predict", "lfm_predict_ranks", "lfm_auc_from_rank", "lfm_in_positives",
     "lfm_session_create", "lfm_session_create_scoring", "lfm_session_set_features", "lfm_session_set_interactions", "lfm_session_upload_shuffle",
-    "lfm_session_device_shuffle", "lfm_shuffle_permutation", "lfm_session_download_shuffle",
+    "lfm_session_device_shuffle", "lfm_session_device_shuffle_ahead", "lfm_shuffle_permutation", "lfm_session_download_shuffle",
     "lfm_session_epoch", "lfm_session_check_finite", "lfm_session_predict",
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",

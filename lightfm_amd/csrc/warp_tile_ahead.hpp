@@ -98,7 +98,12 @@ struct ItemAddr {
     }
 };
 
-template <int NBF, bool SHARDED = false>
+// USTORE: the USER row of an update is written with plain stores instead of float atomics (experiment, lfm_opts.debug
+// bit 11 = 2048; uncached tables only: a store is then visible to every XCD).  With identity user features a user's row
+// is touched by that user's interactions alone, so what a plain read-modify-write can lose is one of two updates of the
+// same user that are in flight at the same time -- the reference's own Hogwild race -- and a third of C2's float
+// atomics (2 x 64 of 390 per update) leave the atomic unit.
+template <int NBF, bool SHARDED = false, bool USTORE = false>
 __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 {
     constexpr int LPR = 16, VEC = 4, NG = 4;
@@ -386,8 +391,13 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                         atomicAdd(aP + cq, __fsub_rn(nGP, gP[gg]));
                         atomicAdd(wN + cq, __fsub_rn(nWN, Nr));
                         atomicAdd(aN + cq, __fsub_rn(nGN, gN[gg]));
-                        atomicAdd(WuW + bu_ + cq, __fsub_rn(nWU, Ur));
-                        atomicAdd(Gu + bu_ + cq, __fsub_rn(nGU, gU[gg]));
+                        if constexpr (USTORE) {
+                            WuW[bu_ + cq] = nWU;
+                            Gu[bu_ + cq] = nGU;
+                        } else {
+                            atomicAdd(WuW + bu_ + cq, __fsub_rn(nWU, Ur));
+                            atomicAdd(Gu + bu_ + cq, __fsub_rn(nGU, gU[gg]));
+                        }
                     }
                 }
             }

@@ -362,18 +362,28 @@ class DistributedFit(object):
         alone would leave the others blocked in the next collective).  Returns the per-segment lfm_opts."""
         m = self.model
         n = self.shard.nnz
+        from .options import options
+        slot = getattr(self, "_slot", 0)
         if self.host_shuffle:
             shuffle = np.arange(n, dtype=np.int32)
             m.random_state.shuffle(shuffle)
             self.session.upload_shuffle(shuffle)
-        else:
+        elif getattr(self, "_ahead_keys", None) is None:
             keys = m.random_state.randint(0, np.iinfo(np.int32).max, size=624)
-            self.session.device_shuffle(int(keys[0]), int(keys[1]))
+            self.session.device_shuffle(int(keys[0]), int(keys[1]), slot=slot)
         seeds = None
         if m.loss != "logistic":
             seeds = np.ascontiguousarray(m.random_state.randint(
                 0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
-        stats = self.run_epoch(seeds)
+        self._ahead_keys = None
+        if not self.host_shuffle and options.shuffle_ahead and hasattr(self.session, "device_shuffle_ahead"):
+            # the next epoch's permutation is written to the other slot while this epoch trains (the same keys -> seeds
+            # -> keys order of draws; one block more is drawn after the last epoch of a run)
+            self._ahead_keys = m.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+            self.session.device_shuffle_ahead(int(self._ahead_keys[0]), int(self._ahead_keys[1]), slot=1 - slot)
+        stats = self.run_epoch(seeds, slot=slot)
+        if self._ahead_keys is not None:
+            self._slot = 1 - slot
         bad = not self.session.check_finite()  # (owner-sharded: the item rows this rank owns + its users)
         if self.owner_sharded:
             bad = self._any(bad)

@@ -144,6 +144,10 @@ class _Session(object):
     def device_shuffle(self, key0, key1, slot=0):
         N.check(N.lib().lfm_session_device_shuffle(self.handle, slot, C.c_uint32(key0), C.c_uint32(key1)))
 
+    def device_shuffle_ahead(self, key0, key1, slot):
+        """The permutation of a LATER epoch written while the current one trains (lfm_session_device_shuffle_ahead)."""
+        N.check(N.lib().lfm_session_device_shuffle_ahead(self.handle, slot, C.c_uint32(key0), C.c_uint32(key1)))
+
     def download_shuffle(self, n, slot=0):
         out = np.empty(n, np.int32)
         N.check(N.lib().lfm_session_download_shuffle(self.handle, slot, N.i32p(out), C.c_int64(n)))
@@ -652,13 +656,16 @@ class LightFM(object):
                 session.build_positives(interactions.shape[0], interactions.shape[1])
             stages.mark("positives")
             self._last_epoch_stats = []
-            for _ in self._progress(epochs, verbose=verbose):
+            ahead = device_shuffle and options.shuffle_ahead and epochs > 1
+            slot, next_keys = 0, None
+            for e in self._progress(epochs, verbose=verbose):
                 if device_shuffle:
                     # two draws key a permutation built on the device (the caller's RandomState
                     # still advances every epoch, tests/test_movielens.py:669-682 of the reference)
                     # (624 draws = one full Mersenne-Twister block, so get_state()[1] changes too)
-                    keys = self.random_state.randint(0, np.iinfo(np.int32).max, size=624)
-                    session.device_shuffle(int(keys[0]), int(keys[1]))
+                    if next_keys is None:
+                        keys = self.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+                        session.device_shuffle(int(keys[0]), int(keys[1]), slot=slot)
                 else:
                     shuffle_indices = np.arange(n, dtype=np.int32)
                     self.random_state.shuffle(shuffle_indices)
@@ -667,9 +674,17 @@ class LightFM(object):
                 if loss != "logistic":  # _lightfm_fast.pyx.template:812-814
                     seeds = np.ascontiguousarray(self.random_state.randint(
                         0, np.iinfo(np.int32).max, size=num_threads).astype(np.uint32))
+                next_keys = None
+                if ahead and e + 1 < epochs:
+                    # the NEXT epoch's permutation goes to the other slot on a stream of its own while this epoch
+                    # trains (the draws keep their order: keys, seeds, keys, seeds, ...)
+                    next_keys = self.random_state.randint(0, np.iinfo(np.int32).max, size=624)
+                    session.device_shuffle_ahead(int(next_keys[0]), int(next_keys[1]), slot=1 - slot)
                 opts, _ = make_opts()
                 opts.history = int(getattr(self, "_trained_interactions", 0))
-                session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts)
+                session.epoch(loss, self.item_alpha, self.user_alpha, self.k, self.n, seeds, opts, slot=slot)
+                if next_keys is not None:
+                    slot = 1 - slot
                 self._trained_interactions = getattr(self, "_trained_interactions", 0) + n
                 self._last_epoch_stats.append({"kernel_ms": float(opts.kernel_ms),
                                                "counters": list(opts.counters),

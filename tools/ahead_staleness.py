@@ -25,7 +25,8 @@ for nu, ni, nnz in ((300, 120, 12000), (1000, 400, 60000), (4000, 300, 200000)):
     for arm, cls, debug in (("ahead (default)", LightFM, 4), ("plain tile kernel", LightFM, 4 | 1024), ("reference, 16 threads", RefLightFM, 0)):
         res = []
         for seed in range(1, n_seeds + 1):
-            options.set(mode="parallel", debug=debug, ramp_k=-1)  # the whole chip's width from the first interaction: the worst case
+            # AHEAD_RAMP=1: the shipped concurrency ramp; default here: the whole chip's width from the first interaction (worst case)
+            options.set(mode="parallel", debug=debug, ramp_k=0 if os.environ.get("AHEAD_RAMP") else -1)
             m = cls(no_components=64, loss="warp", random_state=seed)
             m.fit(train, epochs=epochs, num_threads=16 if cls is RefLightFM else 1)
             if cls is LightFM:

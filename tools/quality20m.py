@@ -61,7 +61,8 @@ for v in variants:
             m.fit(train, epochs=epochs, num_threads=1)
         else:
             # hip<update_mode>[g] : g = generic kernel
-            options.set(mode="parallel", update_mode=int(v[3]), warp_kernel=1 if v.endswith("g") else 0)
+            options.set(mode="parallel", update_mode=int(v[3]), warp_kernel=1 if v.endswith("g") else 0,
+                        debug=int(os.environ.get("QUALITY_DEBUG", "0")))  # QUALITY_DEBUG: lfm_opts.debug bits (kernel experiments)
             m = LightFM(no_components=64, loss="warp", random_state=seed)
             m.fit(train, epochs=epochs, num_threads=1)
         dt = time.time() - t

@@ -730,6 +730,42 @@ PY
   bash tools/profile2.sh r05_c2 --config c2
   bash tools/profile2.sh r05_c4shard --config c4shard
   ;;
+r5f)
+  # kernel experiments, one box: user rows by plain stores (debug 2048) on c2 / c4shard, no bias snapshots on the C4 shard (debug 32),
+  # the next epoch's shuffle written under the current epoch (on / off), the staleness A/B under the shipped ramp
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 2 --steady-seconds 3 --steps 20 --warmup 5"
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-34s %8.1f M/s (fits %s)  frac %.3f  launch %.3f ms  U %.3f | steady %8.1f M/s frac %.3f" % (
+        sys.argv[1], d["value"] / 1e6, [round(x / 1e6) for x in d["config"].get("fresh_fits", [])], r["frac"], r["avg_launch_ms"],
+        r["updates_per_interaction"], ss.get("value", 0) / 1e6, ss.get("kernel_frac", 0)))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  for rep in 1 2; do
+    for arm in "c2:default:" "c2:ustore:--debug 2048" "c2:noahead:" ; do
+      IFS=: read cfg name extra <<< "$arm"
+      if [ "$name" = noahead ]; then export LIGHTFM_AMD_SHUFFLE_AHEAD=0; else export LIGHTFM_AMD_SHUFFLE_AHEAD=1; fi
+      timeout 300 python3 bench.py $S --config $cfg $extra > $OUT/${cfg}_${name}_$rep.json 2> $OUT/${cfg}_${name}_$rep.err
+      line "$cfg $name run $rep" $OUT/${cfg}_${name}_$rep.json
+    done
+  done
+  export LIGHTFM_AMD_SHUFFLE_AHEAD=1
+  S4="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 2 --steps 8 --warmup 3"
+  for rep in 1 2; do
+    for arm in "c4shard:default:" "c4shard:nosnap:--debug 32" "c4shard:ustore:--debug 2048" "c4shard:both:--debug 2080"; do
+      IFS=: read cfg name extra <<< "$arm"
+      timeout 300 python3 bench.py $S4 --config $cfg $extra > $OUT/${cfg}_${name}_$rep.json 2> $OUT/${cfg}_${name}_$rep.err
+      line "$cfg $name run $rep" $OUT/${cfg}_${name}_$rep.json
+    done
+  done
+  QUALITY_DEBUG=0 timeout 600 python3 tools/quality20m.py 3 20000 1,2,3,4,5,6,7,8 hip0 > $OUT/quality_default.txt 2>&1; tail -1 $OUT/quality_default.txt
+  QUALITY_DEBUG=2048 timeout 600 python3 tools/quality20m.py 3 20000 1,2,3,4,5,6,7,8 hip0 > $OUT/quality_ustore.txt 2>&1; tail -1 $OUT/quality_ustore.txt
+  AHEAD_RAMP=1 timeout 600 python3 tools/ahead_staleness.py 12 10 > $OUT/ahead_staleness_ramp.txt 2>&1; grep -a " x " $OUT/ahead_staleness_ramp.txt | tail -12
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
