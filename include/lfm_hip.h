@@ -319,12 +319,13 @@ int lfm_session_comm_merge(lfm_session *s, int32_t sides, int32_t mode);
  * lfm_session_comm_merge_flush (call it before reading the tables: check_finite, sync_to_host, the end of
  * an epoch).  *bytes (may be NULL) = what this rank handed to RCCL.  Same modes and the same arithmetic as the dense merge
  * (adadelta models carry their momentum tables too; LFM_MERGE_ADAGRAD means LFM_MERGE_MEAN for them, as there).
- * Per side and merge the packed deltas of all kinds are ONE buffer: one pack launch, one all-reduce (two in
- * LFM_MERGE_ADAGRAD mode: accumulators, then the rescaled embedding deltas), one apply launch.  Once a merge's union has
- * covered >= 90 % of a side's rows (lfm_session_set_merge_dense_fraction) the following merges of that side skip the
- * detection, the all-reduce of the byte maps and the compaction and carry every row: bit-identical (an untouched row's
- * deltas are zeros), and what a small, fully touched table (ML-20M's 26 744 item rows) costs is then three to five
- * launches instead of sixteen and a host round trip. */
+ * Per side and merge the packed deltas of all kinds are ONE buffer and travel in ONE all-reduce, whatever the mode: one
+ * pack launch, one exchange, one apply launch (LFM_MERGE_ADAGRAD sends dW sqrt(G0 + dG / 2) next to dG and divides the
+ * summed numerators by sqrt(G0 + sum dG / 2) when applying: the same step as the dense merge's two exchanges up to
+ * float rounding).  Once a merge's union has covered >= 90 % of a side's rows (lfm_session_set_merge_dense_fraction) the
+ * following merges of that side skip the detection, the all-reduce of the byte maps and the compaction and carry
+ * every row: bit-identical (an untouched row's deltas are zeros), and what a small, fully touched table (ML-20M's
+ * 26 744 item rows) costs is then three launches instead of sixteen and a host round trip. */
 int lfm_session_comm_merge_sparse(lfm_session *s, int32_t sides, int32_t mode, int32_t overlap, int64_t *bytes);
 int lfm_session_comm_merge_flush(lfm_session *s);
 int lfm_session_set_merge_dense_fraction(lfm_session *s, float fraction);

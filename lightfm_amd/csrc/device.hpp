@@ -87,6 +87,8 @@ struct FitArgs {
     unsigned long long *counters;  // [13]: 4 event counters, 8 phase timers, the fault flag (guard_row)
     const uint32_t *bloom;         // Bloom filter over the positives lookup (struct Bloom below), nullptr = none
     ItemShards shards;             // owner-sharded item tables (n = 0: none)
+    int32_t user_store;            // parallel mode: the USER row of an update (identity user features: touched by that user's
+                                   // interactions alone) is written with plain stores instead of float atomics (session.hip)
     float *reg_live;               // [RegScale::FLOATS] parallel mode, lazy L2 regularisation (see RegScale): line 0 =
                                    // min(item_scale, MAX), min(user_scale, MAX) at the last launch boundary, lines 1.. =
                                    // the slots collecting the growth of log(scale) since then (float atomics)

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
     const bool fastd = d == DF;
     const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
+    const bool ustore = a.user_store && um == 0;  // user-side rows (identity user features): plain stores, FitArgs::user_store
     const int max_sampled = a.m.max_sampled;
     const int cand_base = a.cand_base, CB = RR - cand_base;  // candidate rows of the tile
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                             double lr;
                             cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, st_ ? alpha_u : alpha_i, nW, nG, nM, lr);
                             if constexpr (REG) lr_sum += c < a.m.d_real ? lr : 0.0;
-                            publish(Wp + c, nW, oW, um);
-                            publish(Gp + c, nG, oG, um);
+                            publish(Wp + c, nW, oW, (st_ && ustore) ? 1 : um);
+                            publish(Gp + c, nG, oG, (st_ && ustore) ? 1 : um);
                         }
                     }
                 }
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
                 cell_math(obW, obG, 0.0f, (double)e.w, gb, h, e.eside ? alpha_u : alpha_i, nW, nG, nM, lr);
                 if (mine) {
                     if constexpr (REG) lr_sum += lr;
-                    publish(bp, nW, obW, um);
-                    publish(bgp, nG, obG, um);
+                    publish(bp, nW, obW, (e.eside && ustore) ? 1 : um);
+                    publish(bgp, nG, obG, (e.eside && ustore) ? 1 : um);
                 }
             }
             stamp(6);

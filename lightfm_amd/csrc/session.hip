@@ -449,6 +449,7 @@ struct lfm_session {
         bool active = false, on_comm_stream = false;
         int sides = 0;
         float wscale = 1.0f, ascale = 1.0f;  // what the summed deltas of the weights / of the accumulators are scaled by
+        int adagrad_mode = 0;                // LFM_MERGE_ADAGRAD: the weight plane carries numerators (FusedPlan)
         int64_t n_u[2] = {0, 0};
         DBuf<int32_t> ids[2];     // the union of touched rows, ascending (unused when the merge covers every row)
         bool all_rows[2] = {false, false};  // this merge covers every row of the side: no id list
@@ -1125,53 +1126,53 @@ __global__ void detect_dirty_kernel(const float *W, const float *sW, const float
         if (lane == 0) flags[r] = any ? 1 : 0;
     }
 }
-// ---- steps 3-5 on ONE buffer per side.  The packed deltas of all kinds of a side live in one allocation, kind after
-// kind: adagrad [G | bG | W | b], adadelta [G | bG | M | bM | W | b] (accumulators first: LFM_MERGE_ADAGRAD reduces them
-// before the weights), each kind n_u rows of w = d or 1 floats.  One pack, one (two) all-reduce(s), one apply per side
-// and merge -- the merge of a small table (ML-20M's 26 744 item rows: 14 MB) is bound by its launches, not its bytes.
-struct FusedSeg { float *tab, *snap; int64_t off; int w; float scale; };
+// ---- steps 3-5 on ONE buffer per side and ONE all-reduce per merge.  A side's packed deltas live in one allocation of
+// K planes of P = n_u (d + 1) floats, a plane = the cells of one table kind over the union's rows: first the n_u x d
+// embedding cells (row-major over the union), then the n_u bias cells.  Planes: adagrad [accumulators | weights],
+// adadelta [accumulators | momenta | weights].  One thread owns cell r of EVERY plane (the accumulator and the weight of
+// a cell are merged together), so a merge is: one pack launch, one all-reduce over K P floats, one apply launch --
+// the merge of a small table (ML-20M's 26 744 item rows: 14 MB) is bound by its launches, not its bytes.
+// LFM_MERGE_ADAGRAD in one exchange: the merged step sum_r dW_r sqrt((G0 + dG_r / 2) / (G0 + sum dG / 2)) has a
+// rank-independent denominator, so a rank sends dW_r sqrt(G0 + dG_r / 2) next to dG_r and divides the summed
+// numerators by sqrt(G0 + sum dG / 2) when it applies them (round 4 reduced the accumulators first, rescaled, and
+// reduced the weights: two exchanges; the same quantity up to the rounding of sqrt(a) / sqrt(b) against sqrt(a / b)).
 struct FusedPlan {
-    FusedSeg seg[6];
-    int nseg;
-    int64_t total, n_u;
-    const int32_t *ids;  // nullptr: every row (u is the row)
-    __device__ __forceinline__ int find(int64_t j) const
+    float *tab[3][2], *snap[3][2];  // [plane: 0 accumulators, 1 weights, 2 momenta (adadelta)][0 embedding table, 1 bias table]
+    int planes;                     // 2 (adagrad) or 3 (adadelta)
+    int d, adagrad_mode;
+    float wscale, ascale;           // what the summed deltas of the weights / accumulators (and momenta) are scaled by
+    int64_t n_u, P;                 // rows of the union, cells per plane = n_u (d + 1)
+    const int32_t *ids;             // nullptr: every row (u is the row)
+    // buffer order: accumulators, [momenta], weights
+    __device__ __forceinline__ int64_t off_w() const { return (int64_t)(planes - 1) * P; }
+    __device__ __forceinline__ void locate(int64_t r, int &t, size_t &at) const
     {
-        int q = 0;
-#pragma unroll
-        for (int t = 1; t < 6; ++t)
-            if (t < nseg && j >= seg[t].off) q = t;
-        return q;
+        const int64_t ne = n_u * d;
+        if (r < ne) {
+            const int64_t u = r / d;
+            t = 0;
+            at = (size_t)(ids ? ids[u] : (int32_t)u) * d + (size_t)(r - u * d);
+        } else {
+            const int64_t u = r - ne;
+            t = 1;
+            at = (size_t)(ids ? ids[u] : (int32_t)u);
+        }
     }
 };
 __global__ void pack_fused_kernel(FusedPlan p, float *loc, float *sum)
 {
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t0; j < p.total; j += st) {
-        const FusedSeg &g = p.seg[p.find(j)];
-        const int64_t r = j - g.off, u = r / g.w;
-        const int c = (int)(r - u * g.w);
-        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * g.w + c;
-        const float v = g.tab[at] - g.snap[at];
-        loc[j] = v;
-        sum[j] = v;
-    }
-}
-// LFM_MERGE_ADAGRAD: dW *= sqrt((G0 + dG_rank / 2) / (G0 + dG_all / 2)), G0 from the snapshot; the accumulator segments
-// (G at seg[0], bG at seg[1]) have been reduced, the weight segments (W = seg[nseg - 2], b = seg[nseg - 1]) not yet
-__global__ void rescale_fused_kernel(FusedPlan p, float *sum, const float *loc)
-{
-    const int64_t w0 = p.seg[p.nseg - 2].off, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = w0 + t0; j < p.total; j += st) {
-        const int q = j >= p.seg[p.nseg - 1].off ? 1 : 0;  // 0: W against G, 1: b against bG
-        const FusedSeg &gw = p.seg[p.nseg - 2 + q], &ga = p.seg[q];
-        const int64_t r = j - gw.off, u = r / gw.w;
-        const int c = (int)(r - u * gw.w);
-        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * gw.w + c;
-        const float g0 = ga.snap[at];
-        const int64_t ja = ga.off + r;
-        const float num = g0 + 0.5f * loc[ja], den = g0 + 0.5f * sum[ja];
-        if (den > 0.0f && num >= 0.0f && den > num) sum[j] *= sqrtf(num / den);
+    const int64_t ow = p.off_w();
+    for (int64_t r = t0; r < p.P; r += st) {
+        int t;
+        size_t at;
+        p.locate(r, t, at);
+        const float g0 = p.snap[0][t][at];
+        const float dg = p.tab[0][t][at] - g0, dw = p.tab[1][t][at] - p.snap[1][t][at];
+        loc[r] = sum[r] = dg;
+        loc[ow + r] = dw;
+        sum[ow + r] = p.adagrad_mode ? dw * sqrtf(fmaxf(g0 + 0.5f * dg, 0.0f)) : dw;
+        if (p.planes == 3) loc[p.P + r] = sum[p.P + r] = p.tab[2][t][at] - p.snap[2][t][at];
     }
 }
 // table += scale * sum - local ; snapshot += scale * sum   (rows of U).  exact: nothing trained since the pack
@@ -1179,15 +1180,30 @@ __global__ void rescale_fused_kernel(FusedPlan p, float *sum, const float *loc)
 __global__ void apply_fused_kernel(FusedPlan p, const float *sum, const float *loc, int exact)
 {
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = t0; j < p.total; j += st) {
-        const FusedSeg &g = p.seg[p.find(j)];
-        const int64_t r = j - g.off, u = r / g.w;
-        const int c = (int)(r - u * g.w);
-        const size_t at = (size_t)(p.ids ? p.ids[u] : (int32_t)u) * g.w + c;
-        const float sv = sum[j] * g.scale;
-        const float v = g.snap[at] + sv;
-        g.tab[at] = exact ? v : g.tab[at] + (sv - loc[j]);
-        g.snap[at] = v;
+    const int64_t ow = p.off_w();
+    for (int64_t r = t0; r < p.P; r += st) {
+        int t;
+        size_t at;
+        p.locate(r, t, at);
+        const float g0 = p.snap[0][t][at], sg_raw = sum[r];
+        float sw = sum[ow + r];
+        if (p.adagrad_mode) {
+            const float den = g0 + 0.5f * sg_raw;  // (adagrad accumulators start at 1 and only grow)
+            sw = den > 0.0f ? sw / sqrtf(den) : 0.0f;
+        } else {
+            sw *= p.wscale;
+        }
+        const float sg = sg_raw * p.ascale;
+        const float ng = g0 + sg, nw = p.snap[1][t][at] + sw;
+        p.tab[0][t][at] = exact ? ng : p.tab[0][t][at] + (sg - loc[r]);
+        p.snap[0][t][at] = ng;
+        p.tab[1][t][at] = exact ? nw : p.tab[1][t][at] + (sw - loc[ow + r]);
+        p.snap[1][t][at] = nw;
+        if (p.planes == 3) {
+            const float sm = sum[p.P + r] * p.ascale, nm = p.snap[2][t][at] + sm;
+            p.tab[2][t][at] = exact ? nm : p.tab[2][t][at] + (sm - loc[p.P + r]);
+            p.snap[2][t][at] = nm;
+        }
     }
 }
 struct BytePack { unsigned char *p[16]; };
@@ -1201,24 +1217,25 @@ __global__ void local_or_kernel(BytePack xs, int k, int64_t n)
     }
 }
 
-// the kinds a sparse merge carries, in the fused buffer's order (accumulators first), and the plan of a side
-static FusedPlan fused_plan(lfm_session *s, int side, int64_t n_u, const int32_t *ids, float wscale, float ascale)
+// the plan of a side's merge (see FusedPlan)
+static FusedPlan fused_plan(lfm_session *s, int side, int64_t n_u, const int32_t *ids, float wscale, float ascale, int adagrad_mode)
 {
-    static const int ADAGRAD_KINDS[4] = {1, 4, 0, 3};        // G, bG, W, b
-    static const int ADADELTA_KINDS[6] = {1, 4, 2, 5, 0, 3};  // G, bG, M, bM, W, b
     FusedPlan p;
     memset(&p, 0, sizeof(p));
-    p.nseg = s->adadelta ? 6 : 4;
+    p.planes = s->adadelta ? 3 : 2;
+    static const int KIND[3][2] = {{1, 4}, {0, 3}, {2, 5}};  // accumulators (G, bG), weights (W, b), momenta (M, bM)
+    for (int pl = 0; pl < p.planes; ++pl)
+        for (int t = 0; t < 2; ++t) {
+            p.tab[pl][t] = s->tab[side][KIND[pl][t]].p;
+            p.snap[pl][t] = s->snap[side][KIND[pl][t]].p;
+        }
+    p.d = s->d;
+    p.adagrad_mode = adagrad_mode;
+    p.wscale = wscale;
+    p.ascale = ascale;
     p.n_u = n_u;
+    p.P = n_u * ((int64_t)s->d + 1);
     p.ids = ids;
-    int64_t off = 0;
-    for (int q = 0; q < p.nseg; ++q) {
-        const int kind = s->adadelta ? ADADELTA_KINDS[q] : ADAGRAD_KINDS[q];
-        const bool is_weight = kind == 0 || kind == 3;
-        p.seg[q] = FusedSeg{s->tab[side][kind].p, s->snap[side][kind].p, off, kind < 3 ? s->d : 1, is_weight ? wscale : ascale};
-        off += n_u * p.seg[q].w;
-    }
-    p.total = off;
     return p;
 }
 static int64_t fused_row_floats(const lfm_session *s) { return (s->adadelta ? 3 : 2) * ((int64_t)s->d + 1); }
@@ -1232,8 +1249,9 @@ static int complete_pending(lfm_session *s, bool exact)
         if (!((s->pend.sides >> side) & 1)) continue;
         const int64_t n_u = s->pend.n_u[side];
         if (n_u == 0) continue;
-        const FusedPlan p = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, s->pend.wscale, s->pend.ascale);
-        apply_fused_kernel<<<grid_for(p.total), 256, 0, s->stream>>>(p, s->pend.sum[side].p, s->pend.loc[side].p, exact ? 1 : 0);
+        const FusedPlan p = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, s->pend.wscale, s->pend.ascale,
+                                       s->pend.adagrad_mode);
+        apply_fused_kernel<<<grid_for(p.P), 256, 0, s->stream>>>(p, s->pend.sum[side].p, s->pend.loc[side].p, exact ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     s->pend.active = false;
@@ -1267,7 +1285,6 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
     const float wscale = mode == LFM_MERGE_MEAN ? 1.0f / (float)nranks_total : 1.0f;
     const float ascale = s0->adadelta ? wscale : 1.0f;  // adadelta's accumulators are moving averages: averaged like the weights
     const int64_t row_floats = fused_row_floats(s0);
-    FusedPlan plans[16][2];
     for (int side = 0; side < 2; ++side) {
         if (!((sides >> side) & 1)) continue;
         const int64_t nf = s0->n_feat[side];
@@ -1339,8 +1356,9 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
             lfm_session *s = ss[i];
             LFM_TRY(s->pend.sum[side].reserve((size_t)(n_u * row_floats)));
             LFM_TRY(s->pend.loc[side].reserve((size_t)(n_u * row_floats)));
-            plans[i][side] = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, wscale, ascale);
-            pack_fused_kernel<<<grid_for(plans[i][side].total), 256, 0, st>>>(plans[i][side], s->pend.loc[side].p, s->pend.sum[side].p);
+            const FusedPlan plan = fused_plan(s, side, n_u, s->pend.all_rows[side] ? nullptr : s->pend.ids[side].p, wscale, ascale,
+                                              mode == LFM_MERGE_ADAGRAD ? 1 : 0);
+            pack_fused_kernel<<<grid_for(plan.P), 256, 0, st>>>(plan, s->pend.loc[side].p, s->pend.sum[side].p);
         }
         HIP_TRY(hipGetLastError());
         if (use_rccl) bytes += n_u * row_floats * (int64_t)sizeof(float);
@@ -1367,16 +1385,7 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         if (!((sides >> side) & 1) || s0->n_feat[side] == 0) continue;
         const int64_t n_u = s0->pend.n_u[side];
         if (n_u == 0) continue;
-        const int64_t total = n_u * row_floats;
-        if (mode == LFM_MERGE_ADAGRAD) {
-            const int64_t acc = n_u * ((int64_t)s0->d + 1);  // [G | bG] first ...
-            LFM_TRY(reduce(side, 0, acc));
-            for (int i = 0; i < k; ++i)  // ... then the embedding deltas, rescaled with every rank's squared gradients
-                rescale_fused_kernel<<<grid_for(total - acc), 256, 0, cs>>>(plans[i][side], ss[i]->pend.sum[side].p, ss[i]->pend.loc[side].p);
-            LFM_TRY(reduce(side, acc, total - acc));
-        } else {
-            LFM_TRY(reduce(side, 0, total));
-        }
+        LFM_TRY(reduce(side, 0, n_u * row_floats));  // ONE exchange in every mode (FusedPlan)
     }
     HIP_TRY(hipGetLastError());
     if (use_rccl) HIP_TRY(hipEventRecord(s0->ev_comm, cs));
@@ -1385,6 +1394,7 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
         ss[i]->pend.sides = sides;
         ss[i]->pend.wscale = wscale;
         ss[i]->pend.ascale = ascale;
+        ss[i]->pend.adagrad_mode = mode == LFM_MERGE_ADAGRAD ? 1 : 0;
         ss[i]->pend.on_comm_stream = use_rccl;
     }
     if (!overlap) {
@@ -1920,6 +1930,18 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // together with its row instead of after the scoring pass for the violators only)
     a.bloom = (s->bloom_valid && !(opts->debug & 256)) ? s->bloom.p : nullptr;
     a.shards = s->shards;
+    {
+        // The user row of an update by plain stores instead of float atomics (FitArgs::user_store; warp_tile_ahead.hpp): identity
+        // user features (a user's row is touched by that user's interactions alone), uncached tables (a store is then visible to
+        // every XCD), atomic publication, adagrad, and a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of
+        // tables) the same switch LOST 5-10 % (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit
+        // 11 (2048) forces it for uncached tables of any size, bit 12 (4096) switches it off.
+        size_t bytes = 0;
+        for (int side = 0; side < 2; ++side)
+            for (int kk = 0; kk < 6; ++kk) bytes += s->tab[side][kk].n * sizeof(float);
+        const bool eligible = !serial && a.update_mode == 0 && s->usf.identity && s->tab[1][0].flags != 0 && !s->adadelta && s->shards.n == 0;
+        a.user_store = (eligible && !(opts->debug & 4096) && (bytes <= ((size_t)192 << 20) || (opts->debug & 2048))) ? 1 : 0;
+    }
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
     // never calls log(): PYX:881 / C_OMP:7446 (WARP), PYX:1039 / C_OMP:8452 (k-OS).
@@ -2092,8 +2114,13 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         const int64_t slice = std::max<int64_t>(1, (s->n + L - 1) / L);
         const size_t generic_smem = smem;
         const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);
-        if (snap_biases)
-            for (int side = 0; side < 2; ++side)
+        // ... a side's bias table is snapshot only while it fits an L2 with room to spare (2 MiB): the C4 shard's 20 MB of item
+        // biases miss the L2s anyway, and a miss of the cached snapshot fetches a 128-byte line where the uncached live table
+        // answers a 4-byte read with less (C4 shard +2-8 % without snapshots, profiles/r05_visit_f.txt)
+        bool snap_side[2] = {false, false};
+        for (int side = 0; side < 2; ++side) snap_side[side] = snap_biases && tab_count(s, side, 3) * sizeof(float) <= ((size_t)2 << 20);
+        for (int side = 0; side < 2; ++side)
+            if (snap_side[side])
                 for (int par = 0; par < 2; ++par) LFM_TRY(s->bias_snap[side][par].alloc(tab_count(s, side, 3)));
         // Consecutive full-residency launches go to two streams alternately: the wavefronts of a launch finish
         // unevenly (same number of passes each, passes of different length: a tail of ~100 us in which the chip
@@ -2209,8 +2236,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 // Updates still read and publish the live tables.  (LFM debug bit 5 disables it.)
                 a.b_read[0] = a.m.b[0];
                 a.b_read[1] = a.m.b[1];
-                if (snap_biases) {
+                {
                     for (int side = 0; side < 2; ++side) {
+                        if (!snap_side[side]) continue;
                         const int64_t cnt = (int64_t)tab_count(s, side, 3);
                         if (cnt) {
                             const int cgrid = (int)std::min<int64_t>(1024, (cnt + 255) / 256);

@@ -15,7 +15,7 @@ size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch)
 hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used)
 {
     void (*kernel)(FitArgs) = a.shards.n > 0 ? fit_warp_tile_ahead_kernel<10, true> : fit_warp_tile_ahead_kernel<10, false>;
-    if (a.shards.n == 0 && (a.debug & 2048)) kernel = fit_warp_tile_ahead_kernel<10, false, true>;  // user rows by plain stores
+    if (a.shards.n == 0 && a.user_store) kernel = fit_warp_tile_ahead_kernel<10, false, true>;  // user rows by plain stores
     const size_t smem = tile_ahead_smem<10>();
     if (cus > 0) {
         const int per_cu = occupancy_cached(kernel, 256, smem);

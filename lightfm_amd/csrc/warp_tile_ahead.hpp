@@ -98,11 +98,12 @@ struct ItemAddr {
     }
 };
 
-// USTORE: the USER row of an update is written with plain stores instead of float atomics (experiment, lfm_opts.debug
-// bit 11 = 2048; uncached tables only: a store is then visible to every XCD).  With identity user features a user's row
+// USTORE (FitArgs::user_store, decided by the session): the USER row of an update is written with plain stores instead of
+// float atomics (uncached tables only: a store is then visible to every XCD).  With identity user features a user's row
 // is touched by that user's interactions alone, so what a plain read-modify-write can lose is one of two updates of the
 // same user that are in flight at the same time -- the reference's own Hogwild race -- and a third of C2's float
-// atomics (2 x 64 of 390 per update) leave the atomic unit.
+// atomics (2 x 64 of 390 per update) leave the atomic unit: C2 1.25 -> 1.44 G interactions/s in a one-box A/B,
+// precision@10 0.1743 against 0.1747 (8 seeds each; profiles/r05_visit_f.txt).
 template <int NBF, bool SHARDED = false, bool USTORE = false>
 __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 {

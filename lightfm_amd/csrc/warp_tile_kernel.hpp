@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     const uint32_t base_seed = a.seeds[0];
     const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
+    const int umU = (a.user_store && um == 0) ? 1 : um;  // the user row of an update: see FitArgs::user_store
     const uint32_t *bloom = a.bloom;              // in_positives pre-filter, nullptr = none
     // when the filter is probed: after the scoring pass, by the violating candidates only (default: one round trip
     // with the speculative accumulator loads instead of the search's two; C2 +5 %, C4 shard +7 % against the
@@ -688,8 +689,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                     publish(aP + cq, nGr[q][0], gP[gg][q], um);
                                     publish(wN + cq, nWr[q][1], oWr[q][1], um);
                                     publish(aN + cq, nGr[q][1], gN[gg][q], um);
-                                    publish(wU + cq, nWr[q][2], oWr[q][2], um);
-                                    publish(aU + cq, nGr[q][2], gU[gg][q], um);
+                                    publish(wU + cq, nWr[q][2], oWr[q][2], umU);  // (FitArgs::user_store: plain stores)
+                                    publish(aU + cq, nGr[q][2], gU[gg][q], umU);
                                 }
                             }
                         }

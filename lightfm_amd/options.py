@@ -34,6 +34,9 @@ device             the GPU LightFM.fit_partial / predict / predict_rank run on (
                    DistributedFit and bench.py take theirs from the rank).
 shuffle_ahead      with device_shuffle: the permutation of epoch e + 1 is written on a stream of its own while epoch e
                    trains (two slots alternate; lfm_session_device_shuffle_ahead).  The RandomState draws keep their order.
+                   Off by default: measured without effect on C2 (1.250 / 1.249 against 1.261 / 1.238 G interactions/s,
+                   profiles/r05_visit_f.txt -- the 0.36 ms the shuffle takes alone it takes from the epoch kernels when
+                   it runs beside them).
 host_positives     True: the positives lookup is built on the host (interactions.tocsr(), LFM:365-372)
                    and uploaded; False (default): built on the device from the uploaded COO.
 
@@ -60,7 +63,7 @@ class _Options(object):
         self.device = int(os.environ.get("LIGHTFM_AMD_DEVICE", "0"))
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.host_positives = os.environ.get("LIGHTFM_AMD_HOST_POSITIVES", "0") != "0"
-        self.shuffle_ahead = os.environ.get("LIGHTFM_AMD_SHUFFLE_AHEAD", "1") != "0"
+        self.shuffle_ahead = os.environ.get("LIGHTFM_AMD_SHUFFLE_AHEAD", "0") != "0"
         self.cache_scoring_session = os.environ.get("LIGHTFM_AMD_CACHE_SCORING", "1") != "0"
         self.log_samples = False
         self.last_counters = None

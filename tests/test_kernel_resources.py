@@ -75,11 +75,13 @@ def test_gather_ahead_kernel_budget_and_waits(tmp_path):
     variant is about -- no wait for outstanding memory operations between the top of a pass and the gather of the
     next one (a compiler-placed vmcnt(0) there would wait for the previous pass's atomics)."""
     k = _usage("warp_tile_ahead.hip", tmp_path)
-    for frag in ("fit_warp_tile_ahead_kernelILi10ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1EEE"):  # plain, owner-sharded items
+    FRAGS = ("fit_warp_tile_ahead_kernelILi10ELb0ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1ELb0EEE",   # plain, owner-sharded items,
+             "fit_warp_tile_ahead_kernelILi10ELb0ELb1EEE")                                                  # user rows by plain stores
+    for frag in FRAGS:
         u = _one(k, frag)
         assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 3, (frag, u)
     bodies = _asm("warp_tile_ahead.hip", tmp_path)
-    for frag in ("fit_warp_tile_ahead_kernelILi10ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1EEE"):
+    for frag in FRAGS:
         lines = [b for n, b in bodies.items() if frag in n][0].splitlines()
         dma = [i for i, l in enumerate(lines) if "global_load_lds_dword " in l]   # the bias DMAs end a gather
         assert len(dma) == 4, (frag, dma)                                         # prologue + in-loop gather, two each
