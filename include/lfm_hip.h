@@ -134,6 +134,10 @@ typedef struct lfm_opts {
     int32_t streams_used;       /* out: HIP streams the epoch's launches were spread over: 2 when consecutive
                                    full-residency launches of the tile kernel alternated between the session's
                                    two streams (see `debug` bit 7), else 1                                      */
+    int32_t user_store;         /* out: 1 when the epoch wrote the USER rows of its updates with plain stores instead of float
+                                   atomics: parallel mode, identity user features, uncached tables, adagrad, a model of <= 192 MB
+                                   and >= 8 users per interaction in flight (csrc/session.hip; `debug` bit 11 = 2048 forces it for
+                                   uncached tables, bit 12 = 4096 switches it off)                                  */
     int32_t tile_ahead;         /* out: 1 when the epoch's last launch ran the steady-state variant of the tile kernel
                                    with the next pass's gather issued inside the current pass (csrc/warp_tile_ahead.hpp;
                                    `debug` bit 10 = 1024 keeps the plain tile kernel)                            */

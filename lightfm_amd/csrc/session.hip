@@ -1930,17 +1930,23 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // together with its row instead of after the scoring pass for the violators only)
     a.bloom = (s->bloom_valid && !(opts->debug & 256)) ? s->bloom.p : nullptr;
     a.shards = s->shards;
+    int base_user_store = 0;
     {
         // The user row of an update by plain stores instead of float atomics (FitArgs::user_store; warp_tile_ahead.hpp): identity
         // user features (a user's row is touched by that user's interactions alone), uncached tables (a store is then visible to
-        // every XCD), atomic publication, adagrad, and a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of
-        // tables) the same switch LOST 5-10 % (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit
-        // 11 (2048) forces it for uncached tables of any size, bit 12 (4096) switches it off.
+        // every XCD), atomic publication, adagrad.  What a plain read-modify-write loses is one of two updates of the SAME user
+        // that are in flight together, so the switch needs many more users than interactions in flight: measured precision@10
+        // cost -0.0032 at 1.4 users per interaction in flight (the 1/8-scale gate of tests/test_precision_parity.py, which
+        // failed) and -0.0004 at 11 (C2, 8 seeds) -- proportional to in-flight / users.  Rule: >= 8 users per interaction of a
+        // full-residency launch (48 per CU), and a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of tables)
+        // the same switch LOST 5-10 % (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit 11
+        // (2048) forces it for uncached tables of any size and user count, bit 12 (4096) switches it off.
         size_t bytes = 0;
         for (int side = 0; side < 2; ++side)
             for (int kk = 0; kk < 6; ++kk) bytes += s->tab[side][kk].n * sizeof(float);
         const bool eligible = !serial && a.update_mode == 0 && s->usf.identity && s->tab[1][0].flags != 0 && !s->adadelta && s->shards.n == 0;
-        a.user_store = (eligible && !(opts->debug & 4096) && (bytes <= ((size_t)192 << 20) || (opts->debug & 2048))) ? 1 : 0;
+        const bool many_users = (int64_t)s->n_feat[1] >= 8LL * 48 * (int64_t)std::max(1, s->cus);
+        base_user_store = a.user_store = (eligible && !(opts->debug & 4096) && ((many_users && bytes <= ((size_t)192 << 20)) || (opts->debug & 2048))) ? 1 : 0;
     }
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
@@ -2289,6 +2295,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     opts->launches = n_launches;
     opts->streams_used = used_second_stream ? 2 : 1;
     opts->tile_ahead = (tile_ng_used == 4 && tile[4].ahead) ? 1 : 0;
+    opts->user_store = (base_user_store && (tile_ng_used || use_feat)) ? 1 : 0;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));

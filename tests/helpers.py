@@ -106,7 +106,7 @@ def assert_states_within_ulps(a, b, ulps=1, min_exact=0.5):
         top = np.float32(max(np.abs(x).max(), np.abs(y).max()))
         tol = ulps * float(np.spacing(top))
         err = np.abs(x.astype(np.float64) - y.astype(np.float64))
-        print("within_ulps %-28s max err %.2f ulp of %g, bit-identical %.4f" % (n, err.max() / float(np.spacing(top)), top, np.mean(x == y)))
+        print("within_ulps %-28s max err %.2f ulp of %g, bit-identical %.4f" % (n, err.max() / max(float(np.spacing(top)), 1e-45), top, np.mean(x == y)))
         assert err.max() <= tol, "%s: %d cells beyond %d ulp of %g, max abs %g" % (
             n, int((err > tol).sum()), ulps, top, err.max())
         assert np.mean(x == y) >= min_exact, "%s: only %.3f of the cells bit-identical" % (n, np.mean(x == y))

@@ -250,13 +250,16 @@ def _conflict_free(nu, ni, n, per_launch, ms, rng, attempts=200):
     raise AssertionError("no conflict-free arrangement found")
 
 
+@pytest.mark.parametrize("ustore", [False, True], ids=["atomics", "user-rows-stored"])
 @pytest.mark.parametrize("per_launch", [4, 32], ids=["one-pass", "four-waves-two-passes"])
-def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch):
+def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore):
     """The kernel bench.py's headline runs on (fit_warp_tile_ahead_kernel: update_mode 0, debug 0 apart from the forced
     lane-group width the session picks at full residency anyway), with NON-ZERO updates under concurrency: four lane
     groups of a wavefront update in the same pass (speculative cU / cP / cN copies, the four-at-once bias cells);
     with 32 positions per launch four wavefronts run two passes each, the second pass's rows requested before the
-    first publishes.  No two interactions of a launch share a row, so the result is the sequential oracle's."""
+    first publishes.  No two interactions of a launch share a row, so the result is the sequential oracle's.
+    "user-rows-stored": the instantiation that writes the user row of an update with plain stores (lfm_opts.user_store;
+    the session picks it for models with >= 8 users per interaction in flight -- C2 -- here forced by debug bit 11)."""
     from lightfm_amd.options import options
     d, ms = 64, 10
     nu, ni, n = (400, 40000, 160) if per_launch == 4 else (800, 300000, 256)
@@ -265,9 +268,10 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch):
     _spread(st)
     st.item_biases[:] = np.random.RandomState(3).randn(ni).astype(np.float32) * 0.3
     a, b = st.copy(), st.copy()
-    options.set(log_samples=True, launches_per_epoch=n // per_launch, update_mode=0, debug=4, max_waves=16)
+    options.set(log_samples=True, launches_per_epoch=n // per_launch, update_mode=0, debug=4 | (2048 if ustore else 0), max_waves=16)
     _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
     assert options.last_tile_ahead == 1 and options.last_tile_ng == 4, "the steady-state tile kernel did not run"
+    assert options.last_user_store == int(ustore)  # (a few hundred users: the session's own rule says atomics)
     o = _orc_warp(coo, b, shuffle, seeds, coo.data)
     neg, sampled = options.last_logs
     assert np.array_equal(sampled, o.sampled)
