@@ -509,8 +509,10 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     # global_atomic_add_f32 per table (W, G), and the chip executes a fixed ~320 G of them per second
     # (tools/membench.hip, profiles/r02_membench.txt; profiles/README.md "bench line").
     n_upd = counters[2] if loss != "logistic" else float(n_local) * n_epochs
-    rows_upd = (1.0 + 2.0 * f_i) if loss != "logistic" else (1.0 + f_i)
+    ustore = bool(int(getattr(stats[-1], "user_store", 0)))  # user rows written with plain stores (lfm_opts.user_store)
+    rows_upd = ((0.0 if ustore else 1.0) + 2.0 * f_i) if loss != "logistic" else ((0.0 if ustore else 1.0) + f_i)
     atomics = float(n_upd) * rows_upd * (d + 1) * 2.0
+    roofline["user_rows_by_plain_stores"] = ustore
     roofline["atomic_unit"] = {"achieved": atomics / kernel_s / 1e9, "peak": ATOMIC_PEAK_GOPS, "unit": "G float atomics/s",
                                "frac": atomics / kernel_s / 1e9 / ATOMIC_PEAK_GOPS,
                                "atomics_per_interaction": atomics / max(1.0, counters[0])}

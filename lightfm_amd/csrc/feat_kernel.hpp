@@ -59,8 +59,14 @@ struct Entries {
 // in_positives, 1 CSR extents + entry lists, 2 representation row gathers, 3 reduction into the
 // tile, 4 scoring and loss, 5 update row gathers (W and G), 6 cell arithmetic + publication,
 // 7 everything else (loop tail, logs).
+// Register budget: left alone the k-OS instantiation takes 129-133 VGPRs -- one too many for a fourth wavefront per SIMD.
+// Under a launch bound of four it compiles to 106-120 without scratch (tests/test_kernel_resources.py), and 16 wavefronts per
+// CU with a 10 KB LDS budget each (feat_kernels.hip: feat_plan) beat the 12 of round 4 by 2.9 % on the C5 shard (59.15 ->
+// 60.87 M interactions/s at --scale 0.25; the same kernel at 12 wavefronts loses 1.3 % to the tighter allocation;
+// profiles/r05_visit_i.txt): the kernel is instruction-bound, residency buys little.
+#define LFM_FEAT_MIN_BLOCKS(LOSS, TIMED) (((LOSS) == 3 && !(TIMED)) ? 4 : 2)
 template <int LOSS, int NC, bool TIMED = false, bool REG = false>
-__global__ __launch_bounds__(256, 2) void fit_feat_kernel(FitArgs a)
+__global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_feat_kernel(FitArgs a)
 {
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {

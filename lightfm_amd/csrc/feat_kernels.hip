@@ -45,11 +45,16 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     const size_t floor_b = d > 64 ? 12 * 1024 : 6 * 1024;
     size_t budget = budget_kb > 0 ? (size_t)budget_kb * 1024
                                   : std::min<size_t>(19 * 1024, std::max(floor_b, tile_bytes + (size_t)16 * d * 4 + 256));
-    // WARP / k-OS (not bound by the atomic unit): 12 wavefronts per CU when a twelfth of the LDS still stages >= 8 rows
-    int waves_per_cu = 8;
+    // WARP / k-OS (not bound by the atomic unit): 12 wavefronts per CU when a twelfth of the LDS still stages >= 8 rows;
+    // k-OS (held to 128 VGPRs, feat_kernel.hpp): 16 when a sixteenth still stages 6
+    int waves_per_cu = 8, min_sr = 8;
     if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID)) {
-        const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255;
-        if (b12 >= tile_bytes + 2 * WAVE * 4 + (size_t)8 * d * 4) {
+        const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255, b16 = (size_t)(160 * 1024 / 16);
+        if (loss == LFM_LOSS_WARP_KOS_ID && b16 >= tile_bytes + 2 * WAVE * 4 + (size_t)6 * d * 4) {
+            budget = b16;
+            waves_per_cu = 16;
+            min_sr = 6;
+        } else if (b12 >= tile_bytes + 2 * WAVE * 4 + (size_t)8 * d * 4) {
             budget = b12;
             waves_per_cu = 12;
         }
@@ -62,7 +67,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
         if (fixed < budget) {
             int sr = (int)((budget - fixed) / ((size_t)d * 4));
             sr = std::min(sr, want) & ~1;
-            if (sr >= 8 || (sr >= 6 && budget_kb > 0) || (sr >= 4 && cb <= 1)) {
+            if (sr >= min_sr || (sr >= 6 && budget_kb > 0) || (sr >= 4 && cb <= 1)) {
                 g.sr = sr;
                 break;
             }

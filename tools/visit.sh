@@ -766,6 +766,27 @@ PY
   QUALITY_DEBUG=2048 timeout 600 python3 tools/quality20m.py 3 20000 1,2,3,4,5,6,7,8 hip0 > $OUT/quality_ustore.txt 2>&1; tail -1 $OUT/quality_ustore.txt
   AHEAD_RAMP=1 timeout 600 python3 tools/ahead_staleness.py 12 10 > $OUT/ahead_staleness_ramp.txt 2>&1; grep -a " x " $OUT/ahead_staleness_ramp.txt | tail -12
   ;;
+r5i)
+  # k-OS row-stream kernel held to 128 VGPRs (build -DLFM_KOS_WAVES4 -> lightfm_amd/_lib_kos4): 16 wavefronts per CU with a
+  # 10 KB LDS budget per wavefront (6 staged rows) against the shipped 12; C5 shard at --scale 0.25
+  S="--config c5shard --scale 0.25 --no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 0 --steps 3 --warmup 1"
+  run() { name=$1; shift; env "$@" timeout 300 python3 bench.py $S > $OUT/$name.json 2> $OUT/$name.err
+    python3 - "$name" $OUT/$name.json <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]
+    print("  %-28s %7.2f M/s  frac %.3f  launch %.2f ms  in flight %d  kernel %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], r["kernel"]))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  for rep in 1 2; do
+    run default12_$rep LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib/liblfm_hip.so
+    run kos4_12_$rep LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_kos4/liblfm_hip.so
+    run kos4_16_lds10_$rep LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_kos4/liblfm_hip.so LIGHTFM_AMD_FEAT_WAVES_PER_CU=16 LIGHTFM_AMD_FEAT_LDS_KB=10
+    run kos4_14_lds11_$rep LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_kos4/liblfm_hip.so LIGHTFM_AMD_FEAT_WAVES_PER_CU=14 LIGHTFM_AMD_FEAT_LDS_KB=11
+  done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
