@@ -325,8 +325,8 @@ def kernel_label(loss, d, stats_last, reg, options):
     from lightfm_amd import _native as N
     ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
     dp = (d + 3) // 4 * 4
-    if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):
-        return "fit_warp_tile_ahead_kernel<10, false>"
+    if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):  # <candidates, owner-sharded item tables, user rows by plain stores>
+        return "fit_warp_tile_ahead_kernel<10, false, %s>" % ("true" if int(getattr(stats_last, "user_store", 0)) else "false")
     if used == 1:
         return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",

@@ -73,7 +73,7 @@ EXPORTS = (
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
-    "lfm_device_trim", "lfm_device_pool_stats", "lfm_host_scan_f32",
+    "lfm_device_trim", "lfm_device_pool_stats", "lfm_host_scan_f32", "lfm_host_mt19937_table",
     "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush", "lfm_session_set_merge_dense_fraction",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
@@ -154,6 +154,25 @@ def host_scan(a):
         check(lib().lfm_host_scan_f32(f32p(a), C.c_int64(a.size), C.byref(ones), C.byref(fin)))
         return bool(ones.value), bool(fin.value)
     return bool(np.array_equiv(a, 1.0)), bool(np.isfinite(np.sum(a)))
+
+
+def init_table(random_state, rows, d):
+    """((random_state.rand(rows, d) - 0.5) / d).astype(float32) -- the reference's embedding initialisation
+    (LFM:281-312) -- drawn by the native restatement of numpy's MT19937 stream (lfm_host_mt19937_table) on the
+    RandomState's own state; numpy itself when the library is not built or the generator is not a legacy MT19937."""
+    if isinstance(random_state, np.random.RandomState) and rows * d >= (1 << 14) and os.path.exists(LIB_PATH):
+        st = random_state.get_state()
+        if st[0] == "MT19937":
+            key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+            pos = C.c_int32(int(st[2]))
+            out = np.empty((rows, d), np.float32)
+            check(lib().lfm_host_mt19937_table(key.ctypes.data_as(U32P), C.byref(pos), f32p(out), C.c_int64(rows * d), C.c_int32(d)))
+            random_state.set_state((st[0], key, pos.value, st[3], st[4]))
+            return out
+    draw = random_state.rand(rows, d)  # float64; the two steps below in place: the same values as
+    draw -= 0.5                        # ((rand - 0.5) / d).astype(float32) without two temporaries
+    draw /= d
+    return draw.astype(np.float32)
 
 
 def device_trim():

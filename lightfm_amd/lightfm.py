@@ -456,10 +456,8 @@ class LightFM(object):
         """LFM:281-312 -- item table drawn first, then the user table."""
         start = np.ones if self.learning_schedule == "adagrad" else np.zeros  # accumulators: 1 (adagrad) / 0
         for side, rows in (("item", no_item_features), ("user", no_user_features)):
-            draw = self.random_state.rand(rows, no_components)  # float64; the two steps below in place: the same
-            draw -= 0.5                                         # values as ((rand - 0.5) / d).astype(float32)
-            draw /= no_components                               # without two temporaries of the table's size
-            setattr(self, side + "_embeddings", draw.astype(np.float32))
+            # ((rand(rows, d) - 0.5) / d).astype(float32) on the model's RandomState stream, natively (N.init_table)
+            setattr(self, side + "_embeddings", N.init_table(self.random_state, rows, no_components))
             setattr(self, side + "_embedding_gradients", start((rows, no_components), dtype=np.float32))
             setattr(self, side + "_embedding_momentum", np.zeros((rows, no_components), dtype=np.float32))
             setattr(self, side + "_biases", np.zeros(rows, dtype=np.float32))

@@ -315,3 +315,46 @@ def test_session_opens_on_the_configured_device(monkeypatch):
     L._Session(m._get_lightfm_data(), CSRMatrix(eye3), CSRMatrix(eye2))
     L._Session(m._get_lightfm_data(), CSRMatrix(eye3), CSRMatrix(eye2), device=2, scoring=True)
     assert seen == [5, 2]
+
+
+def test_native_table_initialisation_is_numpys_stream():
+    """lfm_host_mt19937_table (the embedding initialisation of LFM:281-312 restated natively on the RandomState's own
+    state): the same float32 values as ((rand(rows, d) - 0.5) / d).astype(float32) and the same generator state
+    afterwards, from fresh, mid-block, odd and end-of-block positions."""
+    from lightfm_amd import _native as N
+    import os
+    if not os.path.exists(N.LIB_PATH):
+        pytest.skip("liblfm_hip.so not built")
+    for seed, burn, rows, d in ((1, 0, 300, 64), (2, 5, 1000, 17), (3, 311, 2500, 10), (4, 623, 4096, 4), (5, 1248, 20000, 3)):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        if burn:
+            a.randint(0, 1 << 30, size=burn), b.randint(0, 1 << 30, size=burn)  # (one 32-bit output each: odd positions)
+        got = N.init_table(a, rows, d)
+        want = ((b.rand(rows, d) - 0.5) / d).astype(np.float32)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (seed, burn)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]
+        assert a.rand() == b.rand() and a.randint(0, 100) == b.randint(0, 100)
+    # the model's initialisation through it: items first, then users, one stream
+    from lightfm_amd import LightFM
+    m = LightFM(no_components=16, random_state=9)
+    m._initialize(16, 1500, 2500)
+    r = np.random.RandomState(9)
+    assert np.array_equal(m.item_embeddings, ((r.rand(1500, 16) - 0.5) / 16).astype(np.float32))
+    assert np.array_equal(m.user_embeddings, ((r.rand(2500, 16) - 0.5) / 16).astype(np.float32))
+
+
+def test_native_input_scan_matches_numpy():
+    from lightfm_amd import _native as N
+    import os
+    if not os.path.exists(N.LIB_PATH):
+        pytest.skip("liblfm_hip.so not built")
+    a = np.ones(3_000_000, np.float32)
+    assert N.host_scan(a) == (True, True)
+    a[12345] = 0.5
+    assert N.host_scan(a) == (False, True)
+    for bad in (np.inf, -np.inf, np.nan):
+        a[777] = bad
+        assert N.host_scan(a) == (False, False)
+    a[:] = 3e38   # finite values whose float32 sum is not (the reference tests isfinite(sum))
+    assert N.host_scan(a) == (False, False)
