@@ -149,9 +149,10 @@ def require(a, dtype, ndim, name):
 def host_scan(a):
     """(all values == 1.0, all finite with a finite float32 sum) of a C-contiguous float32 array in one pass
     (lfm_host_scan_f32); numpy when the library has not been built (host-side validation only)."""
-    if a.dtype == np.float32 and a.flags.c_contiguous and os.path.exists(LIB_PATH):
+    scan = getattr(lib(), "lfm_host_scan_f32", None) if os.path.exists(LIB_PATH) else None
+    if scan is not None and a.dtype == np.float32 and a.flags.c_contiguous:
         ones, fin = C.c_int32(), C.c_int32()
-        check(lib().lfm_host_scan_f32(f32p(a), C.c_int64(a.size), C.byref(ones), C.byref(fin)))
+        check(scan(f32p(a), C.c_int64(a.size), C.byref(ones), C.byref(fin)))
         return bool(ones.value), bool(fin.value)
     return bool(np.array_equiv(a, 1.0)), bool(np.isfinite(np.sum(a)))
 
@@ -160,13 +161,14 @@ def init_table(random_state, rows, d):
     """((random_state.rand(rows, d) - 0.5) / d).astype(float32) -- the reference's embedding initialisation
     (LFM:281-312) -- drawn by the native restatement of numpy's MT19937 stream (lfm_host_mt19937_table) on the
     RandomState's own state; numpy itself when the library is not built or the generator is not a legacy MT19937."""
-    if isinstance(random_state, np.random.RandomState) and rows * d >= (1 << 14) and os.path.exists(LIB_PATH):
+    fill = getattr(lib(), "lfm_host_mt19937_table", None) if os.path.exists(LIB_PATH) else None
+    if fill is not None and isinstance(random_state, np.random.RandomState) and rows * d >= (1 << 14):
         st = random_state.get_state()
         if st[0] == "MT19937":
             key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
             pos = C.c_int32(int(st[2]))
             out = np.empty((rows, d), np.float32)
-            check(lib().lfm_host_mt19937_table(key.ctypes.data_as(U32P), C.byref(pos), f32p(out), C.c_int64(rows * d), C.c_int32(d)))
+            check(fill(key.ctypes.data_as(U32P), C.byref(pos), f32p(out), C.c_int64(rows * d), C.c_int32(d)))
             random_state.set_state((st[0], key, pos.value, st[3], st[4]))
             return out
     draw = random_state.rand(rows, d)  # float64; the two steps below in place: the same values as
