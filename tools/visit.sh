@@ -787,6 +787,23 @@ PY
     run kos4_14_lds11_$rep LIGHTFM_AMD_LIB=$R/lightfm_amd/_lib_kos4/liblfm_hip.so LIGHTFM_AMD_FEAT_WAVES_PER_CU=14 LIGHTFM_AMD_FEAT_LDS_KB=11
   done
   ;;
+r5j)
+  # end-to-end fit with the native initialisation; kernel traces + counter passes of c2 (plain-store user rows), c3 and the C5 shard
+  LIGHTFM_AMD_TIMING=1 timeout 300 python3 - > $OUT/fit_timing.txt 2>&1 <<'PY'
+import time, sys
+sys.path.insert(0, ".")
+from lightfm_amd import LightFM, synthetic
+data = synthetic.named("ml-20m")
+for rep in range(4):
+    m = LightFM(no_components=64, loss="warp", random_state=3)
+    t = time.perf_counter(); m.fit(data, epochs=10); dt = time.perf_counter() - t
+    print("fit(10 epochs) %.1f ms = %.1f M interactions/s" % (1e3 * dt, data.nnz * 10 / dt / 1e6), flush=True)
+PY
+  cat $OUT/fit_timing.txt | cut -c1-330
+  bash tools/profile2.sh r05_c2 --config c2
+  PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r05_c3 --config c3
+  PROF_STEPS=3 PROF_WARMUP=1 bash tools/profile2.sh r05_c5shard --config c5shard --scale 0.25
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
