@@ -165,6 +165,9 @@ int lfm_device_trim(int64_t *released);
  * answers what LFM:383-386 (np.array_equiv(data, 1.0)) and LFM:447-472 / 617-625 (isfinite(sum)) ask in two to
  * three numpy passes.  *all_ones = every value == 1.0f; *finite = no inf / nan and the sum inside float32 range. */
 int lfm_host_scan_f32(const float *p, int64_t n, int32_t *all_ones, int32_t *finite);
+/* Host-side helper: *out = sum of word[i] * (2 i + 1) modulo 2^64 over n 32-bit words -- the signature with which the
+ * Python class re-validates a resident scoring session against the caller's weight arrays (no BLAS, four threads). */
+int lfm_host_checksum_u32(const uint32_t *p, int64_t n, uint64_t *out);
 /* Host-side helper: out[i] = (float)((u_i - 0.5) / d) for the next n uniform doubles u_i of numpy's legacy MT19937
  * stream (RandomState.rand: LFM:281-312 initialises the embedding tables with it), on the 624-word key and the position
  * of RandomState.get_state(), both updated in place -- bit-identical to numpy, values and stream position. */

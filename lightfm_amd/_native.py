@@ -73,7 +73,7 @@ EXPORTS = (
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
-    "lfm_device_trim", "lfm_device_pool_stats", "lfm_host_scan_f32", "lfm_host_mt19937_table",
+    "lfm_device_trim", "lfm_device_pool_stats", "lfm_host_scan_f32", "lfm_host_mt19937_table", "lfm_host_checksum_u32",
     "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush", "lfm_session_set_merge_dense_fraction",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",
@@ -155,6 +155,19 @@ def host_scan(a):
         check(scan(f32p(a), C.c_int64(a.size), C.byref(ones), C.byref(fin)))
         return bool(ones.value), bool(fin.value)
     return bool(np.array_equiv(a, 1.0)), bool(np.isfinite(np.sum(a)))
+
+
+def checksum(a):
+    """Position-sensitive exact signature of a C-contiguous float32 array (lfm_host_checksum_u32); a numpy restatement
+    of the same sum when the library is not built."""
+    flat = a.reshape(-1).view(np.uint32)
+    fn = getattr(lib(), "lfm_host_checksum_u32", None) if os.path.exists(LIB_PATH) else None
+    if fn is not None:
+        out = C.c_uint64()
+        check(fn(flat.ctypes.data_as(U32P), C.c_int64(flat.size), C.byref(out)))
+        return int(out.value)
+    w = np.arange(flat.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    return int(np.add.reduce(flat.astype(np.uint64) * w, dtype=np.uint64))
 
 
 def init_table(random_state, rows, d):

@@ -11,7 +11,9 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -94,6 +96,33 @@ extern "C" int lfm_host_scan_f32(const float *p, int64_t n, int32_t *all_ones, i
     }
     *all_ones = o;
     *finite = (f && fabs(total) <= 3.4028234663852886e38) ? 1 : 0;
+    return LFM_OK;
+}
+
+// Host-side signature of a weight array (LightFM._scoring_session re-validates its resident tables against the host arrays
+// before every predict / predict_rank): sum of word[i] * (2 i + 1) modulo 2^64 over the array's 32-bit words -- exact (any
+// single-word edit changes it) and position-sensitive (row / column moves change it) -- by a few host threads.  Round 4 used
+// a numpy bit-pattern sum plus a BLAS matrix-vector probe; on a 256-core box the BLAS call woke every core, which under a
+// container CPU quota (16 CPUs per 100 ms on the GPU boxes) throttled the process: every other predict_rank call stalled by
+// 75 ms (profiles/r05_visit_k.txt).
+extern "C" int lfm_host_checksum_u32(const uint32_t *p, int64_t n, uint64_t *out)
+{
+    if (n < 0 || (n && !p) || !out) return fail(LFM_EINVAL, "bad checksum arguments");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(4, n / (1 << 20)));
+    std::vector<uint64_t> part((size_t)T, 0ull);
+    auto work = [&](int t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        uint64_t acc = 0ull;
+        for (int64_t j = lo; j < hi; ++j) acc += (uint64_t)p[j] * (2ull * (uint64_t)j + 1ull);
+        part[(size_t)t] = acc;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    uint64_t total = 0ull;
+    for (int t = 0; t < T; ++t) total += part[(size_t)t];
+    *out = total;
     return LFM_OK;
 }
 
@@ -2188,8 +2217,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         const size_t generic_smem = smem;
         const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);
         // ... a side's bias table is snapshot only while it fits an L2 with room to spare (2 MiB): the C4 shard's 20 MB of item
-        // biases miss the L2s anyway, and a miss of the cached snapshot fetches a 128-byte line where the uncached live table
-        // answers a 4-byte read with less (C4 shard +2-8 % without snapshots, profiles/r05_visit_f.txt)
+        // biases miss the L2s anyway: the per-launch copies and their L2 footprint buy nothing there (C4 shard +2-8 % without
+        // snapshots, profiles/r05_visit_f.txt; the memory-side requests are 128-byte lines with or without them)
         bool snap_side[2] = {false, false};
         for (int side = 0; side < 2; ++side) snap_side[side] = snap_biases && tab_count(s, side, 3) * sizeof(float) <= ((size_t)2 << 20);
         for (int side = 0; side < 2; ++side)
@@ -2575,8 +2604,13 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     DBuf<float> urep, irep, irows, dranks, ieps, tscores;
     DBuf<int32_t> ulist, work;
     DrainOnExit drain(s->stream);
+    // LIGHTFM_AMD_TIMING=1: host wall time of the call's phases on stderr
+    static const bool timing = [] { const char *e = getenv("LIGHTFM_AMD_TIMING"); return e && atoi(e) != 0; }();
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
     LFM_TRY(dtest.upload(test, false, false));
     LFM_TRY(dtrain.upload(train, false, false));
+    const double ms_upload = since();
     int rs = ((s->d + 1 + 3) / 4) * 4;
     DCsr usf = s->usf.view(), itf = s->itf.view();
     usf.rows = test->rows;  // only users/items of the interaction matrix (PYX:1264, 1301)
@@ -2730,9 +2764,15 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
         HIP_TRY(launch_ranks(a, s->stream));
     }
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    const double ms_enqueued = since();
     HIP_TRY(hipStreamSynchronize(s->stream));
+    const double ms_synced = since();
     HIP_TRY(hipEventElapsedTime(&g_kernel_ms, s->ev0, s->ev1));
-    return dranks.download(ranks);
+    const int rc = dranks.download(ranks);
+    if (timing)
+        fprintf(stderr, "[lfm predict_ranks] uploads of test + train %.2f ms, everything enqueued at %.2f ms, device done at %.2f ms (kernels %.2f ms), "
+                        "ranks downloaded at %.2f ms\n", ms_upload, ms_enqueued, ms_synced, (double)g_kernel_ms, since());
+    return rc;
 }
 
 // ---------------------------------------------------- one-shot entry points ---

@@ -210,7 +210,7 @@ def test_weight_array_signature_sees_edits_moves_and_reassignment():
     sv = LightFM._array_signature(v)
     v[-1] += 1.0
     assert LightFM._array_signature(v)[3:] != sv[3:]
-    assert LightFM._array_signature(np.zeros((0, 8), np.float32))[2:] == (0, 0.0)
+    assert LightFM._array_signature(np.zeros((0, 8), np.float32))[2:] == (0,)
 
 
 def test_committed_traffic_feeds_the_roofline():
@@ -222,8 +222,8 @@ def test_committed_traffic_feeds_the_roofline():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    names = {"c2": "fit_warp_tile_ahead_kernel<10, false>",
-             "c4shard": "fit_warp_tile_ahead_kernel<10, false>",
+    names = {"c2": "fit_warp_tile_ahead_kernel<10, false, true>",       # user rows by plain stores (lfm_opts.user_store)
+             "c4shard": "fit_warp_tile_ahead_kernel<10, false, false>",
              "c3": "fit_feat_kernel<2, 2, false, false>",
              "c5shard": "fit_feat_kernel<3, 2, false, false>"}
     for cfg, kernel in names.items():

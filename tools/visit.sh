@@ -804,6 +804,14 @@ PY
   PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r05_c3 --config c3
   PROF_STEPS=3 PROF_WARMUP=1 bash tools/profile2.sh r05_c5shard --config c5shard --scale 0.25
   ;;
+r5z)
+  # the driver's sequence on the final tree: GPU suite, smoke, default bench; then the C4 shard's trace + counters on the shipped defaults
+  timeout 1200 $PYT tests -m gpu -x -q > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt
+  timeout 300 python3 __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+  timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $? bytes $(wc -c < $OUT/bench.json)"
+  grep -a "failed" $OUT/bench.err
+  bash tools/profile2.sh r05_c4shard --config c4shard
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
