@@ -658,7 +658,7 @@ def ranks_leg(env, pieces):
     test_csr, train_csr = test.tocsr().astype(np.float32), train.tocsr().astype(np.float32)
     users = int(np.count_nonzero(np.diff(test_csr.indptr)))
     walls, kms = [], []
-    for _ in range(4):
+    for _ in range(9):
         t1 = time.perf_counter()
         ranks = m.predict_rank(test_csr, train_interactions=train_csr, check_intersections=False)
         walls.append(time.perf_counter() - t1)
@@ -667,6 +667,7 @@ def ranks_leg(env, pieces):
     k_ms, wall = float(np.median(kms[1:])), float(np.median(walls[1:]))
     leg = {"name": "predict_ranks", "metric": "user-item scores ranked/s (predict_ranks, ML-20M shape, no_components=64)",
            "value": pairs / (k_ms * 1e-3), "unit": "scores/s", "kernel_ms": k_ms, "call_ms": wall * 1e3,
+           "call_ms_min_max": [min(walls[1:]) * 1e3, max(walls[1:]) * 1e3],
            "users": users, "items": n_items, "test_interactions": int(test_csr.nnz),
            "roofline": {"bound": "mfma", "achieved": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
