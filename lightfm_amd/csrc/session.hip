@@ -2212,7 +2212,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         // and drain unevenly) -- C2 at 20 launches of 1 Mi per epoch ran 1.04 G interactions/s, at 10 launches
         // 1.14 G/s, at 5 launches 1.17 G/s (round 3; precision@10 of 3 seeds unchanged at 10).  What a boundary
         // still gives: fresh bias snapshots for the tile kernel's scoring and the regularisation folds.
-        if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1 << 21) - 1) >> 21));
+        // (LIGHTFM_AMD_LAUNCH_LOG2: experiments with the launch length, default 21 = 2 Mi positions)
+        static const int launch_log2 = [] { const char *e = getenv("LIGHTFM_AMD_LAUNCH_LOG2"); const int v = e ? atoi(e) : 21; return v >= 16 && v <= 28 ? v : 21; }();
+        if (L <= 0) L = (int)std::max<int64_t>(1, std::min<int64_t>(64, (s->n + (1ll << launch_log2) - 1) >> launch_log2));
         const int64_t slice = std::max<int64_t>(1, (s->n + L - 1) / L);
         const size_t generic_smem = smem;
         const bool snap_biases = use_tile && s->tab[0][3].flags != 0 && !(opts->debug & 32);

@@ -694,6 +694,8 @@ class LightFM(object):
             stages.mark("download")
         finally:
             session.close()
+            if options.trim_after_fit:
+                N.device_trim()
 
     # ---------------------------------------------------------------- predict
 

@@ -37,6 +37,9 @@ shuffle_ahead      with device_shuffle: the permutation of epoch e + 1 is writte
                    Off by default: measured without effect on C2 (1.250 / 1.249 against 1.261 / 1.238 G interactions/s,
                    profiles/r05_visit_f.txt -- the 0.36 ms the shuffle takes alone it takes from the epoch kernels when
                    it runs beside them).
+trim_after_fit     True: LightFM.fit_partial hands the device memory its session used back to the HIP runtime when it returns
+                   (lfm_device_trim; for processes that share the GPU with other code).  Off by default: the pool that keeps
+                   released blocks is what fixed the stale-memory fault of round 2, and the next fit reuses them.
 host_positives     True: the positives lookup is built on the host (interactions.tocsr(), LFM:365-372)
                    and uploaded; False (default): built on the device from the uploaded COO.
 
@@ -64,6 +67,7 @@ class _Options(object):
         self.device_shuffle = os.environ.get("LIGHTFM_AMD_DEVICE_SHUFFLE", "1") != "0"
         self.host_positives = os.environ.get("LIGHTFM_AMD_HOST_POSITIVES", "0") != "0"
         self.shuffle_ahead = os.environ.get("LIGHTFM_AMD_SHUFFLE_AHEAD", "0") != "0"
+        self.trim_after_fit = os.environ.get("LIGHTFM_AMD_TRIM_AFTER_FIT", "0") != "0"
         self.cache_scoring_session = os.environ.get("LIGHTFM_AMD_CACHE_SCORING", "1") != "0"
         self.log_samples = False
         self.last_counters = None

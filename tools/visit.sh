@@ -812,6 +812,26 @@ r5z)
   grep -a "failed" $OUT/bench.err
   bash tools/profile2.sh r05_c4shard --config c4shard
   ;;
+r5l)
+  # launch length of the tile kernel (2 Mi shipped; 4 Mi / 1 Mi) on c2, residency of the BPR row-stream kernel on c3 (8 shipped; 6 / 10 / 12)
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-26s %8.1f M/s  frac %.3f  launch %.3f ms  in flight %d | steady %8.1f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 2 --steady-seconds 2 --steps 20 --warmup 5 --config c2"
+  for rep in 1 2; do for lg in 21 22 20; do
+    LIGHTFM_AMD_LAUNCH_LOG2=$lg timeout 200 python3 bench.py $S > $OUT/c2_log2_${lg}_$rep.json 2> $OUT/c2_log2_${lg}_$rep.err; line "c2 launch 2^$lg run $rep" $OUT/c2_log2_${lg}_$rep.json
+  done; done
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 4 --warmup 2 --config c3"
+  for rep in 1 2; do for wv in 8 6 10 12; do
+    LIGHTFM_AMD_FEAT_WAVES_PER_CU=$wv timeout 200 python3 bench.py $S3 > $OUT/c3_waves_${wv}_$rep.json 2> $OUT/c3_waves_${wv}_$rep.err; line "c3 waves/CU $wv run $rep" $OUT/c3_waves_${wv}_$rep.json
+  done; done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
