@@ -738,6 +738,7 @@ def main():
     # for) is loaded BEFORE torch brings its own copy of the runtime into the process
     n_devices = N.device_count()
     if world > 1:
+        N.preload_comm()  # the RCCL of OUR HIP runtime, before torch's bundled one is in the process
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)

@@ -305,6 +305,10 @@ int lfm_session_destroy(lfm_session *s);
  * (lightfm_amd/distributed.py: merge_schedule).
  * ------------------------------------------------------------------------ */
 #define LFM_UNIQUE_ID_BYTES 128
+/* Loads RCCL now -- the librccl next to the HIP runtime this library is linked to, by absolute path (a process that has
+ * imported torch holds torch's own bundled RCCL and HIP runtime, which know nothing of this library's device contexts).
+ * The Python layer calls it before importing torch in a multi-process job. */
+int lfm_comm_preload(void);
 int lfm_comm_unique_id(char id[LFM_UNIQUE_ID_BYTES]);
 int lfm_session_comm_init(lfm_session *s, const char id[LFM_UNIQUE_ID_BYTES], int32_t rank,
                           int32_t nranks);

@@ -452,10 +452,34 @@ static Rccl *rccl()
     static bool tried = false;
     if (!tried) {
         tried = true;
-        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // The RCCL that belongs to the HIP runtime THIS library runs on: next to the libamdhip64 that provides our hip* symbols, by
+        // absolute path.  A process that has imported torch (bench.py and DistributedFit use torch.distributed's gloo backend for
+        // the rendezvous) already holds torch's own bundled librccl.so -- linked to torch's own copy of the HIP runtime, in which no
+        // device of ours is initialised: dlopen("librccl.so") returned THAT one and ncclCommInitRank failed with "no ROCm-capable
+        // device is detected" (round 5, tools/rccl_with_torch_probe.py; rounds 2-4 had only ever initialised RCCL in processes
+        // without torch).  LIGHTFM_AMD_RCCL=<path> overrides.
+        std::vector<std::string> names;
+        if (const char *e = getenv("LIGHTFM_AMD_RCCL")) names.push_back(e);
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so");
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        for (const std::string &n : names) {
+            r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) {
+                if (trace_enabled()) fprintf(stderr, "LFM_RCCL %s\n", n.c_str());
+                break;
+            }
         }
         if (r.lib) {
             r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
@@ -1591,6 +1615,13 @@ extern "C" int lfm_sessions_merge_local_flush(lfm_session **sessions, int32_t k)
         HIP_TRY(hipStreamSynchronize(sessions[i]->stream));
     }
     return LFM_OK;
+}
+
+// Resolves librccl now (see rccl()): called by the Python layer of a multi-process job BEFORE it imports torch, so that nothing
+// torch brings along can take RCCL's place.  0 when RCCL is available.
+extern "C" int lfm_comm_preload(void)
+{
+    return rccl() ? LFM_OK : fail(LFM_ECOMM, "librccl.so not available");
 }
 
 extern "C" int lfm_comm_unique_id(char id[LFM_UNIQUE_ID_BYTES])

@@ -108,6 +108,7 @@ def _worker(rank, world, port, out, argv):
 
     L._Session = FakeSession
     N.device_count = lambda: 8
+    N.preload_comm = lambda: True
     N.device_info = lambda i: ("fake-gfx950", 256, 288 << 30)
     N.lib = lambda: _FakeLib()
     N.check = lambda rc: rc

@@ -163,3 +163,20 @@ def test_deterministic_device_inputs_after_rccl_in_process():
     missing = np.setdiff1d(np.arange(ni), row)
     for col in (int(missing[0]), int(missing[len(missing) // 2]), int(missing[-1])):
         assert not fast.__dict__["__test_in_positives"](u, col, pos)
+
+
+@pytest.mark.parametrize("mode", ["late", "early"])
+def test_rccl_initialises_in_a_process_that_imported_torch(mode):
+    """bench.py and DistributedFit use torch.distributed (gloo) for the rendezvous, and torch brings its own bundled librccl.so and
+    HIP runtime into the process.  dlopen("librccl.so") then returned torch's copy, whose runtime knows nothing of this library's
+    devices: ncclCommInitRank failed with "no ROCm-capable device is detected" -- in every multi-rank job, had one ever run.  The
+    loader now takes the librccl next to OUR libamdhip64 by absolute path ("late": torch imported first, RCCL resolved at
+    comm_init; "early": lfm_comm_preload-style resolution before torch, what bench.py does)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MODE=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 200) + (1 if mode == "late" else 0)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_with_torch_probe.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert "MODE=%s: RCCL communicator initialised" % mode in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
