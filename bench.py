@@ -286,6 +286,9 @@ def parse_args():
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="debug, N = 1: run rank 0's row shard of a K-way strong-scaling split on this one GPU")
     ap.add_argument("--epochs-per-step", type=int, default=1, help="epochs of the fresh fit per step")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="debug: every rank uses this one GPU (owner-sharded item tables work across processes of one GPU; "
+                         "RCCL refuses two ranks on one device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-fit", action="store_true")
@@ -308,7 +311,7 @@ class Env(object):
     def __init__(self, args):
         self.args = args
         self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.all_ranks_on_device is None else int(args.all_ranks_on_device)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus and self.world > 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
@@ -320,13 +323,14 @@ class Env(object):
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def kernel_label(loss, d, stats_last, reg, options):
+def kernel_label(loss, d, stats_last, reg, options, sharded=False):
     """Name of the epoch kernel a run's launches used (as rocprofv3 prints it)."""
     from lightfm_amd import _native as N
     ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
     dp = (d + 3) // 4 * 4
     if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):  # <candidates, owner-sharded item tables, user rows by plain stores>
-        return "fit_warp_tile_ahead_kernel<10, false, %s>" % ("true" if int(getattr(stats_last, "user_store", 0)) else "false")
+        return "fit_warp_tile_ahead_kernel<10, %s, %s>" % ("true" if sharded else "false",
+                                                           "true" if int(getattr(stats_last, "user_store", 0)) else "false")
     if used == 1:
         return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
@@ -488,7 +492,7 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
     launches = sum(int(st.launches) for st in stats)
     reg = bool(args.item_alpha or args.user_alpha)
-    kernel_name = kernel_label(loss, d, stats[-1], reg, options)
+    kernel_name = kernel_label(loss, d, stats[-1], reg, options, sharded=owner)
     achieved = alg / kernel_s / 1e9
     traffic, traffic_source, traffic_extra = committed_traffic(name if d_override is None else name + "_d%d" % d, kernel_name,
                                                                counters[0] / max(1, launches))
