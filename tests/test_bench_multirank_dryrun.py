@@ -304,3 +304,94 @@ def test_distributed_fit_hybrid_model_two_ranks(tmp_path):
         assert g["log"]["shapes"] == [300, 320, n_local_users, 12, 320, 12]
         assert g["log"]["positions"] == 2 * g["n_local"]
     assert got[0]["log"]["kinds"] == got[1]["log"]["kinds"]                   # the same schedule on both ranks
+
+
+def _owner_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import lightfm_amd.lightfm as L
+        from lightfm_amd import LightFM, synthetic
+        from lightfm_amd.distributed import DistributedFit
+        log = {"calls": [], "epochs": 0}
+
+        class FakeSession(object):
+            handle = True
+
+            def __init__(self, struct, item_f, user_f, device=0):
+                self.struct = struct
+
+            def set_interactions(self, positives, rows, cols, data, weight):
+                self.n = len(rows)
+
+            def build_positives(self, n_users, n_items):
+                pass
+
+            def export_items(self):
+                log["calls"].append("export")
+                return bytes([rank]) * 336
+
+            def share_items_ipc(self, exports, my_rank):
+                assert my_rank == rank and len(exports) == world
+                assert [e[0] for e in exports] == list(range(world)), "every rank's export, in rank order"
+                log["calls"].append("share")
+
+            def device_shuffle(self, k0, k1, slot=0):
+                pass
+
+            def epoch(self, loss, ia, ua, k, n, seeds, opts, slot=0):
+                assert int(opts.pos_begin) == 0 and int(opts.pos_end) == self.n, "owner-sharded: no segments, no merges"
+                log["epochs"] += 1
+                self.struct.item_features[rank::world] += 1.0   # "training" of the rows this rank owns
+
+            def check_finite(self):
+                return True
+
+            def gather_shared_items(self):
+                log["calls"].append("gather")
+
+            def sync_to_host(self, struct):
+                log["calls"].append("sync")
+
+            def comm_merge_sparse(self, *a, **k):
+                raise AssertionError("owner-sharded item tables are never merged")
+
+            comm_init = comm_merge = comm_merge_hot = comm_merge_sparse
+
+            def close(self):
+                log["calls"].append("close")
+                self.handle = None
+
+        L._Session = FakeSession
+        data = synthetic.make_interactions(300, 200, 12000, seed=3)
+        model = LightFM(no_components=16, loss="warp", random_state=5)
+        fit = DistributedFit(model, data, rank, world, device=0, dist=dist, item_tables="owner")
+        assert fit.owner_sharded
+        fit.run(epochs=2)
+        fit.close()
+        # refused outside the kernel's scope (every rank raises before any collective)
+        for bad in (dict(loss="bpr"), dict(loss="warp", no_components=96), dict(loss="warp", item_alpha=1e-6)):
+            kw = dict(no_components=16, loss="warp", random_state=5)
+            kw.update(bad)
+            with pytest.raises(NotImplementedError):
+                DistributedFit(LightFM(**kw), data, rank, world, device=0, dist=dist, item_tables="owner")
+        json.dump({"log": log, "merges": fit.merges}, open(out % rank, "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_distributed_fit_owner_sharded_control_flow_two_ranks(tmp_path):
+    """DistributedFit(item_tables="owner") with a stand-in session over gloo: the exports of all ranks reach every rank in rank
+    order, an epoch is ONE call over all local positions (no segments, no merges, no communicator), the finite flag and the final
+    gather are collective (a rank that skipped one would hang this test), sessions close behind a barrier."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    out = str(tmp_path / "owner%d.json")
+    mp.spawn(_owner_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [json.load(open(out % r)) for r in range(world)]
+    for g in got:
+        assert g["merges"] == 0 and g["log"]["epochs"] == 2
+        assert g["log"]["calls"] == ["export", "share", "gather", "sync", "close"], g["log"]["calls"]
