@@ -685,7 +685,8 @@ class LightFM(object):
                                                "kernel_used": int(opts.kernel_used),
                                                "tile_ng": int(opts.tile_ng),
                                                "in_flight": int(opts.in_flight),
-                                               "launches": int(opts.launches)})
+                                               "launches": int(opts.launches),
+                                               "user_store": int(opts.user_store)})
                 if not session.check_finite():  # LFM:664
                     session.sync_to_host(model)
                     raise ValueError(_NOT_FINITE)
