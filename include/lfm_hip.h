@@ -141,6 +141,12 @@ typedef struct lfm_opts {
     int32_t tile_ahead;         /* out: 1 when the epoch's last launch ran the steady-state variant of the tile kernel
                                    with the next pass's gather issued inside the current pass (csrc/warp_tile_ahead.hpp;
                                    `debug` bit 10 = 1024 keeps the plain tile kernel)                            */
+    int32_t plan_flags;         /* out: what the epoch's launch plan looked like (tests assert the branch they mean to cover):
+                                   bit 0 / 1 = the item / user side's biases were scored from per-launch cached snapshots (else
+                                   the live table: sides above 2 MiB of biases); bit 2 / 3 = the item / user embedding tables
+                                   live in uncached memory; bit 4 = the item embedding table is >= 4 GB (64-bit row offsets
+                                   in the tile kernel's gathers); bit 5 = the shared tag rows were accumulated in LDS slices
+                                   (csrc/tag_slices.hip) instead of by float atomics of every interaction             */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -106,6 +106,7 @@ def _record(o, logs):
     options.last_tile_ng = int(o.tile_ng)
     options.last_tile_ahead = int(o.tile_ahead)
     options.last_user_store = int(o.user_store)
+    options.last_plan_flags = int(o.plan_flags)
     options.last_phase_cycles = list(o.phase_cycles)
     options.last_logs = logs
 

@@ -52,7 +52,8 @@ class LfmOpts(C.Structure):
                 ("history", C.c_int64), ("ramp_k", C.c_int32), ("launches", C.c_int32),
                 ("kernel_used", C.c_int32), ("shared_cap", C.c_int32),
                 ("pos_begin", C.c_int64), ("pos_end", C.c_int64),
-                ("streams_used", C.c_int32), ("user_store", C.c_int32), ("tile_ahead", C.c_int32)]
+                ("streams_used", C.c_int32), ("user_store", C.c_int32), ("tile_ahead", C.c_int32),
+                ("plan_flags", C.c_int32)]
 
 
 class LfmItemExport(C.Structure):

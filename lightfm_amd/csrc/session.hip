@@ -546,6 +546,7 @@ struct lfm_session {
     bool bloom_valid = false;
     bool recs_valid = false;
     int64_t n = 0;
+    double user_pair_share = -1.0;  // sum_u c_u^2 / n^2 of the uploaded COO (c_u = interactions of user u); < 0: not computed yet
     std::vector<DBuf<int32_t> *> shuffles;
     // lfm_session_device_shuffle_ahead: the permutation of the NEXT epoch is written on a stream of its own while the current
     // epoch's kernels run; the epoch that uses the slot waits for the event
@@ -885,6 +886,7 @@ extern "C" int lfm_session_set_interactions(lfm_session *s, const lfm_csr *posit
     HIP_TRY(hipSetDevice(s->device));
     s->n = n;
     s->recs_valid = false;
+    s->user_pair_share = -1.0;
     s->guard_sums.clear();  // new contents: nothing to compare against
     // an argument that is NULL leaves nothing of an earlier upload behind
     if (positives) {
@@ -1989,6 +1991,56 @@ static int validate_inputs(lfm_session *s, int slot, int when, bool recs_in_use)
     return LFM_OK;
 }
 
+// sum_u c_u^2 / n^2 over the uploaded COO, c_u = interactions of user u: the probability that two interactions drawn at
+// random belong to the same user.  Times the interactions in flight it is the share of interactions that have ANOTHER
+// interaction of their user in flight with them -- what the plain-store user rows (FitArgs::user_store) can lose an update
+// to.  One histogram pass with integer atomics (ML-20M: 20 M adds on 138 k counters), once per uploaded COO.
+__global__ void user_count_kernel(const int32_t *user_ids, int64_t n, int32_t *counts, int32_t n_users)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = user_ids[i];
+        if (u >= 0 && u < n_users) atomicAdd(counts + u, 1);
+    }
+}
+
+__global__ void count_sumsq_kernel(const int32_t *counts, int64_t m, unsigned long long *out)
+{
+    unsigned long long acc = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = (unsigned long long)counts[i];
+        acc += c * c;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+static int user_pair_share(lfm_session *s, double *out)
+{
+    if (s->user_pair_share < 0.0) {
+        if (s->n <= 0 || s->n_feat[1] <= 0) {
+            s->user_pair_share = 1.0;
+        } else {
+            DBuf<int32_t> counts;
+            DBuf<unsigned long long> acc;
+            LFM_TRY(counts.alloc((size_t)s->n_feat[1]));
+            LFM_TRY(acc.alloc(1));
+            HIP_TRY(hipMemsetAsync(counts.p, 0, (size_t)s->n_feat[1] * sizeof(int32_t), s->stream));
+            HIP_TRY(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), s->stream));
+            const int g1 = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (s->n + 255) / 256));
+            user_count_kernel<<<g1, 256, 0, s->stream>>>(s->user_ids.p, s->n, counts.p, s->n_feat[1]);
+            const int g2 = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)s->n_feat[1] + 255) / 256));
+            count_sumsq_kernel<<<g2, 256, 0, s->stream>>>(counts.p, (int64_t)s->n_feat[1], acc.p);
+            HIP_TRY(hipGetLastError());
+            unsigned long long sq = 0ull;
+            HIP_TRY(hipMemcpyAsync(&sq, acc.p, sizeof(sq), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            s->user_pair_share = (double)sq / ((double)s->n * (double)s->n);
+        }
+    }
+    *out = s->user_pair_share;
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------------ epoch ---
 
 static void tile_geometry(int d, int want_rows, int *rows, int *stride)
@@ -2060,20 +2112,29 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     int base_user_store = 0;
     {
         // The user row of an update by plain stores instead of float atomics (FitArgs::user_store; warp_tile_ahead.hpp): identity
-        // user features (a user's row is touched by that user's interactions alone), uncached tables (a store is then visible to
-        // every XCD), atomic publication, adagrad.  What a plain read-modify-write loses is one of two updates of the SAME user
-        // that are in flight together, so the switch needs many more users than interactions in flight: measured precision@10
-        // cost -0.0032 at 1.4 users per interaction in flight (the 1/8-scale gate of tests/test_precision_parity.py, which
-        // failed) and -0.0004 at 11 (C2, 8 seeds) -- proportional to in-flight / users.  Rule: >= 8 users per interaction of a
-        // full-residency launch (48 per CU), and a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of tables)
-        // the same switch LOST 5-10 % (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit 11
-        // (2048) forces it for uncached tables of any size and user count, bit 12 (4096) switches it off.
+        // user features (a user's row is touched by that user's interactions alone), uncached tables -- W AND G of the user side
+        // (a store is then visible to every XCD) --, atomic publication, adagrad.  What a plain read-modify-write loses is one
+        // of two updates of the SAME user that are in flight together, so the rule is about the data's own collision rate:
+        // share = (interactions in flight at full residency, 48 per CU) x sum_u c_u^2 / n^2 = the fraction of interactions that
+        // have another interaction of their user in flight with them (user_pair_share above; uniform activity gives in-flight /
+        // users, a heavy tail more).  Measured precision@10 cost: -0.0004 at share 0.21 (C2: log-normal activity, 8 seeds),
+        // -0.0032 at share 1.57 (the 1/8-scale gate of tests/test_precision_parity.py, which failed) -- ~0.002 per unit, so the
+        // switch is taken up to share 0.3 (round 5's rule counted users only and assumed uniform activity: ADVICE r5).  And
+        // only for a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of tables) the same switch LOST 5-10 %
+        // (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit 11 (2048) forces it for uncached
+        // tables of any size and collision rate, bit 12 (4096) switches it off.
         size_t bytes = 0;
         for (int side = 0; side < 2; ++side)
             for (int kk = 0; kk < 6; ++kk) bytes += s->tab[side][kk].n * sizeof(float);
-        const bool eligible = !serial && a.update_mode == 0 && s->usf.identity && s->tab[1][0].flags != 0 && !s->adadelta && s->shards.n == 0;
-        const bool many_users = (int64_t)s->n_feat[1] >= 8LL * 48 * (int64_t)std::max(1, s->cus);
-        base_user_store = a.user_store = (eligible && !(opts->debug & 4096) && ((many_users && bytes <= ((size_t)192 << 20)) || (opts->debug & 2048))) ? 1 : 0;
+        const bool eligible = !serial && a.update_mode == 0 && s->usf.identity && s->tab[1][0].flags != 0 && s->tab[1][1].flags != 0 &&
+                              !s->adadelta && s->shards.n == 0;
+        bool rare_collisions = false;
+        if (eligible && !(opts->debug & (4096 | 2048)) && bytes <= ((size_t)192 << 20)) {
+            double share = 1.0;
+            LFM_TRY(user_pair_share(s, &share));
+            rare_collisions = share * 48.0 * (double)std::max(1, s->cus) <= 0.3;
+        }
+        base_user_store = a.user_store = (eligible && !(opts->debug & 4096) && (rare_collisions || (opts->debug & 2048))) ? 1 : 0;
     }
 
     // WARP loss term per sampled count, evaluated with the HOST libm so the device
@@ -2127,10 +2188,15 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         const double avg = (double)f->nnz / (double)f->rows;
         shared_cap = std::min<int64_t>(shared_cap, std::max<int64_t>(64, (int64_t)((double)f->cols / std::max(1.0, avg))));
     }
+    // ... and no more interactions in flight than the smaller side has rows: every interaction in flight updates one user
+    // row and two item rows, so beyond that every row has several concurrent writers whatever the history (ML-100k, 943 x
+    // 1 682, is a BASELINE shape; round 5 measured -0.0020 / -0.0021 precision@10 at 300 x 120 / 1 000 x 400 without
+    // this bound: profiles/r05_visit_f.txt).  No BASELINE bench shape is bound by it (C2: 26 744 rows > 12 288 in flight).
+    const int64_t rows_cap = std::max<int64_t>(8, std::min<int64_t>(s->n_feat[0], s->n_feat[1]));
     auto allowed_in_flight = [&](int64_t done_this_epoch) -> int64_t {
         if (fixed_cap) return opts->max_waves;
         if (opts->ramp_k < 0) return INT64_MAX / 4;  // ramp disabled
-        return std::min<int64_t>(shared_cap, std::max<int64_t>(8, (history0 + done_this_epoch) / ramp_k));
+        return std::min<int64_t>(std::min(shared_cap, rows_cap), std::max<int64_t>(8, (history0 + done_this_epoch) / ramp_k));
     };
 
     // Parallel WARP over identity features, with or without L2 regularisation (BASELINE configs C2/C4):
@@ -2224,7 +2290,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // multiplied by (1 + alpha lr) in place (PYX:433, 446), and only a boundary divides them again
     const int64_t reg_len_cap = !reg ? INT64_MAX : (int64_t)std::max(256.0, std::max(
         std::min(1e12, 0.5 / std::max(reg_step, 1e-300)), std::min(65536.0, 55.0 / std::max(reg_step, 1e-300))));
-    int in_flight = 1, tile_ng_used = 0, n_launches = 0;
+    int in_flight = 1, tile_ng_used = 0, n_launches = 0, plan_flags = 0;
     bool used_second_stream = false;
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (serial) {
@@ -2380,6 +2446,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                             copy_kernel<<<cgrid, 256, 0, lst>>>(s->bias_snap[side][par].p, s->tab[side][3].p, cnt);
                         }
                         a.b_read[side] = s->bias_snap[side][par].p;
+                        plan_flags |= 1 << side;
                     }
                 }
                 if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
@@ -2425,6 +2492,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     opts->streams_used = used_second_stream ? 2 : 1;
     opts->tile_ahead = (tile_ng_used == 4 && tile[4].ahead) ? 1 : 0;
     opts->user_store = (base_user_store && (tile_ng_used || use_feat)) ? 1 : 0;
+    for (int side = 0; side < 2; ++side)
+        if (s->tab[side][0].flags != 0) plan_flags |= 4 << side;
+    if ((uint64_t)s->itf.rows * (uint64_t)s->d >= (1ull << 30)) plan_flags |= 16;
+    opts->plan_flags = plan_flags;
     if (opts->neg_log) LFM_TRY(s->neg_log.download(opts->neg_log));
     if (opts->sampled_log) LFM_TRY(s->sampled_log.download(opts->sampled_log));
     if (validate_enabled()) LFM_TRY(validate_inputs(s, slot, 1, recs_in_use));

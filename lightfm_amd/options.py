@@ -78,6 +78,7 @@ class _Options(object):
         self.last_tile_ng = None     # interactions per wavefront pass of the tile kernel (4, 2, 1), 0 = another kernel ran
         self.last_tile_ahead = None  # 1 = the steady-state (gather-ahead) tile kernel ran the last launch
         self.last_user_store = None  # 1 = user rows were written with plain stores (lfm_opts.user_store)
+        self.last_plan_flags = None  # lfm_opts.plan_flags of the last epoch (bias snapshots, uncached tables, 64-bit item rows)
         self.last_phase_cycles = None
         self.last_logs = None
 

@@ -16,6 +16,6 @@ int main(void)
     F(lfm_opts, update_mode); F(lfm_opts, feat_kernel); F(lfm_opts, warp_kernel); F(lfm_opts, debug);
     F(lfm_opts, phase_cycles); F(lfm_opts, tile_ng); F(lfm_opts, in_flight); F(lfm_opts, history);
     F(lfm_opts, ramp_k); F(lfm_opts, launches); F(lfm_opts, kernel_used); F(lfm_opts, shared_cap); F(lfm_opts, pos_begin); F(lfm_opts, pos_end);
-    F(lfm_opts, streams_used); F(lfm_opts, tile_ahead);
+    F(lfm_opts, streams_used); F(lfm_opts, tile_ahead); F(lfm_opts, plan_flags);
     return 0;
 }

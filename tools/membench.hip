@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CHECK(x)                                                                      \
@@ -131,6 +132,48 @@ __global__ __launch_bounds__(256) void atomic_flavour_kernel(float *tab, uint32_
     if (acc == 123.456f) out[0] = acc;
 }
 
+// LDS read-modify-write rate (round 6: the ceiling of accumulating C3's 1 128 shared tag rows in LDS slices instead
+// of publishing every cell of every interaction through the L2 float-atomic unit, csrc/tag_slices.hip).  A workgroup
+// owns a table of ROWS x 8 cells x {W, G} in LDS (1 128 rows: 72 KB); a wavefront pass touches 8 random rows x 8
+// cells (lane = row slot * 8 + cell), reads W and G, optionally evaluates the reference's float64 adagrad cell
+// (PYX:416-449) and writes back -- mode 0: ds_add_f32 of new - old (several wavefronts may hit a cell: nothing is
+// lost), mode 1: plain ds_write (a single writer), mode 2: ds_add_f32 without the arithmetic (the LDS rate alone).
+template <int MODE>
+__global__ __launch_bounds__(256) void lds_rmw_kernel(int rows, int iters, float *out)
+{
+    extern __shared__ float lds[];
+    float *W = lds, *G = lds + (size_t)rows * 8;
+    for (int i = threadIdx.x; i < rows * 8; i += blockDim.x) {
+        W[i] = 0.01f * (float)(i & 15);
+        G[i] = 1.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t s = mix(blockIdx.x * 8u + wave + 1u);
+    float keep = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+        s = lcg(s);
+        const uint32_t r = mix(s + (lane >> 3)) % (uint32_t)rows;  // 8 random rows per pass
+        const int cell = (int)r * 8 + (lane & 7);
+        const float oW = W[cell], oG = G[cell];
+        float nW = oW + 1e-3f, nG = oG + 1e-6f;
+        if (MODE != 2) {
+            const double g = 1e-3 * (double)(lane + 1), lr = 0.05 / sqrt((double)oG);
+            nW = (float)((double)oW - lr * g);
+            nG = (float)((double)oG + g * g);
+        }
+        if (MODE == 1) {
+            W[cell] = nW;
+            G[cell] = nG;
+        } else {
+            atomicAdd(W + cell, nW - oW);
+            atomicAdd(G + cell, nG - oG);
+        }
+        keep += oW;
+    }
+    if (keep == 123.456f) out[0] = keep;
+}
+
 static float *alloc(size_t bytes, bool uncached)
 {
     void *p = nullptr;
@@ -161,13 +204,38 @@ static double time_ms(F launch, int reps = 3)
     return best;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("# %s, %d CUs\n", prop.gcnArchName, cus);
     float *out = alloc(256, false);
+    {   // LDS read-modify-write of 8-cell row slices (`membench lds` runs only this section)
+        const int rows = 1128, iters = 20000;
+        const size_t smem = (size_t)rows * 8 * 2 * sizeof(float);
+        CHECK(hipFuncSetAttribute((const void *)lds_rmw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        CHECK(hipFuncSetAttribute((const void *)lds_rmw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        CHECK(hipFuncSetAttribute((const void *)lds_rmw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const char *names[3] = {"f64 adagrad cell + ds_add_f32 x2", "f64 adagrad cell + ds_write x2", "ds_read x2 + ds_add_f32 x2 only"};
+        for (int wgs_per_cu : {1, 2}) {
+            for (int threads : {256, 512, 1024}) {
+                if (threads > 256) continue;  // (__launch_bounds__(256): the shape the slice kernel uses)
+                for (int mode = 0; mode < 3; ++mode) {
+                    const int grid = cus * wgs_per_cu;
+                    double ms = 0;
+                    if (mode == 0) ms = time_ms([&] { lds_rmw_kernel<0><<<grid, threads, smem>>>(rows, iters, out); });
+                    if (mode == 1) ms = time_ms([&] { lds_rmw_kernel<1><<<grid, threads, smem>>>(rows, iters, out); });
+                    if (mode == 2) ms = time_ms([&] { lds_rmw_kernel<2><<<grid, threads, smem>>>(rows, iters, out); });
+                    const double cells = (double)grid * (threads / 64) * iters * 64;
+                    printf("lds    %d rows x 8 cells x {W, G} (%zu KB) %d workgroup(s)/CU x %d threads  %-34s: %8.1f G cells/s "
+                           "(%.1f G dword read-modify-writes/s; the L2 float-atomic unit: 320 G dwords/s)\n", rows, smem >> 10,
+                           wgs_per_cu, threads, names[mode], cells / ms / 1e6, 2 * cells / ms / 1e6);
+                }
+            }
+        }
+        if (argc > 1 && !strcmp(argv[1], "lds")) return 0;
+    }
     struct Tab { const char *name; uint32_t rows; };
     // 256-B rows: ML-20M items (6.8 MB), ML-20M users (35 MB), C4 items (1.28 GB)
     const Tab tabs256[] = {{"26744 rows x 256 B (6.8 MB)", 26744u}, {"138493 rows x 256 B (35 MB)", 138493u},

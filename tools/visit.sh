@@ -832,6 +832,17 @@ PY
     LIGHTFM_AMD_FEAT_WAVES_PER_CU=$wv timeout 200 python3 bench.py $S3 > $OUT/c3_waves_${wv}_$rep.json 2> $OUT/c3_waves_${wv}_$rep.err; line "c3 waves/CU $wv run $rep" $OUT/c3_waves_${wv}_$rep.json
   done; done
   ;;
+r6a)
+  # round 6, first visit: the new parity tests at the HBM-bound shapes, the small-shape gates, the LDS read-modify-write rate,
+  # and C2 / C3 short bench runs (user rows by plain stores must still be chosen on C2 under the collision-rate rule)
+  free -g | head -2; nproc
+  timeout 200 tools/_bin/membench lds > $OUT/membench_lds.txt 2>&1; echo "membench rc $?"; cat $OUT/membench_lds.txt
+  ( time timeout 1500 $PYT tests/test_hbm_shapes.py -m gpu -x -q -s ) > $OUT/hbm_shapes.txt 2>&1; tail -5 $OUT/hbm_shapes.txt; grep real $OUT/hbm_shapes.txt
+  ( time timeout 1500 $PYT tests/test_precision_parity.py -m gpu -q -s -k "ml100k or tiny" ) > $OUT/small_gates.txt 2>&1; grep -aE "delta|passed|failed|real" $OUT/small_gates.txt
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 2 --steps 20 --warmup 5"
+  timeout 300 python3 bench.py $S --config c2 > $OUT/c2.json 2> $OUT/c2.err; echo "c2 rc $?"; python3 -c "
+import json; d=json.load(open('$OUT/c2.json')); print(d['value']/1e6, d['roofline']['frac'], d['roofline']['kernel'])"
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
