@@ -843,6 +843,18 @@ r6a)
   timeout 300 python3 bench.py $S --config c2 > $OUT/c2.json 2> $OUT/c2.err; echo "c2 rc $?"; python3 -c "
 import json; d=json.load(open('$OUT/c2.json')); print(d['value']/1e6, d['roofline']['frac'], d['roofline']['kernel'])"
   ;;
+r6b)
+  # which cells change in a frozen-weight epoch over an item table beyond 4 GB (tests/test_hbm_shapes.py failure of r6a)
+  for args in "20000000 0" "20000000 1024" "20000000 0 noepoch" "16000000 0"; do
+    timeout 300 python3 tools/debug_big_items.py $args 2>&1 | tail -8
+  done
+  ;;
+r6c)
+  # the N > 1 merge path over the stand-in collective (tests/fake_rccl.hip): K = 2, 4 rank processes on the one GPU + bench.py --gpus 2;
+  # the HBM-shape parity tests again
+  ( time timeout 1700 $PYT tests/test_fake_rccl_multirank.py -m gpu -x -q -s ) > $OUT/fake_rccl.txt 2>&1; grep -aE "FAKE_RCCL case|passed|failed|real|Error|error|assert" $OUT/fake_rccl.txt | cut -c1-300 | head -60
+  ( time timeout 1500 $PYT tests/test_hbm_shapes.py -m gpu -x -q -s ) > $OUT/hbm_shapes.txt 2>&1; tail -5 $OUT/hbm_shapes.txt | cut -c1-300; grep real $OUT/hbm_shapes.txt
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
