@@ -59,6 +59,29 @@ struct ItemShards {
     uint32_t rows_per_shard, magic;  // magic = floor(2^32 / rows_per_shard) + 1 (exact division of ids < 2^31)
 };
 
+// ---- shared ("hot") item-feature rows accumulated in LDS slices (hot_slices.hip; round 6) ------------------------------
+// A hybrid model's tag / genre rows are updated by a large share of ALL interactions (BASELINE config C3: 16 of the 19
+// rows an interaction updates are among 1 128 tag rows), and publishing every cell of every interaction through the L2
+// float-atomic unit is that configuration's ceiling (320 G dwords/s).  With a hot set the row-stream kernels
+// (feat_kernel.hpp, HOT instantiations) leave those rows OUT of their update and write one record per interaction
+// instead; between two launches hot_slice_kernel applies the records to component SLICES of the hot rows held in LDS and
+// publishes each slice's total change once.  One record = what update_features needs for the hot entries of the
+// interaction (PYX:602-638): per job the gradient coefficient g_j (the hot rows sit on the item side, so the other
+// factor is the vector x written next to it: the user representation), and per entry the row's slot and its weight.
+constexpr int HOT_EMAX = 24;  // hot entries one record holds; an interaction with more publishes the rest as before
+struct __attribute__((aligned(32))) HotRec {
+    double g[3];              // gradient coefficient of job 0 / 1 / 2 (PYX:537-649: -loss, +loss, ...)
+    int32_t n_total;          // entries; <= 0: nothing to apply at this position (the launch memsets the records to -1)
+    unsigned char cnt[3];     // entries of job 0 / 1 / 2, in this order in e[]
+    unsigned char pad;
+    struct Entry {
+        int32_t slot;         // slot of the row in the hot set
+        float w;              // the feature weight (PYX:613)
+    } e[HOT_EMAX];
+    int32_t tail[8];
+};
+static_assert(sizeof(HotRec) == 256, "HotRec is one 256-byte record");
+
 struct FitArgs {
     DCsr itf, usf, pos;
     DModel m;
@@ -89,6 +112,9 @@ struct FitArgs {
     ItemShards shards;             // owner-sharded item tables (n = 0: none)
     int32_t user_store;            // parallel mode: the USER row of an update (identity user features: touched by that user's
                                    // interactions alone) is written with plain stores instead of float atomics (session.hip)
+    const int32_t *hot_slot;       // [n_item_feat] slot of a hot item-feature row, -1 otherwise; nullptr = no hot set (HotRec above)
+    HotRec *hot_rec;               // [end - begin] one record per position of the launch
+    float *hot_x;                  // [end - begin][d] the vector the hot rows' gradients multiply (the user representation)
     float *reg_live;               // [RegScale::FLOATS] parallel mode, lazy L2 regularisation (see RegScale): line 0 =
                                    // min(item_scale, MAX), min(user_scale, MAX) at the last launch boundary, lines 1.. =
                                    // the slots collecting the growth of log(scale) since then (float atomics)
