@@ -65,9 +65,14 @@ struct Entries {
 // 60.87 M interactions/s at --scale 0.25; the same kernel at 12 wavefronts loses 1.3 % to the tighter allocation;
 // profiles/r05_visit_i.txt): the kernel is instruction-bound, residency buys little.
 #define LFM_FEAT_MIN_BLOCKS(LOSS, TIMED) (((LOSS) == 3 && !(TIMED)) ? 4 : 2)
-template <int LOSS, int NC, bool TIMED = false, bool REG = false>
+// HOT (round 6): the model has a hot set (device.hpp: HotRec; session.hip: HotSet).  The update leaves the hot item-feature
+// rows out -- no W / G row gathers, no cell arithmetic, no atomics for them -- and writes their (slot, weight) entries, the
+// jobs' gradient coefficients and the user representation to the position's record; hot_slice_kernel (hot_slices.hip)
+// applies the records after the launch.  Scoring, sampling and every other row's update are unchanged.
+template <int LOSS, int NC, bool TIMED = false, bool REG = false, bool HOT = false>
 __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_feat_kernel(FitArgs a)
 {
+    static_assert(!(HOT && (REG || TIMED)), "the hot-set variants carry neither the lazy regularisation nor phase timers");
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMED) {
@@ -398,8 +403,41 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
     // must see its earlier update: such entries get a "generation" (how many earlier entries name
     // the same row) and the generations are processed one after the other with a device-scope
     // fence in between -- rare, and exactly the sequential result.
-    auto update_round = [&](const Entries &e, double g0, double g1, double g2, const float (&xI)[NC],
+    HotRec *hrec = nullptr;                  // HOT: this position's record
+    int hot_n0 = 0, hot_n1 = 0, hot_n2 = 0;  // HOT: entries recorded so far for job 0 / 1 / 2 of the current interaction
+    auto update_round = [&](const Entries &e_in, double g0, double g1, double g2, const float (&xI)[NC],
                             const float (&xU)[NC], double &lr_sum) {
+        Entries e = e_in;
+        if constexpr (HOT) {
+            // entries that name a hot item-side row go to the record (in list order: job by job, as the reference walks
+            // them); the others are compacted to the front of the list and updated below as ever
+            int hs = -1;
+            if (lane < e.n && e.eside == 0) hs = a.hot_slot[e.feat];
+            const unsigned long long hm = __ballot(hs >= 0);
+            if (hm != 0ull) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int rank = hot_n0 + hot_n1 + hot_n2 + __popcll(hm & below);
+                const bool rec = hs >= 0 && rank < HOT_EMAX;  // (beyond the record's capacity: published as before)
+                if (rec) {
+                    HotRec::Entry en;
+                    en.slot = hs;
+                    en.w = e.w;
+                    hrec->e[rank] = en;
+                }
+                hot_n0 += __popcll(__ballot(rec && e.job == 0));
+                hot_n1 += __popcll(__ballot(rec && e.job == 1));
+                hot_n2 += __popcll(__ballot(rec && e.job == 2));
+                const unsigned long long km = __ballot(lane < e.n && !rec);
+                const int nk = __popcll(km);
+                const int dst = ((km >> lane) & 1ull) ? __popcll(km & below) : nk + __popcll(~km & below);  // a permutation
+                e.feat = __builtin_amdgcn_ds_permute(dst << 2, e.feat);
+                e.w = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(e.w)));
+                const int js = __builtin_amdgcn_ds_permute(dst << 2, e.job | (e.eside << 8));
+                e.job = js & 0xff;
+                e.eside = js >> 8;
+                e.n = nk;
+            }
+        }
         const int SRh = SR >> 1;
         float *stW = stage, *stG = stage + (size_t)SRh * d;
         const bool on = lane < e.n;
@@ -468,6 +506,31 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             stamp(6);
         }
     };
+    // HOT: the record's header and the vector the hot rows' gradients multiply (item-side rows: x = xI, PYX:602-638),
+    // written once the interaction's lists have been walked
+    auto hot_finish = [&](double g0, double g1, double g2, const float (&xI)[NC]) {
+        if constexpr (HOT) {
+            const int tot = hot_n0 + hot_n1 + hot_n2;
+            if (tot > 0) {
+                if (lane == 0) {
+                    hrec->g[0] = g0;
+                    hrec->g[1] = g1;
+                    hrec->g[2] = g2;
+                    hrec->cnt[0] = (unsigned char)hot_n0;
+                    hrec->cnt[1] = (unsigned char)hot_n1;
+                    hrec->cnt[2] = (unsigned char)hot_n2;
+                    hrec->n_total = tot;
+                }
+                float *xp = a.hot_x + (size_t)(hrec - a.hot_rec) * d;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int c = lane + WAVE * q;
+                    if (c < d) xp[c] = xI[q];
+                }
+            }
+            hot_n0 = hot_n1 = hot_n2 = 0;
+        }
+    };
     // the same for a list of jobs given as rows (fetches the flat list round by round)
     auto update_rows = [&](int row, int side, int J, double g0, double g1, double g2, const float (&xI)[NC],
                            const float (&xU)[NC]) {
@@ -482,12 +545,14 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             update_round(e, g0, g1, g2, xI, xU, lr_sum);
         }
         scale_step(lr_sum, T);
+        hot_finish(g0, g1, g2, xI);
     };
     // a list that fitted one round and was kept from the representation phase
     auto update_kept = [&](const Entries &e, double g0, double g1, double g2, const float (&xI)[NC], const float (&xU)[NC]) {
         double lr_sum = 0.0;
         update_round(e, g0, g1, g2, xI, xU, lr_sum);
         scale_step(lr_sum, e.n);
+        hot_finish(g0, g1, g2, xI);
     };
     auto rep_regs = [&](int r, float (&v)[NC]) {
         const float *rp = reps + (size_t)r * TS;
@@ -529,6 +594,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
         cur = nxt;
         row1 = row2;
         refresh(i);
+        if constexpr (HOT) hrec = a.hot_rec + (i - a.begin);
 
         if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
             // fit_logistic, PYX:726-775
@@ -788,5 +854,27 @@ inline hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block
 
 hipError_t launch_fit_feat_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                                 int *grid_used);
+
+// the HOT instantiations (feat_kernels_hot.hip): adagrad, no regularisation, d <= 128
+template <int NC>
+inline hipError_t launch_feat_hot_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                                     int *grid_used)
+{
+    void (*kernel)(FitArgs) = nullptr;
+    switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, false, true>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, false, true>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, false, true>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, false, true>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (cus > 0) {
+        const int per_cu = occupancy_cached(kernel, block, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, block, smem, st>>>(a);
+    return hipGetLastError();
+}
 
 }  // namespace lfm
