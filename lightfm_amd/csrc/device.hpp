@@ -185,6 +185,12 @@ __device__ __forceinline__ float read_lanef(float v, int l)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), uni(l)));
 }
+__device__ __forceinline__ double unid(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ __forceinline__ double read_laned(double v, int l)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), uni(l));

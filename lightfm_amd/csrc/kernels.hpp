@@ -78,6 +78,23 @@ struct FeatPlan {
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used = nullptr, bool timed = false);
+// feat_kernels_hot.hip: the HOT instantiations of the row-stream kernels (a model with a hot set: FitArgs::hot_slot)
+hipError_t launch_fit_feat_hot(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                               int *grid_used = nullptr);
+// hot_slices.hip: the hot rows' records of one launch applied to component slices held in LDS (device.hpp: HotRec)
+struct HotArgs {
+    const HotRec *rec;   // [n_rec] the launch's records
+    const float *x;      // [n_rec][d]
+    int64_t n_rec;
+    int32_t d, hot_n, n_rep;
+    const int32_t *rows;                    // [hot_n] feature row of a slot
+    float *W, *G, *b, *bG;                  // the live item-side tables
+    float *snapW, *snapG, *snapb, *snapbG;  // [hot_n][d] / [hot_n]: the hot rows as they were when the records' launch ended
+    float lr, rho, eps;
+};
+int hot_slice_components(int hot_n, int d);  // components per LDS slice (8, 4, 2), 0 = the hot set does not fit
+hipError_t launch_hot_slices(const HotArgs &a, int cs, int threads, hipStream_t st);
+hipError_t launch_column_counts(const int32_t *indices, int64_t nnz, int32_t cols, int32_t *counts, hipStream_t st);
 // csr_build.hip: the Bloom filter over the positives lookup (device.hpp: Bloom); bloom has Bloom::words(nnz) words
 hipError_t build_positives_bloom(const int32_t *indptr, const int32_t *indices, int32_t n_rows, int64_t nnz, uint32_t *bloom,
                                  hipStream_t st);

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -546,6 +547,20 @@ struct lfm_session {
     bool bloom_valid = false;
     bool recs_valid = false;
     int64_t n = 0;
+    // The hot set of the item side (hot_slices.hip; device.hpp: HotRec): feature rows shared by so many items that an
+    // interaction touches each with probability >= 1/512 (a hybrid model's tag / genre rows) are accumulated in LDS slices
+    // between launches instead of by float atomics of every interaction.  Derived from the resident feature matrix by the
+    // first epoch that qualifies (build_hot_set).
+    struct HotSet {
+        int state = 0;       // 0 = not looked at yet, 1 = in use, -1 = none (identity features, no shared rows, does not pay)
+        int n = 0, cs = 0;   // hot rows; components per LDS slice
+        DBuf<int32_t> slot;  // [n_item_feat] slot of a hot row, -1 otherwise
+        DBuf<int32_t> rows;  // [n] feature row of a slot, ascending
+        DBuf<float> snapW, snapG, snapb, snapbG;
+        DBuf<HotRec> rec;    // one record per position of a launch
+        DBuf<float> x;       // [positions][d]
+        double share = 0.0;  // hot entries / all entries of the feature matrix
+    } hot;
     double user_pair_share = -1.0;  // sum_u c_u^2 / n^2 of the uploaded COO (c_u = interactions of user u); < 0: not computed yet
     std::vector<DBuf<int32_t> *> shuffles;
     // lfm_session_device_shuffle_ahead: the permutation of the NEXT epoch is written on a stream of its own while the current
@@ -850,6 +865,7 @@ extern "C" int lfm_session_set_features(lfm_session *s, const lfm_csr *item_feat
         LFM_TRY(validate_csr(f[side], names[side]));
         if (f[side]->cols > s->n_feat[side]) return fail(LFM_EINVAL, "feature matrix has more columns than there are embeddings");
         dst[side]->clear();
+        if (side == 0) s->hot.state = 0;  // the hot set is derived from the item feature matrix
         LFM_TRY(dst[side]->upload(f[side], true, true));
         if (!dst[side]->identity) LFM_TRY(check_id_range(s, dst[side]->indices.p, dst[side]->nnz, s->n_feat[side], idx[side]));
     }
@@ -2041,6 +2057,53 @@ static int user_pair_share(lfm_session *s, double *out)
     return LFM_OK;
 }
 
+// The hot set of the resident item feature matrix: columns an interaction touches with probability >= 1/512 -- 2 x
+// occurrences / rows (the positive and the negative item), the rule of lightfm_amd/distributed.py: hot_rows -- and at
+// least twice; taken when they carry >= 1/4 of the matrix's entries (C3: 1 128 tag columns, 8 of 9 entries of every row;
+// C5's hashed columns: none) and fit the LDS slices (<= 4 864 rows, the most frequent ones beyond that).
+static int build_hot_set(lfm_session *s)
+{
+    lfm_session::HotSet &h = s->hot;
+    h.state = -1;
+    h.n = 0;
+    const int32_t cols = s->n_feat[0];
+    if (s->itf.identity || s->itf.nnz <= 0 || s->itf.rows <= 0 || cols <= 0 || (s->d & 1)) return LFM_OK;
+    std::vector<int32_t> counts((size_t)cols);
+    {
+        DBuf<int32_t> dc;
+        LFM_TRY(dc.alloc((size_t)cols));
+        HIP_TRY(launch_column_counts(s->itf.indices.p, s->itf.nnz, cols, dc.p, s->stream));
+        HIP_TRY(hipMemcpyAsync(counts.data(), dc.p, (size_t)cols * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    std::vector<int32_t> hot;
+    for (int32_t c = 0; c < cols; ++c)
+        if (counts[c] >= 2 && 2.0 * (double)counts[c] * 512.0 >= (double)s->itf.rows) hot.push_back(c);
+    const size_t cap = 4864;
+    if (hot.size() > cap) {
+        std::partial_sort(hot.begin(), hot.begin() + cap, hot.end(), [&](int32_t x, int32_t y) { return counts[x] > counts[y] || (counts[x] == counts[y] && x < y); });
+        hot.resize(cap);
+        std::sort(hot.begin(), hot.end());
+    }
+    int64_t covered = 0;
+    for (int32_t c : hot) covered += counts[c];
+    h.share = (double)covered / (double)s->itf.nnz;
+    const int cs = hot.empty() ? 0 : hot_slice_components((int)hot.size(), s->d);
+    if (hot.empty() || cs == 0 || 4 * covered < s->itf.nnz) return LFM_OK;
+    std::vector<int32_t> slot((size_t)cols, -1);
+    for (size_t j = 0; j < hot.size(); ++j) slot[(size_t)hot[j]] = (int32_t)j;
+    LFM_TRY(h.slot.upload(slot.data(), slot.size()));
+    LFM_TRY(h.rows.upload(hot.data(), hot.size()));
+    LFM_TRY(h.snapW.alloc(hot.size() * (size_t)s->d));
+    LFM_TRY(h.snapG.alloc(hot.size() * (size_t)s->d));
+    LFM_TRY(h.snapb.alloc(hot.size()));
+    LFM_TRY(h.snapbG.alloc(hot.size()));
+    h.n = (int)hot.size();
+    h.cs = cs;
+    h.state = 1;
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------------ epoch ---
 
 static void tile_geometry(int d, int want_rows, int *rows, int *stride)
@@ -2271,6 +2334,31 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         }
     }
 
+    // Shared item-feature rows in LDS slices (hot_slices.hip): the row-stream kernels of an adagrad model without
+    // regularisation, atomic publication.  A launch is then at most `hot_chunk` positions long -- the hot rows a launch reads
+    // are as old as the launch -- and ramps with the training history like the interactions in flight do (hot_k).
+    // lfm_opts.debug bit 14 (16384) / LIGHTFM_AMD_HOT_SLICES=0 keep the rows on the float atomics.
+    static const int hot_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_SLICES"); return e ? atoi(e) : 1; }();
+    static const int64_t hot_chunk_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_CHUNK"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 64 ? v : 32768); }();
+    static const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
+    static const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
+    bool use_hot = false;
+    if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
+        s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
+        if (s->hot.state == 0) LFM_TRY(build_hot_set(s));
+        use_hot = s->hot.state == 1;
+    }
+    if (use_hot) {
+        // the rows the float atomics still see are the rest: the steady-state bound of the shared rows counts them only
+        if (opts->shared_cap == 0 && !s->itf.identity && s->itf.rows > 0) {
+            const double avg_rest = (double)s->itf.nnz * (1.0 - s->hot.share) / (double)s->itf.rows;
+            shared_cap = INT64_MAX / 4;
+            if (!s->usf.identity && s->usf.rows > 0 && s->usf.nnz > 0)
+                shared_cap = std::max<int64_t>(64, (int64_t)((double)s->usf.cols / std::max(1.0, (double)s->usf.nnz / (double)s->usf.rows)));
+            shared_cap = std::min<int64_t>(shared_cap, std::max<int64_t>(64, (int64_t)((double)(s->itf.cols - s->hot.n) / std::max(1.0, avg_rest))));
+        }
+    }
+
     if (opts->neg_log) { LFM_TRY(s->neg_log.alloc((size_t)s->n)); a.neg_log = s->neg_log.p; }
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
     if (a.neg_log) HIP_TRY(hipMemsetAsync(a.neg_log, 0xff, (size_t)s->n * 4, s->stream));
@@ -2393,6 +2481,11 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // around a per cent -- but not below 64 Ki positions for accuracy's sake: past that alpha the model is
             // flattened whatever the scale's third digit is ("excessive regularisation"; see reg_len_cap).
             if (reg) len = std::min<int64_t>(len, reg_len_cap);
+            if (use_hot) {
+                const int64_t hist = history0 + (begin - seg_begin);
+                const int64_t hot_len = opts->ramp_k < 0 ? hot_chunk_env : std::min<int64_t>(hot_chunk_env, std::max<int64_t>(256, hist / hot_k_env));
+                len = std::min<int64_t>(len, hot_len);
+            }
             // ... and the FIRST regularised launch of a session has no measured rate to extrapolate with (reg_live is
             // created zeroed; LightFM.fit_partial opens a session per call): its readers see the launch-start scale
             // throughout, so it is kept to a growth of <= 0.02 -- the launch after it extrapolates from its rate
@@ -2452,6 +2545,42 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
                 else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                                   &grid_used, tile[ng].dma4));
+            }
+            else if (use_feat && use_hot) {
+                lfm_session::HotSet &h = s->hot;
+                LFM_TRY(h.rec.reserve((size_t)len));
+                LFM_TRY(h.x.reserve((size_t)len * (size_t)s->d));
+                HIP_TRY(hipMemsetAsync(h.rec.p, 0xff, (size_t)len * sizeof(HotRec), lst));  // n_total = -1: nothing to apply
+                a.hot_slot = h.slot.p;
+                a.hot_rec = h.rec.p;
+                a.hot_x = h.x.p;
+                HIP_TRY(launch_fit_feat_hot(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used));
+                HotArgs ha;
+                ha.rec = h.rec.p;
+                ha.x = h.x.p;
+                ha.n_rec = len;
+                ha.d = s->d;
+                ha.hot_n = h.n;
+                // replicas of a slice: two workgroups per CU over all slices; a short launch takes fewer (one record per
+                // launch: ONE replica, the sequential result)
+                const int n_slices = s->d / h.cs + 1;
+                int n_rep = hot_rep_env > 0 ? hot_rep_env : std::max(1, (2 * s->cus) / n_slices);
+                n_rep = (int)std::max<int64_t>(1, std::min<int64_t>(n_rep, len / 64));
+                ha.n_rep = n_rep;
+                ha.rows = h.rows.p;
+                ha.W = s->tab[0][0].p;
+                ha.G = s->tab[0][1].p;
+                ha.b = s->tab[0][3].p;
+                ha.bG = s->tab[0][4].p;
+                ha.snapW = h.snapW.p;
+                ha.snapG = h.snapG.p;
+                ha.snapb = h.snapb.p;
+                ha.snapbG = h.snapbG.p;
+                ha.lr = s->lr;
+                ha.rho = s->rho;
+                ha.eps = s->eps;
+                HIP_TRY(launch_hot_slices(ha, h.cs, n_rep > 1 ? 512 : 64, lst));
+                plan_flags |= 32;
             }
             else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));

@@ -686,7 +686,8 @@ class LightFM(object):
                                                "tile_ng": int(opts.tile_ng),
                                                "in_flight": int(opts.in_flight),
                                                "launches": int(opts.launches),
-                                               "user_store": int(opts.user_store)})
+                                               "user_store": int(opts.user_store),
+                                               "plan_flags": int(opts.plan_flags)})
                 if not session.check_finite():  # LFM:664
                     session.sync_to_host(model)
                     raise ValueError(_NOT_FINITE)

@@ -855,6 +855,25 @@ r6c)
   ( time timeout 1700 $PYT tests/test_fake_rccl_multirank.py -m gpu -x -q -s ) > $OUT/fake_rccl.txt 2>&1; grep -aE "FAKE_RCCL case|passed|failed|real|Error|error|assert" $OUT/fake_rccl.txt | cut -c1-300 | head -60
   ( time timeout 1500 $PYT tests/test_hbm_shapes.py -m gpu -x -q -s ) > $OUT/hbm_shapes.txt 2>&1; tail -5 $OUT/hbm_shapes.txt | cut -c1-300; grep real $OUT/hbm_shapes.txt
   ;;
+r6d)
+  # hot slices (csrc/hot_slices.hip): parity tests, the feature-kernel suites, then C3 A/B: hot set on / off, chunk and replica sweeps
+  ( time timeout 1200 $PYT tests/test_hot_slices.py tests/test_hip_feat.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -15 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-34s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d | steady %8.2f M/s  %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], ss.get("value", 0) / 1e6, r["kernel"][:60]))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 4 --warmup 2 --config c3"
+  for arm in "off:LIGHTFM_AMD_HOT_SLICES=0" "on:X=1" "chunk16k:LIGHTFM_AMD_HOT_CHUNK=16384" "chunk64k:LIGHTFM_AMD_HOT_CHUNK=65536" "chunk128k:LIGHTFM_AMD_HOT_CHUNK=131072" \
+             "rep15:LIGHTFM_AMD_HOT_REPLICAS=15" "rep60:LIGHTFM_AMD_HOT_REPLICAS=60" "waves12:LIGHTFM_AMD_FEAT_WAVES_PER_CU=12" "waves16:LIGHTFM_AMD_FEAT_WAVES_PER_CU=16"; do
+    IFS=: read name envs <<< "$arm"
+    env $envs timeout 300 python3 bench.py $S3 > $OUT/c3_$name.json 2> $OUT/c3_$name.err; line "c3 $name" $OUT/c3_$name.json
+  done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
