@@ -336,8 +336,10 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
             "true" if reg else "false")
     if used == 2:
-        return "fit_feat_kernel<%d, %d, false, %s>" % (N.LOSS_IDS[loss], 1 if dp <= 64 else (2 if dp <= 128 else 4),
-                                                       "true" if reg else "false")  # <loss id, NC, TIMED, REG>
+        hot = bool(int(getattr(stats_last, "plan_flags", 0)) & 32)  # the shared rows in LDS slices (csrc/hot_slices.hip)
+        return "fit_feat_kernel<%d, %d, false, %s, %s>%s" % (
+            N.LOSS_IDS[loss], 1 if dp <= 64 else (2 if dp <= 128 else 4), "true" if reg else "false",
+            "true" if hot else "false", " + hot_slice_kernel<8>" if hot else "")  # <loss id, NC, TIMED, REG, HOT>
     return "fit_%s_kernel (generic)" % loss.replace("-", "_")
 
 

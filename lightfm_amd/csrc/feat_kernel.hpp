@@ -64,15 +64,18 @@ struct Entries {
 // CU with a 10 KB LDS budget each (feat_kernels.hip: feat_plan) beat the 12 of round 4 by 2.9 % on the C5 shard (59.15 ->
 // 60.87 M interactions/s at --scale 0.25; the same kernel at 12 wavefronts loses 1.3 % to the tighter allocation;
 // profiles/r05_visit_i.txt): the kernel is instruction-bound, residency buys little.
-#define LFM_FEAT_MIN_BLOCKS(LOSS, TIMED) (((LOSS) == 3 && !(TIMED)) ? 4 : 2)
+#define LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA) (((LOSS) == 3 && !(TIMED) && !(ADA)) ? 4 : 2)  // (adadelta's third table: no 128-VGPR diet)
 // HOT (round 6): the model has a hot set (device.hpp: HotRec; session.hip: HotSet).  The update leaves the hot item-feature
 // rows out -- no W / G row gathers, no cell arithmetic, no atomics for them -- and writes their (slot, weight) entries, the
 // jobs' gradient coefficients and the user representation to the position's record; hot_slice_kernel (hot_slices.hip)
 // applies the records after the launch.  Scoring, sampling and every other row's update are unchanged.
-template <int LOSS, int NC, bool TIMED = false, bool REG = false, bool HOT = false>
-__global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_feat_kernel(FitArgs a)
+// ADA (round 6): the adadelta schedule (PYX:416-434) -- the momentum rows M travel with W and G (three staged tables instead
+// of two), the cell arithmetic is cell_math's adadelta branch and the moving averages are published by compare-and-swap
+// (device.hpp: publish_adadelta: a summed delta would apply the decay once per concurrent writer).
+template <int LOSS, int NC, bool TIMED = false, bool REG = false, bool HOT = false, bool ADA = false>
+__global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fit_feat_kernel(FitArgs a)
 {
-    static_assert(!(HOT && (REG || TIMED)), "the hot-set variants carry neither the lazy regularisation nor phase timers");
+    static_assert(!(HOT && (REG || TIMED || ADA)), "the hot-set variants: adagrad, no lazy regularisation, no phase timers");
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMED) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
     // d == 64 NC (d = 64 or 128: every BASELINE configuration): the reduce runs with compile-time LDS offsets
     constexpr int DF = 64 * NC;
     const bool fastd = d == DF;
-    const Hyper h{0, a.m.lr, a.m.rho, a.m.eps};
+    const Hyper h{ADA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
     const int um = a.update_mode;
     const bool ustore = a.user_store && um == 0;  // user-side rows (identity user features): plain stores, FitArgs::user_store
     const int max_sampled = a.m.max_sampled;
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
         }
     };
     // rows of entries [c0e, c0e + nc) of the current round: memory -> dst[0 .. nc) by LDS-DMA
-    auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, bool gtab) {
+    auto dma_rows = [&](int feat, int eside, int c0e, int nc, float *dst, int tabk) {  // tabk: 0 = W, 1 = G, 2 = M rows
         const int rsub = lane / LPR, piece = lane - rsub * LPR;
         if (RPI == 2) {
             // d = 128: two rows per instruction.  Every lane forms the address of ITS entry's row once; an instruction's
             // two row addresses then come from lane reads (scalar) and a select by the lane's half -- no ds_bpermute
             // round trips, no per-instruction table select and 64-bit multiply (27 -> ~12 instructions per two rows)
-            const float *tab = gtab ? (eside ? a.m.G[1] : a.m.G[0]) : (eside ? a.m.W[1] : a.m.W[0]);
+            const float *tab = tabk == 2 ? (eside ? a.m.M[1] : a.m.M[0]) : (tabk == 1 ? (eside ? a.m.G[1] : a.m.G[0]) : (eside ? a.m.W[1] : a.m.W[0]));
             const unsigned long long mine = (unsigned long long)(uintptr_t)(tab + (size_t)feat * d);
             const int alo = (int)(unsigned)mine, ahi = (int)(unsigned)(mine >> 32);
             auto two_rows = [&](int i0, bool guard) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             const int e = c0e + i0 + rsub;
             const bool valid = rsub < RPI && (i0 + rsub) < nc;
             const int fe = __shfl(feat, e & (WAVE - 1), WAVE), se = __shfl(eside, e & (WAVE - 1), WAVE);
-            const float *tab = gtab ? (se ? a.m.G[1] : a.m.G[0]) : (se ? a.m.W[1] : a.m.W[0]);
+            const float *tab = tabk == 2 ? (se ? a.m.M[1] : a.m.M[0]) : (tabk == 1 ? (se ? a.m.G[1] : a.m.G[0]) : (se ? a.m.W[1] : a.m.W[0]));
             const float *src = tab + (size_t)fe * d + piece * 4;
             if (valid) __builtin_amdgcn_global_load_lds(src, (lds_f32_t *)(dst + (size_t)i0 * d), 16, 0, 0);
         }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             const int jend_round = off + len - r * WAVE;
             for (int ce = 0; ce < e.n; ce += SR) {
                 const int nc = min(SR, e.n - ce);
-                dma_rows(e.feat, e.eside, ce, nc, stage, false);
+                dma_rows(e.feat, e.eside, ce, nc, stage, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd rows have landed
                 wave_sync();
                 stamp(2);
@@ -406,18 +409,26 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
     HotRec *hrec = nullptr;                  // HOT: this position's record
     int hot_n0 = 0, hot_n1 = 0, hot_n2 = 0;  // HOT: entries recorded so far for job 0 / 1 / 2 of the current interaction
     auto update_round = [&](const Entries &e_in, double g0, double g1, double g2, const float (&xI)[NC],
-                            const float (&xU)[NC], double &lr_sum) {
+                            const float (&xU)[NC], double &lr_sum, bool whole_list = true) {
         Entries e = e_in;
         if constexpr (HOT) {
             // entries that name a hot item-side row go to the record (in list order: job by job, as the reference walks
-            // them); the others are compacted to the front of the list and updated below as ever
+            // them); the others are compacted to the front of the list and updated below as ever.  All of an
+            // interaction's hot entries or none: a tag shared by the positive and the negative item must see its two
+            // updates in the reference's order (early on, G = 1, the two nearly cancel and what remains depends on the
+            // order), so an interaction whose list takes several rounds (> 64 entries) or holds more hot entries than a
+            // record (HOT_EMAX) publishes everything as before.
             int hs = -1;
-            if (lane < e.n && e.eside == 0) hs = a.hot_slot[e.feat];
-            const unsigned long long hm = __ballot(hs >= 0);
+            if (whole_list && lane < e.n && e.eside == 0) hs = a.hot_slot[e.feat];
+            unsigned long long hm = __ballot(hs >= 0);
+            if (__popcll(hm) > HOT_EMAX) {
+                hm = 0ull;
+                hs = -1;
+            }
             if (hm != 0ull) {
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const int rank = hot_n0 + hot_n1 + hot_n2 + __popcll(hm & below);
-                const bool rec = hs >= 0 && rank < HOT_EMAX;  // (beyond the record's capacity: published as before)
+                const bool rec = hs >= 0;
                 if (rec) {
                     HotRec::Entry en;
                     en.slot = hs;
@@ -438,8 +449,8 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
                 e.n = nk;
             }
         }
-        const int SRh = SR >> 1;
-        float *stW = stage, *stG = stage + (size_t)SRh * d;
+        const int SRh = ADA ? SR / 3 : SR >> 1;
+        float *stW = stage, *stG = stage + (size_t)SRh * d, *stM = stage + 2 * (size_t)SRh * d;
         const bool on = lane < e.n;
         int gen = 0;
         stamp(4);
@@ -448,22 +459,25 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             if (on && lane > t && e.feat == ft && e.eside == st_) ++gen;
         }
         float *bp = (e.eside ? a.m.b[1] : a.m.b[0]) + e.feat, *bgp = (e.eside ? a.m.bG[1] : a.m.bG[0]) + e.feat;
+        float *bmp = ADA ? (e.eside ? a.m.bM[1] : a.m.bM[0]) + e.feat : nullptr;
         const double gb = e.job == 0 ? g0 : (e.job == 1 ? g1 : g2);
         for (int g = 0;; ++g) {
             const unsigned long long live = __ballot(on && gen == g);
             if (live == 0ull) break;
             if (g > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the earlier generation is visible
             const bool mine = on && gen == g;
-            float obW = 0.0f, obG = 1.0f;
+            float obW = 0.0f, obG = 1.0f, obM = 0.0f;
             if (mine) {  // bias cells: requested with the first rows, consumed after the last
                 obW = *bp;
                 obG = *bgp;
+                if constexpr (ADA) obM = *bmp;
             }
             for (int ce = 0; ce < e.n; ce += SRh) {
                 const int nc = min(SRh, e.n - ce);
                 if (((live >> ce) & ((nc >= 64) ? ~0ull : ((1ull << nc) - 1ull))) == 0ull) continue;
-                dma_rows(e.feat, e.eside, ce, nc, stW, false);
-                dma_rows(e.feat, e.eside, ce, nc, stG, true);
+                dma_rows(e.feat, e.eside, ce, nc, stW, 0);
+                dma_rows(e.feat, e.eside, ce, nc, stG, 1);
+                if constexpr (ADA) dma_rows(e.feat, e.eside, ce, nc, stM, 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 wave_sync();
                 stamp(5);
@@ -474,19 +488,28 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
                     const double gc = jt == 0 ? g0 : (jt == 1 ? g1 : g2);
                     float *Wp = (st_ ? a.m.W[1] : a.m.W[0]) + (size_t)fe * d;
                     float *Gp = (st_ ? a.m.G[1] : a.m.G[0]) + (size_t)fe * d;
-                    const float *sw = stW + (size_t)(t - ce) * d, *sg = stG + (size_t)(t - ce) * d;
+                    const float *sw = stW + (size_t)(t - ce) * d, *sg = stG + (size_t)(t - ce) * d, *sm = stM + (size_t)(t - ce) * d;
+                    float *Mp = ADA ? (st_ ? a.m.M[1] : a.m.M[0]) + (size_t)fe * d : nullptr;
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
                         const int c = lane + WAVE * q;
                         if (c < d) {
-                            const float oW = sw[c], oG = sg[c];
+                            const float oW = sw[c], oG = sg[c], oM = ADA ? sm[c] : 0.0f;
                             const float x = st_ ? xU[q] : xI[q];
                             float nW, nG, nM;
                             double lr;
-                            cell_math(oW, oG, 0.0f, wt, gc * (double)x, h, st_ ? alpha_u : alpha_i, nW, nG, nM, lr);
+                            const double gcell = gc * (double)x, al = st_ ? alpha_u : alpha_i;
+                            cell_math(oW, oG, oM, wt, gcell, h, al, nW, nG, nM, lr);
+                            if constexpr (ADA) {
+                                // (the moving averages by compare-and-swap: the learning rate that counts is the one of
+                                // the value actually replaced)
+                                if (um == 0) lr = publish_adadelta(Wp + c, Gp + c, Mp + c, oW, oG, oM, wt, gcell, h, al);
+                                else publish_cell(Wp + c, Gp + c, Mp + c, oW, oG, oM, nW, nG, nM, wt, gcell, h, al, um);
+                            } else {
+                                publish(Wp + c, nW, oW, (st_ && ustore) ? 1 : um);
+                                publish(Gp + c, nG, oG, (st_ && ustore) ? 1 : um);
+                            }
                             if constexpr (REG) lr_sum += c < a.m.d_real ? lr : 0.0;
-                            publish(Wp + c, nW, oW, (st_ && ustore) ? 1 : um);
-                            publish(Gp + c, nG, oG, (st_ && ustore) ? 1 : um);
                         }
                     }
                 }
@@ -496,11 +519,17 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             {
                 float nW, nG, nM;
                 double lr;
-                cell_math(obW, obG, 0.0f, (double)e.w, gb, h, e.eside ? alpha_u : alpha_i, nW, nG, nM, lr);
+                const double alb = e.eside ? alpha_u : alpha_i;
+                cell_math(obW, obG, obM, (double)e.w, gb, h, alb, nW, nG, nM, lr);
                 if (mine) {
+                    if constexpr (ADA) {
+                        if (um == 0) lr = publish_adadelta(bp, bgp, bmp, obW, obG, obM, (double)e.w, gb, h, alb);
+                        else publish_cell(bp, bgp, bmp, obW, obG, obM, nW, nG, nM, (double)e.w, gb, h, alb, um);
+                    } else {
+                        publish(bp, nW, obW, (e.eside && ustore) ? 1 : um);
+                        publish(bgp, nG, obG, (e.eside && ustore) ? 1 : um);
+                    }
                     if constexpr (REG) lr_sum += lr;
-                    publish(bp, nW, obW, (e.eside && ustore) ? 1 : um);
-                    publish(bgp, nG, obG, (e.eside && ustore) ? 1 : um);
                 }
             }
             stamp(6);
@@ -542,7 +571,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED)) void fit_fea
             round_entries(r, J, start, len, off, side, T, e.feat, e.w, e.job, e.eside);
             e.n = min(WAVE, T - r * WAVE);
             if (r > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // rounds are sequential
-            update_round(e, g0, g1, g2, xI, xU, lr_sum);
+            update_round(e, g0, g1, g2, xI, xU, lr_sum, T <= WAVE);
         }
         scale_step(lr_sum, T);
         hot_finish(g0, g1, g2, xI);
@@ -854,6 +883,36 @@ inline hipError_t launch_feat_nc(int loss, const FitArgs &a, int grid, int block
 
 hipError_t launch_fit_feat_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                                 int *grid_used);
+
+// the ADA instantiations (feat_kernels_ada.hip): the adadelta schedule, with and without lazy regularisation, d <= 128
+template <int NC>
+inline hipError_t launch_feat_ada_nc(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                                     int *grid_used)
+{
+    void (*kernel)(FitArgs) = nullptr;
+    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
+    if (reg) switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, true, false, true>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, true, false, true>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, true, false, true>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, true, false, true>; break;
+    default: return hipErrorInvalidValue;
+    }
+    else switch (loss) {
+    case LFM_LOSS_LOGISTIC_ID: kernel = fit_feat_kernel<LFM_LOSS_LOGISTIC_ID, NC, false, false, false, true>; break;
+    case LFM_LOSS_WARP_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_ID, NC, false, false, false, true>; break;
+    case LFM_LOSS_BPR_ID: kernel = fit_feat_kernel<LFM_LOSS_BPR_ID, NC, false, false, false, true>; break;
+    case LFM_LOSS_WARP_KOS_ID: kernel = fit_feat_kernel<LFM_LOSS_WARP_KOS_ID, NC, false, false, false, true>; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (cus > 0) {
+        const int per_cu = occupancy_cached(kernel, block, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, block, smem, st>>>(a);
+    return hipGetLastError();
+}
 
 // the HOT instantiations (feat_kernels_hot.hip): adagrad, no regularisation, d <= 128
 template <int NC>

@@ -78,6 +78,9 @@ struct FeatPlan {
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used = nullptr, bool timed = false);
+// feat_kernels_ada.hip: the adadelta instantiations of the row-stream kernels (d <= 128)
+hipError_t launch_fit_feat_ada(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
+                               int *grid_used = nullptr);
 // feat_kernels_hot.hip: the HOT instantiations of the row-stream kernels (a model with a hot set: FitArgs::hot_slot)
 hipError_t launch_fit_feat_hot(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                                int *grid_used = nullptr);

@@ -596,6 +596,7 @@ struct lfm_session {
     // the OR-all-reduce of the byte maps and the compaction: every row travels (bit-identical result: an untouched row's
     // deltas are zeros).  The union is the same on every rank, so every rank takes the same path.
     bool merge_all_rows[2] = {false, false};
+    int merge_all_uses[2] = {0, 0};  // merges of the side that ran on the latch since the rows were last detected
     float merge_dense_frac = 0.9f;
 
     // LIGHTFM_AMD_VALIDATE=1 (debugging): checksums of the read-only device inputs at the end of the
@@ -1433,7 +1434,21 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
                 return fail(LFM_EINVAL, "sessions differ in shape");
         }
         if (nf == 0) continue;
-        const bool all_rows = !hot_only && s0->merge_all_rows[side];
+        // ... re-examined every 16 merges (a long early interval of a large table must not make every later, shorter
+        // interval ship the whole table: ADVICE r5), and never taken for a side whose fused buffer exceeds 64 MB -- the
+        // latch pays where detection, OR and compaction cost more than the zeros they would have saved (ML-20M's item side:
+        // 13.9 MB).  Both conditions depend on counts every rank shares, so all ranks take the same path.
+        bool all_rows = !hot_only && s0->merge_all_rows[side] && s0->merge_dense_frac > 0.0f;
+        if (all_rows && (s0->merge_all_uses[side] >= 16 || (int64_t)nf * row_floats * (int64_t)sizeof(float) > ((int64_t)64 << 20))) {
+            all_rows = false;
+            for (int i = 0; i < k; ++i) {
+                ss[i]->merge_all_rows[side] = false;
+                ss[i]->merge_all_uses[side] = 0;
+            }
+        }
+        if (!hot_only && s0->merge_all_rows[side] && s0->merge_dense_frac <= 0.0f) all_rows = true;  // "always": the caller's choice
+        if (all_rows)
+            for (int i = 0; i < k; ++i) ++ss[i]->merge_all_uses[side];
         if (hot_only) {
             // the given rows (identical on every rank by contract): no detection, no union, no compaction
             for (int i = 0; i < k; ++i) {
@@ -1483,7 +1498,10 @@ static int merge_group_sparse(lfm_session **ss, int k, int nranks_total, int sid
                 s->pend.n_u[side] = n_u;
                 s->pend.all_rows[side] = false;
                 // (the union is the same on every rank: all take the same path from the next merge on)
-                if ((double)n_u >= (double)s->merge_dense_frac * (double)nf) s->merge_all_rows[side] = true;
+                if ((double)n_u >= (double)s->merge_dense_frac * (double)nf && (int64_t)nf * row_floats * (int64_t)sizeof(float) <= ((int64_t)64 << 20)) {
+                    s->merge_all_rows[side] = true;
+                    s->merge_all_uses[side] = 0;
+                }
             }
         }
         const int64_t n_u = s0->pend.n_u[side];
@@ -2320,7 +2338,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
     FeatPlan fplan;
     bool use_feat = false;
-    if (!serial && !use_tile && opts->feat_kernel != 1 && !s->adadelta && s->itf.rows >= 1 && s->n > 0) {
+    // (adadelta: the ADA instantiations, d <= 128 and not the instrumented build; wider adadelta models run the generic kernels)
+    if (!serial && !use_tile && opts->feat_kernel != 1 && !(s->adadelta && (s->d > 128 || opts->feat_kernel == 2)) && s->itf.rows >= 1 && s->n > 0) {
         auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
         const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
         use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan);
@@ -2338,26 +2357,20 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // regularisation, atomic publication.  A launch is then at most `hot_chunk` positions long -- the hot rows a launch reads
     // are as old as the launch -- and ramps with the training history like the interactions in flight do (hot_k).
     // lfm_opts.debug bit 14 (16384) / LIGHTFM_AMD_HOT_SLICES=0 keep the rows on the float atomics.
-    static const int hot_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_SLICES"); return e ? atoi(e) : 1; }();
-    static const int64_t hot_chunk_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_CHUNK"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 64 ? v : 32768); }();
-    static const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
-    static const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
+    // (read per epoch, not once per process: the study scripts vary them between fits)
+    const int hot_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_SLICES"); return e ? atoi(e) : 1; }();
+    const int64_t hot_chunk_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_CHUNK"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 64 ? v : 131072); }();
+    const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 128); }();
+    const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
     bool use_hot = false;
     if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
-        s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
+        !s->adadelta && s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
         if (s->hot.state == 0) LFM_TRY(build_hot_set(s));
         use_hot = s->hot.state == 1;
     }
-    if (use_hot) {
-        // the rows the float atomics still see are the rest: the steady-state bound of the shared rows counts them only
-        if (opts->shared_cap == 0 && !s->itf.identity && s->itf.rows > 0) {
-            const double avg_rest = (double)s->itf.nnz * (1.0 - s->hot.share) / (double)s->itf.rows;
-            shared_cap = INT64_MAX / 4;
-            if (!s->usf.identity && s->usf.rows > 0 && s->usf.nnz > 0)
-                shared_cap = std::max<int64_t>(64, (int64_t)((double)s->usf.cols / std::max(1.0, (double)s->usf.nnz / (double)s->usf.rows)));
-            shared_cap = std::min<int64_t>(shared_cap, std::max<int64_t>(64, (int64_t)((double)(s->itf.cols - s->hot.n) / std::max(1.0, avg_rest))));
-        }
-    }
+    // (the steady-state bound on the interactions in flight of a model with shared rows -- shared_cap above -- stays what it
+    // is: relaxing it because the hot rows left the atomic path cost the hybrid WARP / k-OS gates 0.002-0.003 precision@10
+    // whatever the record length, profiles/r06_hot_gate_sweep.txt)
 
     if (opts->neg_log) { LFM_TRY(s->neg_log.alloc((size_t)s->n)); a.neg_log = s->neg_log.p; }
     if (opts->sampled_log) { LFM_TRY(s->sampled_log.alloc((size_t)s->n)); a.sampled_log = s->sampled_log.p; }
@@ -2582,6 +2595,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 HIP_TRY(launch_hot_slices(ha, h.cs, n_rep > 1 ? 512 : 64, lst));
                 plan_flags |= 32;
             }
+            else if (use_feat && s->adadelta) HIP_TRY(launch_fit_feat_ada(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used));
             else if (use_feat) HIP_TRY(launch_fit_feat(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used,
                                                        opts->feat_kernel == 2));
             else HIP_TRY(launch_fit(loss, a, grid, 256, lsmem, lst, s->cus, &grid_used));

@@ -292,13 +292,24 @@ class DistributedFit(object):
         self.hot = [hot_rows(item_features, self.policy.hot_share, 2.0),
                     hot_rows(user_features if self.shared_users else None, self.policy.hot_share, 1.0)]
         if self.owner_sharded:
-            # every rank's export to every rank (the rendezvous plane), then the peers' allocations are mapped
+            # every rank's export to every rank (the rendezvous plane: CPU tensors, i.e. a gloo-capable process group),
+            # then the peers' allocations are mapped.  A rank-local failure (hipIpcOpenMemHandle, out of memory) must not
+            # leave the others blocked in the next rendezvous: every step ends with an agreement on an error flag
+            # (_agree), and all ranks raise together.
             import torch
-            mine = torch.frombuffer(bytearray(self.session.export_items()), dtype=torch.uint8).clone()
+            err = None
+            try:
+                mine = torch.frombuffer(bytearray(self.session.export_items()), dtype=torch.uint8).clone()
+            except Exception as exc:  # noqa: BLE001 -- reported on every rank below
+                err, mine = exc, torch.zeros(C.sizeof(N.LfmItemExport), dtype=torch.uint8)
+            self._agree(err, "exporting the item tables")
             blobs = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(blobs, mine)
-            self.session.share_items_ipc([bytes(b.numpy().tobytes()) for b in blobs], rank)
-            dist.barrier()  # nobody trains before every rank has its mappings
+            try:
+                self.session.share_items_ipc([bytes(b.numpy().tobytes()) for b in blobs], rank)
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            self._agree(err, "mapping the owners' item tables")  # nobody trains before every rank has its mappings
         elif world > 1:
             import torch
             uid = C.create_string_buffer(N.UNIQUE_ID_BYTES)
@@ -405,6 +416,18 @@ class DistributedFit(object):
         self.session.sync_to_host(self.struct)
         return stats
 
+    def _agree(self, error, what):
+        """A rendezvous that doubles as the barrier of an owner-sharded step: every rank contributes whether ITS part
+        failed; if any did, every rank raises (the failing ones their own exception) instead of some waiting forever
+        in the next collective."""
+        import torch
+        t = torch.tensor([0 if error is None else 1], dtype=torch.int32)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        if error is not None:
+            raise error
+        if int(t[0]):
+            raise RuntimeError("another rank failed while %s" % what)
+
     def _any(self, flag):
         """max over ranks of a flag on the rendezvous plane (owner-sharded jobs have no RCCL communicator)."""
         import torch
@@ -416,8 +439,12 @@ class DistributedFit(object):
         """Owner-sharded item tables, after training: every rank copies the other owners' rows into its own
         tables (device to device through the mappings) -- between two barriers, so nobody trains meanwhile."""
         self.dist.barrier()
-        self.session.gather_shared_items()
-        self.dist.barrier()
+        err = None
+        try:
+            self.session.gather_shared_items()
+        except Exception as exc:  # noqa: BLE001 -- all ranks raise together (_agree)
+            err = exc
+        self._agree(err, "gathering the item rows from their owners")
 
     def barrier(self):
         """Device work of this rank done and every rank here (bench.py's timed region)."""
@@ -445,5 +472,12 @@ class DistributedFit(object):
 
     def close(self):
         if self.owner_sharded and self.session.handle:
-            self.dist.barrier()  # an owner's tables stay mapped in the peers until every rank is done with them
+            # an owner's tables stay mapped in the peers until every rank is done with them; a rank that arrives here on an
+            # error path of its own still takes part (monitored: a rank that died is reported after the timeout instead of
+            # blocking the others for good)
+            import datetime
+            if hasattr(self.dist, "monitored_barrier"):  # (gloo: the owner-sharded rendezvous needs a gloo-capable group anyway)
+                self.dist.monitored_barrier(timeout=datetime.timedelta(seconds=300))
+            else:
+                self.dist.barrier()
         self.session.close()

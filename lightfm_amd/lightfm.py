@@ -436,6 +436,8 @@ class LightFM(object):
         state.pop("_scoring_mutex", None)
         state.pop("_scoring_owner", None)
         state.pop("_scoring_drop_pending", None)
+        state.pop("_scanned", None)  # per-call scratch of fit_partial
+        state.pop("_stages", None)
         return state
 
     def __del__(self):
@@ -541,11 +543,12 @@ class LightFM(object):
         """(all ones, finite) of an input array: one pass of the native helper, remembered per array for the call (the
         interaction values are asked about three times: LFM:383-386, 617-625)."""
         seen = getattr(self, "_scanned", None)
-        if seen is not None and seen[0] is data:
-            return seen[1]
+        if seen is not None and id(data) in seen and seen[id(data)][0] is data:
+            return seen[id(data)][1]
         answer = N.host_scan(data) if isinstance(data, np.ndarray) and data.size >= (1 << 16) else (
             bool(np.array_equiv(data, 1.0)), bool(np.isfinite(np.sum(data))))
-        self._scanned = (data, answer)
+        if seen is not None:  # only inside fit_partial, which clears it again: the entries hold the caller's arrays
+            seen[id(data)] = (data, answer)
         return answer
 
     def _check_input_finite(self, data):
@@ -580,7 +583,20 @@ class LightFM(object):
                     sample_weight=None, epochs=1, num_threads=1, verbose=False):
         """Resume training from the current state (LFM:560-666)."""
         self._stages = stages = _Stages()
-        self._scanned = None
+        self._scanned = {}  # per-array answers of _scan for THIS call (feature values, interaction values, sample weights)
+        try:
+            interactions, user_features, item_features, sample_weight_data = self._fit_prologue(
+                interactions, user_features, item_features, sample_weight, num_threads)
+        finally:
+            self._scanned = None  # (the entries hold references to the caller's arrays)
+        stages.mark("host checks")
+        self._run_epochs(item_features, user_features, interactions, sample_weight_data,
+                         num_threads, epochs, verbose)
+        stages.report()
+        return self
+
+    def _fit_prologue(self, interactions, user_features, item_features, sample_weight, num_threads):
+        """The input coercions and checks of LFM:560-652."""
         interactions = interactions.tocoo()
         if interactions.dtype != CYTHON_DTYPE:
             interactions.data = interactions.data.astype(CYTHON_DTYPE)
@@ -603,13 +619,7 @@ class LightFM(object):
             raise ValueError("Incorrect number of features in user_features")
         if num_threads < 1:
             raise ValueError("Number of threads must be 1 or larger.")
-        stages.mark("host checks")
-        self._scanned = None  # (holds a reference to the caller's array)
-
-        self._run_epochs(item_features, user_features, interactions, sample_weight_data,
-                         num_threads, epochs, verbose)
-        stages.report()
-        return self
+        return interactions, user_features, item_features, sample_weight_data
 
     def _run_epochs(self, item_features, user_features, interactions, sample_weight, num_threads,
                     epochs, verbose):

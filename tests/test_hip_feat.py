@@ -246,4 +246,67 @@ def test_feat_kernel_is_the_one_that_ran(fast):
         m = LightFM(no_components=64, random_state=1, **model_kw)
         m.fit(coo, item_features=f, epochs=1)
         seen[name] = m._last_epoch_stats[-1]["kernel_used"]
-    assert seen == {"feat": 2, "generic": 0, "tile": 1, "adadelta": 0}
+    assert seen == {"feat": 2, "generic": 0, "tile": 1, "adadelta": 2}  # (adadelta: the ADA instantiations since round 6)
+
+
+ADA_SEQ = [
+    ("d64-tags", 64, 10, "tags", "id"),
+    ("d128-tagsonly-both", 128, 10, "tagsonly", "tags"),
+    ("d10-tags", 10, 10, "tags", "id"),
+    ("d32-wide", 32, 6, "wide", "id"),
+]
+
+
+@pytest.mark.parametrize("case", ADA_SEQ, ids=[c[0] for c in ADA_SEQ])
+@pytest.mark.parametrize("loss", ["warp", "bpr", "logistic", "warp-kos"])
+@pytest.mark.parametrize("update_mode", [1, 3], ids=["store", "atomic"])
+def test_adadelta_one_interaction_per_launch_matches_the_oracle(fast, case, loss, update_mode):
+    """The adadelta schedule (PYX:416-434) on the row-stream kernels (ADA instantiations: the momentum rows travel with W
+    and G, the moving averages are published by compare-and-swap): sequential launches against the oracle, the bars of
+    the adagrad test above."""
+    from lightfm_amd.options import options
+    _, d, ms, itf, usf = case
+    nu, ni = 40, 30
+    coo = H.make_interactions(nu, ni, 260, seed=3, ratings=(loss != "warp-kos"))
+    item_f, user_f = _features(itf, ni, 5), _features(usf, nu, 6)
+    rng = np.random.RandomState(4)
+    st = oracle.State(item_f.shape[1], user_f.shape[1], d, rng, schedule="adadelta", max_sampled=ms)
+    _spread(st, item_f.nnz / ni, user_f.nnz / nu)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=(loss != "logistic"), launches_per_epoch=len(coo.data), update_mode=update_mode, warp_kernel=1)
+    weight = coo.data if loss != "logistic" else np.ones_like(coo.data)
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _run_hip(fast, loss, coo, item_f, user_f, a, shuffle, seeds, weight)
+        o = _run_orc(loss, coo, item_f, user_f, b, shuffle, seeds, weight)
+        if loss != "logistic":
+            neg, sampled = options.last_logs
+            assert np.array_equal(sampled, o.sampled) and np.array_equal(neg, o.neg)
+        assert options.last_counters == o.counters
+    assert options.last_kernel_used == 2, "the row-stream kernels did not run"
+    assert not np.array_equal(a.item_embedding_momentum, st.item_embedding_momentum), "the momentum tables were not trained"
+    if update_mode == 1 and loss in ("warp", "warp-kos"):
+        H.assert_states_equal(a, b, exact=True)
+    elif update_mode == 1:
+        H.assert_states_equal(a, b, exact=False, rtol=2e-6, atol=1e-6)
+    else:
+        H.assert_states_equal(a, b, exact=False, rtol=2e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("loss", ["bpr", "warp-kos", "warp"])
+def test_adadelta_hogwild_on_the_row_stream_kernels_learns(loss):
+    """Full concurrency, hybrid model, adadelta: finite tables (the compare-and-swap publication keeps the moving
+    averages positive under any number of concurrent writers of a shared row) and a model that ranks its positives."""
+    from lightfm_amd import LightFM, options
+    coo = H.make_interactions(3000, 2000, 150_000, seed=8, zipf=0.8)
+    feats = H.tag_features(2000, 30, 3, 2)
+    m = LightFM(no_components=64, loss=loss, learning_schedule="adadelta", random_state=3)
+    m.fit(coo, item_features=feats, epochs=4)
+    assert m._last_epoch_stats[-1]["kernel_used"] == 2
+    for name in ("item_embeddings", "item_embedding_gradients", "item_embedding_momentum", "user_embeddings", "item_biases"):
+        assert np.isfinite(getattr(m, name)).all(), name
+    assert (m.item_embedding_gradients >= 0).all() and (m.item_embedding_momentum >= 0).all()
+    rows, cols = np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col)
+    negs = np.random.RandomState(0).randint(0, 2000, size=coo.nnz).astype(np.int32)
+    acc = float(np.mean(m.predict(rows, cols, item_features=feats) > m.predict(rows, negs, item_features=feats)))
+    assert acc > 0.75, acc

@@ -4,7 +4,7 @@ between launches instead of by float atomics of every interaction.  Against the 
 
   * one interaction per launch: the two-phase path is then sequential (one replica, one record) and weights, biases and
     accumulators must equal the oracle's within the bar of every atomically published update (old + fl32(new - old): a few
-    float32 ulps of the array's largest magnitude), samples and counters exactly -- all four losses, weighted tags, a tag
+    float32 ulps of the array's largest magnitude, <= 8 here), samples and counters exactly -- all four losses, weighted tags, a tag
     shared by the positive and the negative item included, d = 16 / 40 / 128;
   * frozen weights under full concurrency and the default launch plan: every position's negative and draw count and the
     counters equal the oracle's, no table moves (a record with gradient 0 leaves its LDS cells as they were);
@@ -108,7 +108,8 @@ def test_one_interaction_per_launch_matches_the_oracle(fast, case, loss):
     assert options.last_counters == o.counters, (options.last_counters, o.counters)
     tag_rows = slice(ni, ni + n_tags)
     assert not np.array_equal(a.item_embeddings[tag_rows], st.item_embeddings[tag_rows]), "the tag rows were not trained"
-    H.assert_states_within_ulps(a, b, ulps=4, min_exact=0.3)
+    # (a cell updated n times carries up to n half-ulps of the value it had then: logistic updates at EVERY position)
+    H.assert_states_within_ulps(a, b, ulps=8, min_exact=0.3)
 
 
 FROZEN = [

@@ -39,4 +39,7 @@ for seed in range(7, 7 + n_ref):
     r.fit(train, item_features=feats, epochs=3, num_threads=min(16, os.cpu_count() or 1))
     ref.append(p10(r))
     print("ref seed %d: %.5f (%.0f s)" % (seed, ref[-1], time.time() - t), flush=True)
-print("C3 full size: hip %.5f (n=3) ref %.5f (n=%d) delta %+.5f" % (np.mean(hip), np.mean(ref), len(ref), np.mean(hip) - np.mean(ref)))
+if ref:
+    print("C3 full size: hip %.5f (n=3) ref %.5f (n=%d) delta %+.5f" % (np.mean(hip), np.mean(ref), len(ref), np.mean(hip) - np.mean(ref)))
+else:
+    print("C3 full size: hip %.5f (n=3; std %.5f)  plan_flags %s  [%s]" % (np.mean(hip), np.std(hip), m._last_epoch_stats[-1].get("plan_flags"), " ".join("%s=%s" % kv for kv in sorted(os.environ.items()) if kv[0].startswith("LIGHTFM_AMD_"))))

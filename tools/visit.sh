@@ -874,6 +874,34 @@ PY
     env $envs timeout 300 python3 bench.py $S3 > $OUT/c3_$name.json 2> $OUT/c3_$name.err; line "c3 $name" $OUT/c3_$name.json
   done
   ;;
+r6e)
+  # hot slices: quality against the record length -- full-size C3 precision@10 (this backend only; the reference: 0.06049, profiles/r05_quality_c3_full.txt)
+  # and the hybrid precision gates at the default and at a 128 Ki record length
+  for envs in "LIGHTFM_AMD_HOT_SLICES=0" "LIGHTFM_AMD_HOT_CHUNK=32768" "LIGHTFM_AMD_HOT_CHUNK=65536" "LIGHTFM_AMD_HOT_CHUNK=131072" "LIGHTFM_AMD_HOT_CHUNK=262144" "LIGHTFM_AMD_HOT_CHUNK=131072 LIGHTFM_AMD_HOT_K=2"; do
+    env $envs timeout 400 python3 tools/quality_c3_full.py 0 2>&1 | tail -1
+  done
+  for envs in "LIGHTFM_AMD_HOT_CHUNK=32768" "LIGHTFM_AMD_HOT_CHUNK=131072"; do
+    ( time env $envs timeout 1500 $PYT tests/test_precision_parity.py -m gpu -q -s -k "bpr_tag or shared_tag" ) > $OUT/gates_$(echo $envs | tr -c 'A-Za-z0-9' '_').txt 2>&1
+    echo "== $envs"; grep -aE "delta|passed|failed|real" $OUT/gates_$(echo $envs | tr -c 'A-Za-z0-9' '_').txt
+  done
+  ;;
+r6f)
+  # hot slices: the record-length ramp (hot_k) and cap against the hybrid gate problems; then the feature suites with the hot set and the
+  # adadelta instantiations
+  timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "k8-32k:HOT_K=8,HOT_CHUNK=32768" "k32-128k:HOT_K=32,HOT_CHUNK=131072" "k64-128k:HOT_K=64,HOT_CHUNK=131072" \
+      "k128-128k:HOT_K=128,HOT_CHUNK=131072" "k256-128k:HOT_K=256,HOT_CHUNK=131072" "k64-32k:HOT_K=64,HOT_CHUNK=32768" 2>&1 | tail -30
+  ( time timeout 1500 $PYT tests/test_hot_slices.py tests/test_hip_feat.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -6 $OUT/tests.txt | cut -c1-300
+  ;;
+r6g)
+  # hot slices after the all-or-none rule and with the in-flight bound restored: suites, the gate sweep, C3 at the new defaults + profile
+  ( time timeout 1500 $PYT tests/test_hot_slices.py tests/test_hip_feat.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -4 $OUT/tests.txt | cut -c1-300
+  timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "default-k128-128k:X=1" "k128-32k:HOT_K=128,HOT_CHUNK=32768" "k64-128k:HOT_K=64,HOT_CHUNK=131072" "k256-128k:HOT_K=256,HOT_CHUNK=131072" 2>&1 | tail -20
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 5 --warmup 2 --config c3"
+  timeout 300 python3 bench.py $S3 > $OUT/c3.json 2> $OUT/c3.err; python3 -c "
+import json; d=json.load(open('$OUT/c3.json')); r=d['roofline']; print('c3 %.2f M/s frac %.3f steady %.2f  %s' % (d['value']/1e6, r['frac'], d['config'].get('steady_state',{}).get('value',0)/1e6, r['kernel']))"
+  TRACE_ONLY=1 PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
+  head -12 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
