@@ -179,6 +179,11 @@ int lfm_host_checksum_u32(const uint32_t *p, int64_t n, uint64_t *out);
  * of RandomState.get_state(), both updated in place -- bit-identical to numpy, values and stream position. */
 int lfm_host_mt19937_table(uint32_t *key, int32_t *pos, float *out, int64_t n, int32_t d);
 int lfm_device_pool_stats(int64_t *reserved, int64_t *cached);
+/* Device self-test (tests): n pseudo-random adagrad cells (PYX:416-449) through the kernels' exact float64 cell and through the
+ * variant without the float64 square root and division that the hot-slice kernel runs (csrc/device.hpp: cell_math_adagrad);
+ * *mismatches = cells whose new (W, G) bit patterns differ (the variant is bit-identical by construction: 0), *fallbacks =
+ * cells for which the variant took its exact fallback (results too close to a float32 rounding boundary). */
+int lfm_selftest_adagrad_cell(int64_t n, uint32_t seed, float learning_rate, int64_t *mismatches, int64_t *fallbacks);
 
 /* ------------------------------------------------------------------------
  * One-shot epoch drivers: upload, run ONE epoch on device 0, download.

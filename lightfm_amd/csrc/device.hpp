@@ -440,6 +440,42 @@ __device__ __forceinline__ void cell_math(float oW, float oG, float oM, double w
     nW = (float)((double)nW * (1.0 + alpha * lr));
 }
 
+// The adagrad cell of cell_math (alpha = 0) WITHOUT the float64 square root and division, bit-identical by construction
+// (round 6: the float64 cell is what the LDS slice kernel is bound by, profiles/r06_membench_lds.txt).
+// lr / sqrt(G) is taken as r = fl(lr y), y = rsq(G) refined by two Newton steps (what is left is the rounding of the last
+// step and of the product: |r - fl(lr / fl(sqrt(G)))| <= 2^-50.8 |r|, the reference's own two roundings included).  The same
+// float64 operations as the reference then give t2' = fl(fl(r w) g) within 2^-49.9 |t2| of the reference's t2 and d' =
+// fl(oW - t2') within 2^-49.9 |t2| + 2^-52 |d'| of its d; D = 2^-49 |t2'| + 2^-51 |d'| bounds that with room to spare.  (float)d' equals (float)d unless a float32 rounding boundary -- the midpoint between two neighbouring
+// floats -- lies between the two, i.e. unless d' is within D of such a midpoint: checked, and only then (a few cells in
+// 10^8; also NaN, infinities, tiny values) the exact cell runs.  nG needs neither root nor quotient.
+__device__ __forceinline__ void cell_math_adagrad(float oW, float oG, double w, double g, float lr_f, float &nW, float &nG)
+{
+    const double G = (double)oG;
+    const double gw = g * w;
+    nG = (float)(G + gw * gw);
+    double y = __builtin_amdgcn_rsq(G);                        // (v_rsq_f64: ~2^-26; two steps leave rounding only)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-G * y, y, 1.0);        // 1 - G y^2
+        y = __builtin_fma(0.5 * y, e, y);                      // y (1 + e / 2)
+    }
+    const double r = (double)lr_f * y;
+    const double t2 = (r * w) * g;
+    const double d = (double)oW - t2;
+    const float m = (float)d;
+    const int mb = __float_as_int(m) & 0x7f800000;             // exponent field of m
+    const double half_ulp = (double)__int_as_float(mb - (24 << 23));  // ulp32(m) / 2 for normal m with exponent field >= 25
+    const double rho = fabs(d - (double)m);
+    const double D = 0x1p-49 * fabs(t2) + 0x1p-51 * fabs(d);
+    // (a power of two has its lower neighbour at half the spacing: the rare m = 2^k takes the exact cell as well)
+    if (mb >= (25 << 23) && mb < 0x7f800000 && (__float_as_int(m) & 0x007fffff) != 0 && (half_ulp - rho) > D) {
+        nW = m;
+    } else {
+        const double lr = (double)lr_f / sqrt(G);
+        nW = (float)((double)oW - (lr * w) * g);
+    }
+}
+
 // Publish new-old with global_atomic_add_f32: exactly the new value when nobody else
 // touched the cell in between (Hogwild otherwise).
 __device__ __forceinline__ void publish(float *p, float nv, float ov, int mode = 0)

@@ -119,10 +119,11 @@ __global__ __launch_bounds__(512) void hot_slice_kernel(HotArgs a)
                 if (p0 + k < nj) {
                     float2 *cell = cells + (size_t)slot * width + c;
                     const float2 o = *cell;
-                    float nW, nG, nM;
-                    double lr;
-                    // PYX:602-638: gradient = g_job * x[component]; bias cells (PYX:571-599): gradient = g_job
-                    cell_math(o.x, o.y, 0.0f, (double)w, bias ? gj : gj * (double)cx, h, 0.0, nW, nG, nM, lr);
+                    float nW, nG;
+                    // PYX:602-638: gradient = g_job * x[component]; bias cells (PYX:571-599): gradient = g_job.
+                    // (device.hpp: cell_math_adagrad = cell_math's adagrad cell, bit for bit, without the float64 root and
+                    // quotient wherever the result cannot depend on them)
+                    cell_math_adagrad(o.x, o.y, (double)w, bias ? gj : gj * (double)cx, h.lr, nW, nG);
                     *cell = make_float2(nW, nG);
                 }
             }
@@ -148,6 +149,39 @@ __global__ __launch_bounds__(512) void hot_slice_kernel(HotArgs a)
     }
 }
 
+// Self-test of cell_math_adagrad against cell_math (lfm_selftest_adagrad_cell): pseudo-random cells over the ranges training
+// produces and beyond -- W in +-[2^-20, 2^4], G in [2^-10, 2^30], weights 1 and (0.1, 2), gradients +-[2^-30, 2^7] -- counted:
+// out[0] = cells whose (nW, nG) bit patterns differ (must be 0), out[1] = cells that took the exact fallback.
+__global__ void selftest_adagrad_kernel(int64_t n, uint32_t seed, float lr_f, unsigned long long *out)
+{
+    unsigned long long bad = 0, slow = 0;
+    const Hyper h{0, lr_f, 0.95f, 1e-6f};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t s = position_seed(seed, (uint64_t)i);
+        auto next = [&]() { s = lcg(s); return (s >> 8) * (1.0f / 16777216.0f); };  // [0, 1)
+        const float oW = (next() < 0.5f ? -1.0f : 1.0f) * exp2f(-20.0f + 24.0f * next()) * (1.0f + next());
+        const float oG = exp2f(-10.0f + 40.0f * next() * next()) * (1.0f + next());
+        const double w = next() < 0.5f ? 1.0 : (double)(0.1f + 1.9f * next());
+        const double g = (double)((next() < 0.5f ? -1.0f : 1.0f) * exp2f(-30.0f + 37.0f * next()) * (1.0f + next())) * (double)(0.5f + next());
+        float nW, nG, nM, fW, fG;
+        double lr;
+        cell_math(oW, oG, 0.0f, w, g, h, 0.0, nW, nG, nM, lr);
+        cell_math_adagrad(oW, oG, w, g, lr_f, fW, fG);
+        if (__float_as_int(nW) != __float_as_int(fW) || __float_as_int(nG) != __float_as_int(fG)) ++bad;
+        // the fallback's condition, restated
+        const double G = (double)oG;
+        double y = __builtin_amdgcn_rsq(G);
+        for (int it = 0; it < 2; ++it) y = __builtin_fma(0.5 * y, __builtin_fma(-G * y, y, 1.0), y);
+        const double t2 = (((double)lr_f * y) * w) * g, d = (double)oW - t2;
+        const float m = (float)d;
+        const int mb = __float_as_int(m) & 0x7f800000;
+        const double hu = (double)__int_as_float(mb - (24 << 23));
+        if (!(mb >= (25 << 23) && mb < 0x7f800000 && (__float_as_int(m) & 0x007fffff) != 0 && (hu - fabs(d - (double)m)) > 0x1p-49 * fabs(t2) + 0x1p-51 * fabs(d))) ++slow;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (slow) atomicAdd(out + 1, slow);
+}
+
 // occurrences of every column of a CSR (the session derives the hot set from them)
 __global__ void column_count_kernel(const int32_t *indices, int64_t nnz, int32_t cols, int32_t *counts)
 {
@@ -158,6 +192,12 @@ __global__ void column_count_kernel(const int32_t *indices, int64_t nnz, int32_t
 }
 
 }  // namespace
+
+hipError_t launch_selftest_adagrad(int64_t n, uint32_t seed, float lr, unsigned long long *out, hipStream_t st)
+{
+    selftest_adagrad_kernel<<<2048, 256, 0, st>>>(n, seed, lr, out);
+    return hipGetLastError();
+}
 
 int hot_slice_components(int hot_n, int d)
 {

@@ -853,6 +853,23 @@ extern "C" int lfm_session_create_scoring(lfm_session **out, int device, const l
     return create_session(out, device, model, item_features, user_features, true);
 }
 
+extern "C" int lfm_selftest_adagrad_cell(int64_t n, uint32_t seed, float learning_rate, int64_t *mismatches, int64_t *fallbacks)
+{
+    if (n < 0 || !mismatches || !fallbacks) return fail(LFM_EINVAL, "bad self-test arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LFM_ENODEV, "no HIP device");
+    HIP_TRY(hipSetDevice(0));
+    DBuf<unsigned long long> out;
+    LFM_TRY(out.alloc(2));
+    HIP_TRY(hipMemset(out.p, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(launch_selftest_adagrad(n, seed, learning_rate, out.p, nullptr));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    *mismatches = (int64_t)h[0];
+    *fallbacks = (int64_t)h[1];
+    return LFM_OK;
+}
+
 extern "C" int lfm_session_set_features(lfm_session *s, const lfm_csr *item_features, const lfm_csr *user_features)
 {
     if (!s) return fail(LFM_EINVAL, "null session");
@@ -2362,6 +2379,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const int64_t hot_chunk_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_CHUNK"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 64 ? v : 131072); }();
     const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 128); }();
     const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
+    const int64_t hot_floor_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_FLOOR"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
     bool use_hot = false;
     if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
         !s->adadelta && s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
@@ -2496,7 +2514,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (reg) len = std::min<int64_t>(len, reg_len_cap);
             if (use_hot) {
                 const int64_t hist = history0 + (begin - seg_begin);
-                const int64_t hot_len = opts->ramp_k < 0 ? hot_chunk_env : std::min<int64_t>(hot_chunk_env, std::max<int64_t>(256, hist / hot_k_env));
+                // (floor: what the in-flight ramp itself starts from -- at history 0 every interaction is a maximum-loss step, and
+                // a launch of 256 positions against frozen hot rows cost the hybrid WARP gate 0.0035 whatever hot_k was)
+                const int64_t hot_len = opts->ramp_k < 0 ? hot_chunk_env : std::min<int64_t>(hot_chunk_env, std::max<int64_t>(hot_floor_env, hist / hot_k_env));
                 len = std::min<int64_t>(len, hot_len);
             }
             // ... and the FIRST regularised launch of a session has no measured rate to extrapolate with (reg_live is

@@ -902,6 +902,23 @@ import json; d=json.load(open('$OUT/c3.json')); r=d['roofline']; print('c3 %.2f 
   TRACE_ONLY=1 PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
   head -12 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
   ;;
+r6h)
+  # hot slices: the floor of the record-length ramp (8 = the in-flight ramp's own start) on the WARP / k-OS hybrid gates
+  SWEEP_PROBLEMS=warp-200tags-d64,kos-100tags-d64 timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "floor8-k128:X=1" "floor8-k32:HOT_K=32" "floor64-k128:HOT_FLOOR=64" "floor256-k128:HOT_FLOOR=256" "floor8-k128-rep8:HOT_REPLICAS=8" 2>&1 | tail -20
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 5 --warmup 2 --config c3"
+  timeout 300 python3 bench.py $S3 > $OUT/c3.json 2> $OUT/c3.err; python3 -c "
+import json; d=json.load(open('$OUT/c3.json')); r=d['roofline']; print('c3 %.2f M/s frac %.3f steady %.2f  %s' % (d['value']/1e6, r['frac'], d['config'].get('steady_state',{}).get('value',0)/1e6, r['kernel']))"
+  ;;
+r6i)
+  # the adagrad cell without float64 root / quotient: self-test + hot suites, C3 with it (hot_slice_kernel), then the whole GPU suite
+  ( time timeout 1500 $PYT tests/test_hot_slices.py -m gpu -x -q -s ) > $OUT/hot.txt 2>&1; grep -aE "mismatches|passed|failed|real" $OUT/hot.txt
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 5 --warmup 2 --config c3"
+  timeout 300 python3 bench.py $S3 > $OUT/c3.json 2> $OUT/c3.err; python3 -c "
+import json; d=json.load(open('$OUT/c3.json')); r=d['roofline']; print('c3 %.2f M/s frac %.3f steady %.2f  %s' % (d['value']/1e6, r['frac'], d['config'].get('steady_state',{}).get('value',0)/1e6, r['kernel']))"
+  TRACE_ONLY=1 PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
+  head -6 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
+  ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -5 $OUT/suite.txt | cut -c1-300
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
