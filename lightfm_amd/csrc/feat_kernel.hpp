@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                             float nW, nG, nM;
                             double lr;
                             const double gcell = gc * (double)x, al = st_ ? alpha_u : alpha_i;
-                            cell_math(oW, oG, oM, wt, gcell, h, al, nW, nG, nM, lr);
+                            if constexpr (!ADA && !REG) cell_math_adagrad(oW, oG, wt, gcell, h.lr, nW, nG);  // (= cell_math, bit for bit)
+                            else cell_math(oW, oG, oM, wt, gcell, h, al, nW, nG, nM, lr);
                             if constexpr (ADA) {
                                 // (the moving averages by compare-and-swap: the learning rate that counts is the one of
                                 // the value actually replaced)
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                 float nW, nG, nM;
                 double lr;
                 const double alb = e.eside ? alpha_u : alpha_i;
-                cell_math(obW, obG, obM, (double)e.w, gb, h, alb, nW, nG, nM, lr);
+                if constexpr (!ADA && !REG) cell_math_adagrad(obW, obG, (double)e.w, gb, h.lr, nW, nG);
+                else cell_math(obW, obG, obM, (double)e.w, gb, h, alb, nW, nG, nM, lr);
                 if (mine) {
                     if constexpr (ADA) {
                         if (um == 0) lr = publish_adadelta(bp, bgp, bmp, obW, obG, obM, (double)e.w, gb, h, alb);

@@ -320,3 +320,41 @@ def test_concurrent_predict_with_different_feature_matrices(fitted):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_resident_train_matrix_is_revalidated_between_calls():
+    """predict_ranks keeps the train matrix of the last call on the scoring session (csrc/session.hip: train_keep) and
+    re-validates it with a position-sensitive checksum of its index arrays: the same matrix again, the same matrix with
+    two entries of a row swapped for other columns IN PLACE, a different matrix of the same shape and nnz, and no train
+    matrix at all must each give the ranks of a session that has never seen another one."""
+    from lightfm_amd import LightFM, synthetic
+    nu, ni = 3000, 2500
+    data = synthetic.make_interactions(nu, ni, 260_000, seed=9)
+    train, test = synthetic.split_off_test(data, data.nnz - 20_000, seed=3)
+    train_a = train.tocsr().astype(np.float32)
+    train_a.sort_indices()
+    assert train_a.nnz >= (1 << 16), "the matrix must be large enough to be kept"
+    test = test.tocsr().astype(np.float32)
+    model = LightFM(loss="warp", no_components=32, random_state=2).fit(train, epochs=2)
+
+    def fresh(tr):
+        return _fresh_copy(model).predict_rank(test, train_interactions=tr).toarray()
+
+    r_a = model.predict_rank(test, train_interactions=train_a).toarray()
+    np.testing.assert_array_equal(r_a, fresh(train_a))
+    np.testing.assert_array_equal(model.predict_rank(test, train_interactions=train_a).toarray(), r_a)  # kept and reused
+    # in place: user 5 loses two train positives and gains two others (same nnz, same indptr)
+    train_b = train_a.copy()
+    lo, hi = train_b.indptr[5], train_b.indptr[5 + 1]
+    assert hi - lo >= 4
+    free = np.setdiff1d(np.arange(ni), np.union1d(train_b.indices[lo:hi], test[5].indices))[:2]
+    row = np.sort(np.concatenate([train_b.indices[lo + 2:hi], free])).astype(np.int32)
+    train_b.indices[lo:hi] = row
+    r_b = model.predict_rank(test, train_interactions=train_b).toarray()
+    np.testing.assert_array_equal(r_b, fresh(train_b))
+    assert not np.array_equal(r_b[5], r_a[5]) and np.array_equal(r_b[6], r_a[6])
+    # the same arrays edited IN PLACE between two calls
+    train_b.indices[lo:hi] = train_a.indices[lo:hi]
+    np.testing.assert_array_equal(model.predict_rank(test, train_interactions=train_b).toarray(), r_a)
+    # no train matrix
+    np.testing.assert_array_equal(model.predict_rank(test).toarray(), _fresh_copy(model).predict_rank(test).toarray())

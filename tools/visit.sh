@@ -919,6 +919,24 @@ import json; d=json.load(open('$OUT/c3.json')); r=d['roofline']; print('c3 %.2f 
   head -6 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -5 $OUT/suite.txt | cut -c1-300
   ;;
+r6j)
+  # the adagrad cell without float64 root / quotient in the tile and row-stream kernels: exactness suites, then A/B against the build
+  # before it (lightfm_amd/_lib_before: the hot-slice kernel has it in both) on c2 / c4shard / c3 / c5shard
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_hip_feat.py tests/test_hot_slices.py tests/test_baseline_shapes.py tests/test_evaluation_gpu.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -4 $OUT/tests.txt | cut -c1-300
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5"
+  for i in 1 2; do for cfg in "c2 --steps 20 --warmup 5" "c4shard --steps 6 --warmup 2" "c3 --steps 4 --warmup 2" "c5shard --steps 2 --warmup 1 --scale 0.25"; do for lib in _lib _lib_before; do
+    name=$(echo $cfg | cut -d' ' -f1)
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 400 python3 bench.py $S --config $cfg > $OUT/${name}_${lib}_$i.json 2> $OUT/${name}_${lib}_$i.err
+    python3 - <<PY
+import json
+try:
+    d = json.load(open("$OUT/${name}_${lib}_$i.json")); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-8s %-12s run $i: %8.2f M/s  frac %.3f  launch %.3f ms | steady %8.2f M/s" % ("$name", "$lib", d["value"] / 1e6, r["frac"], r["avg_launch_ms"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  $name $lib run $i: no result:", e)
+PY
+  done; done; done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
