@@ -9,7 +9,7 @@ namespace lfm {
 // LDS of one wavefront: [stage_rows][d] staging (LDS-DMA target) + [rr][d + 4] representations
 // (+ 3 * pair_cap k-OS slots).  The budget per wavefront decides how many wavefronts a CU holds
 // (160 KiB LDS): many rows in flight per wavefront against many wavefronts.
-bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p)
+bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap)
 {
     if (d < 4 || d > 256 || (d & 3) != 0 || max_sampled < 0) return false;
     FeatPlan g;
@@ -58,6 +58,12 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
             budget = b12;
             waves_per_cu = 12;
         }
+    }
+    // (budget_cap: a caller that needs LDS room beside these wavefronts -- the hot-slice kernel running under the next
+    // launch, session.hip -- bounds the budget per wavefront)
+    if (budget_cap > 0 && budget > budget_cap) {
+        budget = budget_cap;
+        min_sr = std::min(min_sr, 6);
     }
     g.waves_per_block = (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) ? wpb_env : 1;
     const int want = std::min(64, std::max(8, 2 * (rows_hint + 1)));  // W and G rows of one update list

@@ -52,7 +52,7 @@ __global__ void hot_snapshot_kernel(HotArgs a)
 // One workgroup = one (slice, replica).  CS: components per slice (lanes per entry); the last slice (index d / CS)
 // holds the bias cells and runs with one lane per entry.
 template <int CS>
-__global__ __launch_bounds__(512) void hot_slice_kernel(HotArgs a)
+__global__ __launch_bounds__(1024) void hot_slice_kernel(HotArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float2 cells[];  // [hot_n][CS] (W, G); bias slice: [hot_n]
     const int n_comp_slices = a.d / CS;

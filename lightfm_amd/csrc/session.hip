@@ -563,8 +563,10 @@ struct lfm_session {
         DBuf<int32_t> slot;  // [n_item_feat] slot of a hot row, -1 otherwise
         DBuf<int32_t> rows;  // [n] feature row of a slot, ascending
         DBuf<float> snapW, snapG, snapb, snapbG;
-        DBuf<HotRec> rec;    // one record per position of a launch
-        DBuf<float> x;       // [positions][d]
+        DBuf<HotRec> rec[2];  // one record per position of a launch; two sets: the slice kernel of launch k runs under launch k + 1
+        DBuf<float> x[2];     // [positions][d]
+        hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};  // records written / records applied
+        bool pending[2] = {false, false};
         double share = 0.0;  // hot entries / all entries of the feature matrix
     } hot;
     double user_pair_share = -1.0;  // sum_u c_u^2 / n^2 of the uploaded COO (c_u = interactions of user u); < 0: not computed yet
@@ -629,6 +631,10 @@ struct lfm_session {
         }
         for (hipEvent_t e : shuffle_ready)
             if (e) (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; ++i) {
+            if (hot.ev_p1[i]) (void)hipEventDestroy(hot.ev_p1[i]);
+            if (hot.ev_done[i]) (void)hipEventDestroy(hot.ev_done[i]);
+        }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (comm_stream) (void)hipStreamSynchronize(comm_stream);
@@ -2386,11 +2392,31 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 128); }();
     const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
     const int64_t hot_floor_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_FLOOR"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
+    const int hot_overlap_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_OVERLAP"); return e ? atoi(e) : 1; }();
     bool use_hot = false;
     if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
         !s->adadelta && s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
         if (s->hot.state == 0) LFM_TRY(build_hot_set(s));
         use_hot = s->hot.state == 1;
+    }
+    // The slice kernel of launch k runs on the second stream UNDER launch k + 1 (the row-stream kernel is issue-bound with
+    // half of a CU's LDS, the slice kernel is float64 arithmetic on the other half): the row-stream wavefronts then take an
+    // LDS budget that leaves one slice workgroup per CU its room.  Only for full-length launches of the default plan: while
+    // the record length still ramps, and under a caller's own launch plan (the sequential parity tests), a launch's records
+    // are applied before the next launch starts.
+    bool hot_overlap = use_hot && hot_overlap_env != 0 && opts->launches_per_epoch <= 0 && !fixed_cap;
+    if (hot_overlap) {
+        const size_t slice_bytes = (size_t)s->hot.n * s->hot.cs * 2 * sizeof(float);
+        const size_t room = (size_t)156 * 1024 > slice_bytes ? (size_t)156 * 1024 - slice_bytes : 0;
+        FeatPlan tight;
+        auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
+        const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
+        const size_t cap = (room / (size_t)std::max(1, fplan.waves_per_cu)) & ~(size_t)15;
+        if (cap >= 4096 && feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &tight, cap) &&
+            tight.waves_per_cu == fplan.waves_per_cu && tight.smem * (size_t)tight.waves_per_cu / (size_t)tight.waves_per_block + slice_bytes <= (size_t)158 * 1024)
+            fplan = tight;
+        else
+            hot_overlap = false;
     }
     // (the steady-state bound on the interactions in flight of a model with shared rows -- shared_cap above -- stays what it
     // is: relaxing it because the hot rows left the atomic path cost the hybrid WARP / k-OS gates 0.002-0.003 precision@10
@@ -2587,23 +2613,45 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             }
             else if (use_feat && use_hot) {
                 lfm_session::HotSet &h = s->hot;
-                LFM_TRY(h.rec.reserve((size_t)len));
-                LFM_TRY(h.x.reserve((size_t)len * (size_t)s->d));
-                HIP_TRY(hipMemsetAsync(h.rec.p, 0xff, (size_t)len * sizeof(HotRec), lst));  // n_total = -1: nothing to apply
+                const int par = n_launches & 1;
+                // this launch's records may run under the next launch (hot_overlap) once the record length has ramped up
+                const bool under_next = hot_overlap && len >= 8192;
+                if (under_next && !s->stream2) {
+                    HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+                }
+                for (int i = 0; i < 2; ++i) {
+                    if (!h.ev_p1[i]) HIP_TRY(hipEventCreateWithFlags(&h.ev_p1[i], hipEventDisableTiming));
+                    if (!h.ev_done[i]) HIP_TRY(hipEventCreateWithFlags(&h.ev_done[i], hipEventDisableTiming));
+                }
+                // the record set of this parity is free once the slice kernel that read it last has finished; a launch whose
+                // records are applied in line waits for EVERYTHING still running on the second stream
+                for (int i = 0; i < 2; ++i) {
+                    if (h.pending[i] && (i == par || !under_next)) {
+                        HIP_TRY(hipStreamWaitEvent(lst, h.ev_done[i], 0));
+                        h.pending[i] = false;
+                    }
+                }
+                LFM_TRY(h.rec[par].reserve((size_t)len));
+                LFM_TRY(h.x[par].reserve((size_t)len * (size_t)s->d));
+                HIP_TRY(hipMemsetAsync(h.rec[par].p, 0xff, (size_t)len * sizeof(HotRec), lst));  // n_total = -1: nothing to apply
                 a.hot_slot = h.slot.p;
-                a.hot_rec = h.rec.p;
-                a.hot_x = h.x.p;
+                a.hot_rec = h.rec[par].p;
+                a.hot_x = h.x[par].p;
                 HIP_TRY(launch_fit_feat_hot(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used));
                 HotArgs ha;
-                ha.rec = h.rec.p;
-                ha.x = h.x.p;
+                ha.rec = h.rec[par].p;
+                ha.x = h.x[par].p;
                 ha.n_rec = len;
                 ha.d = s->d;
                 ha.hot_n = h.n;
-                // replicas of a slice: two workgroups per CU over all slices; a short launch takes fewer (one record per
-                // launch: ONE replica, the sequential result)
+                // replicas of a slice: the chip's workgroup slots over all slices -- two workgroups of 8 wavefronts per CU
+                // when the slice kernel has the chip to itself, one of 16 when it runs under the next launch; a short launch
+                // takes fewer (one record per launch: ONE replica, the sequential result)
                 const int n_slices = s->d / h.cs + 1;
-                int n_rep = hot_rep_env > 0 ? hot_rep_env : std::max(1, (2 * s->cus) / n_slices);
+                const int per_cu = under_next ? 1 : 2;
+                int n_rep = hot_rep_env > 0 ? hot_rep_env : std::max(1, (per_cu * s->cus) / n_slices);
                 n_rep = (int)std::max<int64_t>(1, std::min<int64_t>(n_rep, len / 64));
                 ha.n_rep = n_rep;
                 ha.rows = h.rows.p;
@@ -2618,7 +2666,17 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 ha.lr = s->lr;
                 ha.rho = s->rho;
                 ha.eps = s->eps;
-                HIP_TRY(launch_hot_slices(ha, h.cs, n_rep > 1 ? 512 : 64, lst));
+                const int threads = n_rep > 1 ? (under_next ? 1024 : 512) : 64;
+                if (under_next) {
+                    HIP_TRY(hipEventRecord(h.ev_p1[par], lst));
+                    HIP_TRY(hipStreamWaitEvent(s->stream2, h.ev_p1[par], 0));
+                    HIP_TRY(launch_hot_slices(ha, h.cs, threads, s->stream2));
+                    HIP_TRY(hipEventRecord(h.ev_done[par], s->stream2));
+                    h.pending[par] = true;
+                    used_second_stream = true;
+                } else {
+                    HIP_TRY(launch_hot_slices(ha, h.cs, threads, lst));
+                }
                 plan_flags |= 32;
             }
             else if (use_feat && s->adadelta) HIP_TRY(launch_fit_feat_ada(loss, a, grid, wpb * WAVE, lsmem, lst, s->cus, &grid_used));
@@ -2639,6 +2697,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             ++n_launches;
         }
         tile_ng_used = ng_used;
+        for (int i = 0; i < 2; ++i) {  // slice kernels still running under the last launch (hot_overlap)
+            if (s->hot.pending[i]) {
+                HIP_TRY(hipStreamWaitEvent(s->stream, s->hot.ev_done[i], 0));
+                s->hot.pending[i] = false;
+            }
+        }
         if (forked) {  // the second stream joins before anything else of this session runs
             HIP_TRY(hipEventRecord(s->ev_join, s->stream2));
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));

@@ -376,11 +376,14 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
                     const float Ur = cU[gg], Pr = cP[gg], Nr = cN[gg];
                     const double u = (double)Ur;
                     const double df = (double)__fsub_rn(Nr, Pr);  // float32 subtraction, PYX:634-635
-                    float nWP, nGP, nWN, nGN, nWU, nGU;
-                    // (device.hpp: cell_math's adagrad cell, bit for bit, without the float64 root and quotient)
-                    cell_math_adagrad(Pr, gP[gg], 1.0, -loss * u, h.lr, nWP, nGP);
-                    cell_math_adagrad(Nr, gN[gg], 1.0, loss * u, h.lr, nWN, nGN);
-                    cell_math_adagrad(Ur, gU[gg], 1.0, loss * df, h.lr, nWU, nGU);
+                    float nWP, nGP, nWN, nGN, nWU, nGU, nM;
+                    double lr;
+                    // (the float64 cell as it stands: cell_math_adagrad -- the same cell without root and quotient, which the
+                    // row-stream and slice kernels run -- measured -1 % here; this kernel waits for memory, not for its ALUs:
+                    // profiles/r06_fast_cell_ab.txt)
+                    cell_math(Pr, gP[gg], 0.0f, 1.0, -loss * u, h, 0.0, nWP, nGP, nM, lr);
+                    cell_math(Nr, gN[gg], 0.0f, 1.0, loss * u, h, 0.0, nWN, nGN, nM, lr);
+                    cell_math(Ur, gU[gg], 0.0f, 1.0, loss * df, h, 0.0, nWU, nGU, nM, lr);
                     asm volatile("" : "+v"(nWP), "+v"(nGP), "+v"(nWN), "+v"(nGN), "+v"(nWU), "+v"(nGU));
                     if (lane < d) {
                         // publication: new - old by global_atomic_add_f32, unconditionally (this variant runs update_mode
@@ -404,8 +407,9 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
             }
             // the pass's bias cells, all interactions at once
             {
-                float bnW, bnG;
-                cell_math_adagrad(obW, obG, 1.0, p == 0 ? -lossd : lossd, h.lr, bnW, bnG);
+                float bnW, bnG, bnM;
+                double blr;
+                cell_math(obW, obG, 0.0f, 1.0, p == 0 ? -lossd : lossd, h, 0.0, bnW, bnG, bnM, blr);
                 if (bupd) {
                     float *bWp, *bGp;
                     bias_ptrs(chosen, bWp, bGp);
