@@ -517,6 +517,19 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     n_upd = counters[2] if loss != "logistic" else float(n_local) * n_epochs
     ustore = bool(int(getattr(stats[-1], "user_store", 0)))  # user rows written with plain stores (lfm_opts.user_store)
     rows_upd = ((0.0 if ustore else 1.0) + 2.0 * f_i) if loss != "logistic" else ((0.0 if ustore else 1.0) + f_i)
+    hot_slices = bool(int(getattr(stats[-1], "plan_flags", 0)) & 32)
+    if hot_slices:
+        # the shared rows (fit.hot[0]: the same rule as the session's hot set) are accumulated in LDS slices and published once
+        # per launch and slice replica (csrc/hot_slices.hip): what still goes through the float-atomic unit per interaction
+        # is the rest of the rows
+        n_hot = len(fit.hot[0])
+        csc = feats.tocsc() if feats is not None else None
+        hot_share = float(np.diff(csc.indptr)[fit.hot[0]].sum()) / max(1, csc.nnz) if csc is not None and n_hot else 0.0
+        f_rest = f_i * (1.0 - hot_share)
+        rows_upd = ((0.0 if ustore else 1.0) + 2.0 * f_rest) if loss != "logistic" else ((0.0 if ustore else 1.0) + f_rest)
+        roofline["hot_slices"] = {"hot_rows": n_hot, "share_of_feature_entries": hot_share,
+                                  "kernels": "fit_feat_kernel<..., HOT> writes one 256-B record + the user representation per "
+                                             "interaction; hot_slice_kernel<8> applies them to LDS slices between launches"}
     atomics = float(n_upd) * rows_upd * (d + 1) * 2.0
     roofline["user_rows_by_plain_stores"] = ustore
     roofline["atomic_unit"] = {"achieved": atomics / kernel_s / 1e9, "peak": ATOMIC_PEAK_GOPS, "unit": "G float atomics/s",

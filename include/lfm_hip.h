@@ -90,8 +90,8 @@ typedef struct lfm_opts {
                                        is lost (DESIGN.md "Hogwild at GPU width")              */
     int32_t feat_kernel;        /* parallel mode, models the lane-group tile kernel does not cover
                                    (feature CSRs, BPR, k-OS, logistic): 0 = auto (the pipelined
-                                   row-stream kernels, csrc/feat_kernel.hpp, for adagrad models with
-                                   d <= 128, d % 4 == 0, any alpha), 1 = force the generic kernels, 2 = row-stream kernels
+                                   row-stream kernels, csrc/feat_kernel.hpp: adagrad up to d = 256, adadelta up to
+                                   d = 128, any alpha), 1 = force the generic kernels, 2 = row-stream kernels
                                    instrumented with per-phase cycle counters (BPR / k-OS, d > 64) */
     int32_t warp_kernel;        /* parallel-mode WARP with identity features (any alpha; adadelta only
                                    without regularisation): 0 = auto (the lane-group tile kernel,
@@ -107,7 +107,9 @@ typedef struct lfm_opts {
                                    (default: two streams alternately, so that a launch's draining tail is
                                    filled by the next launch's workgroups); bit 8 (256): tile kernel without the
                                    Bloom pre-filter of in_positives; bit 9 (512): the filter probed for every
-                                   candidate with its row instead of for the violators after the scoring pass */
+                                   candidate with its row instead of for the violators after the scoring pass; bit 14
+                                   (16384): a hybrid model's shared feature rows stay on the float atomics instead of being
+                                   accumulated in LDS slices between launches (csrc/hot_slices.hip; `plan_flags` bit 5) */
     int64_t phase_cycles[8];    /* out, warp_kernel = 2 / feat_kernel = 2 (profiling builds): shader
                                    cycles summed over wavefronts per phase of a pass -- 0 loop
                                    head, 1 gathers, 2 scoring, 3 in_positives, 4 accumulator
@@ -135,9 +137,10 @@ typedef struct lfm_opts {
                                    full-residency launches of the tile kernel alternated between the session's
                                    two streams (see `debug` bit 7), else 1                                      */
     int32_t user_store;         /* out: 1 when the epoch wrote the USER rows of its updates with plain stores instead of float
-                                   atomics: parallel mode, identity user features, uncached tables, adagrad, a model of <= 192 MB
-                                   and >= 8 users per interaction in flight (csrc/session.hip; `debug` bit 11 = 2048 forces it for
-                                   uncached tables, bit 12 = 4096 switches it off)                                  */
+                                   atomics: parallel mode, identity user features, W and G of the user side in uncached memory,
+                                   adagrad, a model of <= 192 MB and few same-user collisions in the data -- (interactions in
+                                   flight at full residency) x sum_u c_u^2 / n^2 <= 0.3 (csrc/session.hip; `debug` bit 11 = 2048
+                                   forces it for uncached tables, bit 12 = 4096 switches it off)                    */
     int32_t tile_ahead;         /* out: 1 when the epoch's last launch ran the steady-state variant of the tile kernel
                                    with the next pass's gather issued inside the current pass (csrc/warp_tile_ahead.hpp;
                                    `debug` bit 10 = 1024 keeps the plain tile kernel)                            */

@@ -609,6 +609,12 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
         if constexpr (LOSS == LFM_LOSS_WARP_KOS_ID) return make_int4(a.user_ids[row], 0, 0, 0);
         else return a.recs[row];
     };
+    // BPR: what the NEXT position's sampling needs first is requested while the current position is worked on -- its first
+    // eight candidate negatives (PYX:1124-1125: they depend on the position's PRNG stream alone) at the top of the current
+    // iteration, its user's row bounds in the positives lookup once its record has arrived -- two dependent round trips
+    // off the chain of an interaction
+    int pre_cand = 0, pre_lo = 0, pre_hi = 0;
+    bool pre_cand_ok = false, pre_pos_ok = false;
     int64_t i = a.begin + gw;
     int4 cur = make_int4(0, 0, 0, 0);
     int row1 = 0;
@@ -626,6 +632,19 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
         row1 = row2;
         refresh(i);
         if constexpr (HOT) hrec = a.hot_rec + (i - a.begin);
+        const int cand_first = pre_cand, lo_first = pre_lo, hi_first = pre_hi;
+        const bool have_cand = pre_cand_ok, have_pos = pre_pos_ok;
+        pre_cand_ok = pre_pos_ok = false;
+        if constexpr (LOSS == LFM_LOSS_BPR_ID) {
+            if (i + nw < a.end) {
+                uint32_t sn = position_seed(base_seed, (uint64_t)(i + nw));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j <= lane) sn = lcg(sn);
+                if (lane < 8) pre_cand = a.item_ids[draw(sn) % (uint32_t)a.n];
+                pre_cand_ok = true;
+            }
+        }
 
         if constexpr (LOSS == LFM_LOSS_LOGISTIC_ID) {
             // fit_logistic, PYX:726-775
@@ -656,7 +675,11 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
             }
             uint32_t state = position_seed(base_seed, (uint64_t)i);
             // requested now, made wave-uniform where first needed (so that it travels with later loads)
-            const int lo_v = a.pos.indptr[user], hi_v = a.pos.indptr[user + 1];
+            int lo_v = lo_first, hi_v = hi_first;
+            if (!(LOSS == LFM_LOSS_BPR_ID && have_pos)) {
+                lo_v = a.pos.indptr[user];
+                hi_v = a.pos.indptr[user + 1];
+            }
 
             if constexpr (LOSS == LFM_LOSS_BPR_ID) {
                 // fit_bpr, PYX:1118-1169
@@ -668,8 +691,8 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         if (j <= lane) s = lcg(s);
-                    int cand = 0;
-                    if (lane < 8) cand = a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
+                    int cand = cand_first;  // (requested during the previous position)
+                    if (!(have_cand && draws == 0) && lane < 8) cand = a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
                     lo = uni(lo_v);
                     hi = uni(hi_v);
                     int used = 8;
@@ -689,6 +712,11 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                 c1 += (unsigned long long)draws;
                 Entries el;
                 build_reps(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, lane, 3, &el);
+                if (i + nw < a.end) {  // the next position's record has arrived by now (cur holds it since the top of the loop)
+                    pre_lo = a.pos.indptr[cur.x];
+                    pre_hi = a.pos.indptr[cur.x + 1];
+                    pre_pos_ok = true;
+                }
                 float sc = 0.0f;
                 if (lane == 1 || lane == 2) sc = tile_dot(reps, reps + (size_t)lane * TS, d);
                 const double pp = (double)read_lanef(sc, 1), np_ = (double)read_lanef(sc, 2);

@@ -9,7 +9,8 @@ namespace lfm {
 // LDS of one wavefront: [stage_rows][d] staging (LDS-DMA target) + [rr][d + 4] representations
 // (+ 3 * pair_cap k-OS slots).  The budget per wavefront decides how many wavefronts a CU holds
 // (160 KiB LDS): many rows in flight per wavefront against many wavefronts.
-bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap)
+bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap,
+               bool few_atomics)
 {
     if (d < 4 || d > 256 || (d & 3) != 0 || max_sampled < 0) return false;
     FeatPlan g;
@@ -48,7 +49,9 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     // WARP / k-OS (not bound by the atomic unit): 12 wavefronts per CU when a twelfth of the LDS still stages >= 8 rows;
     // k-OS (held to 128 VGPRs, feat_kernel.hpp): 16 when a sixteenth still stages 6
     int waves_per_cu = 8, min_sr = 8;
-    if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID)) {
+    // (few_atomics: BPR / logistic whose shared rows are accumulated in LDS slices, session.hip: HotSet -- no longer bound by
+    // the atomic unit, they take the twelve wavefronts too: C3 80.8 -> 83.5 M/s, profiles/r06_hot_overlap_ab.txt)
+    if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID || few_atomics)) {
         const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255, b16 = (size_t)(160 * 1024 / 16);
         if (loss == LFM_LOSS_WARP_KOS_ID && b16 >= tile_bytes + 2 * WAVE * 4 + (size_t)6 * d * 4) {
             budget = b16;

@@ -75,7 +75,8 @@ struct FeatPlan {
     size_t smem;  // LDS bytes per workgroup
 };
 // rows_hint: rows of a typical update list (f_user + 2 f_item), so that one chunk covers it
-bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap = 0);
+bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap = 0,
+               bool few_atomics = false);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used = nullptr, bool timed = false);
 // feat_kernels_ada.hip: the adadelta instantiations of the row-stream kernels (d <= 128)

@@ -2392,24 +2392,31 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const int64_t hot_k_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_K"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 128); }();
     const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
     const int64_t hot_floor_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_FLOOR"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
-    const int hot_overlap_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_OVERLAP"); return e ? atoi(e) : 1; }();
+    const int hot_overlap_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_OVERLAP"); return e ? atoi(e) : 0; }();
     bool use_hot = false;
     if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
         !s->adadelta && s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
         if (s->hot.state == 0) LFM_TRY(build_hot_set(s));
         use_hot = s->hot.state == 1;
     }
-    // The slice kernel of launch k runs on the second stream UNDER launch k + 1 (the row-stream kernel is issue-bound with
-    // half of a CU's LDS, the slice kernel is float64 arithmetic on the other half): the row-stream wavefronts then take an
-    // LDS budget that leaves one slice workgroup per CU its room.  Only for full-length launches of the default plan: while
-    // the record length still ramps, and under a caller's own launch plan (the sequential parity tests), a launch's records
-    // are applied before the next launch starts.
+    // LIGHTFM_AMD_HOT_OVERLAP=1 (off by default): the slice kernel of launch k on the second stream UNDER launch k + 1, the
+    // row-stream wavefronts on an LDS budget that leaves one slice workgroup per CU its room.  Built and measured: 77.3
+    // against 80.8 M/s on C3 (the row-stream kernel is issue-bound, the slice kernel ALU-bound: side by side they take each
+    // other's issue slots), precision@10 unchanged (profiles/r06_hot_overlap_ab.txt).  Only for full-length launches of the
+    // default plan: while the record length still ramps, and under a caller's own launch plan (the sequential parity
+    // tests), a launch's records are applied before the next launch starts.
     bool hot_overlap = use_hot && hot_overlap_env != 0 && opts->launches_per_epoch <= 0 && !fixed_cap;
+    auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
+    if (use_hot && !hot_overlap) {
+        // without their shared rows BPR / logistic are not bound by the atomic unit any more: the residency of WARP / k-OS
+        FeatPlan wide;
+        const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
+        if (feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &wide, 0, true)) fplan = wide;
+    }
     if (hot_overlap) {
         const size_t slice_bytes = (size_t)s->hot.n * s->hot.cs * 2 * sizeof(float);
         const size_t room = (size_t)156 * 1024 > slice_bytes ? (size_t)156 * 1024 - slice_bytes : 0;
         FeatPlan tight;
-        auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
         const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
         const size_t cap = (room / (size_t)std::max(1, fplan.waves_per_cu)) & ~(size_t)15;
         if (cap >= 4096 && feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &tight, cap) &&
@@ -2666,7 +2673,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 ha.lr = s->lr;
                 ha.rho = s->rho;
                 ha.eps = s->eps;
-                const int threads = n_rep > 1 ? (under_next ? 1024 : 512) : 64;
+                static const int hot_threads_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
+                const int threads = n_rep > 1 ? (hot_threads_env ? hot_threads_env : (under_next ? 1024 : 512)) : 64;
                 if (under_next) {
                     HIP_TRY(hipEventRecord(h.ev_p1[par], lst));
                     HIP_TRY(hipStreamWaitEvent(s->stream2, h.ev_p1[par], 0));

@@ -956,6 +956,26 @@ PY
   done; done
   timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "inline:HOT_OVERLAP=0" "overlap:X=1" "overlap-k256:HOT_K=256" 2>&1 | tail -16
   ;;
+r6l)
+  # C3: 12 row-stream wavefronts per CU with the hot set, BPR candidate / positives-range prefetch; slice-kernel workgroup size; then C5 and the suites
+  ( time timeout 1500 $PYT tests/test_hot_slices.py tests/test_hip_feat.py tests/test_baseline_shapes.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-30s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 5 --warmup 2 --config c3"
+  for i in 1 2; do for arm in "default:X=1" "threads1024:LIGHTFM_AMD_HOT_THREADS=1024" "threads256:LIGHTFM_AMD_HOT_THREADS=256" "rep45:LIGHTFM_AMD_HOT_REPLICAS=45" "chunk256k:LIGHTFM_AMD_HOT_CHUNK=262144" "off:LIGHTFM_AMD_HOT_SLICES=0"; do
+    IFS=: read name envs <<< "$arm"
+    env $envs timeout 300 python3 bench.py $S3 > $OUT/c3_${name}_$i.json 2> $OUT/c3_${name}_$i.err; line "c3 $name run $i" $OUT/c3_${name}_$i.json
+  done; done
+  TRACE_ONLY=1 PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
+  head -6 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
