@@ -2674,7 +2674,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 ha.rho = s->rho;
                 ha.eps = s->eps;
                 static const int hot_threads_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
-                const int threads = n_rep > 1 ? (hot_threads_env ? hot_threads_env : (under_next ? 1024 : 512)) : 64;
+                // (1 024 threads: 32 wavefronts per CU hide the record loads -- C3 92.0 -> 99.9 M/s against 512, 76 at 256;
+                // profiles/r06_c3_tuning.txt)
+                const int threads = n_rep > 1 ? (hot_threads_env ? hot_threads_env : 1024) : 64;
                 if (under_next) {
                     HIP_TRY(hipEventRecord(h.ev_p1[par], lst));
                     HIP_TRY(hipStreamWaitEvent(s->stream2, h.ev_p1[par], 0));

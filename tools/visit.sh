@@ -976,6 +976,29 @@ PY
   TRACE_ONLY=1 PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
   head -6 $R/profiles/r06_c3_kernel_stats.txt | cut -c1-200
   ;;
+r6m)
+  # slice kernel: records prefetched two deep (_lib) against one deep (_lib_d1), both with 1 024-thread workgroups; record length 128 / 256 Ki;
+  # then the hot suites and the hybrid gates on the shipped defaults, full-size C3 quality at both record lengths
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-30s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 5 --warmup 2 --config c3"
+  for i in 1 2; do for arm in "depth2:_lib:X=1" "depth1:_lib_d1:X=1" "depth2-256k:_lib:LIGHTFM_AMD_HOT_CHUNK=262144" "depth2-rep20:_lib:LIGHTFM_AMD_HOT_REPLICAS=20"; do
+    IFS=: read name lib envs <<< "$arm"
+    env $envs LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 300 python3 bench.py $S3 > $OUT/c3_${name}_$i.json 2> $OUT/c3_${name}_$i.err; line "c3 $name run $i" $OUT/c3_${name}_$i.json
+  done; done
+  ( time timeout 1500 $PYT tests/test_hot_slices.py tests/test_hip_feat.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "shipped:X=1" 2>&1 | tail -10
+  for envs in "LIGHTFM_AMD_HOT_CHUNK=131072" "LIGHTFM_AMD_HOT_CHUNK=262144"; do
+    env $envs timeout 400 python3 tools/quality_c3_full.py 0 2>&1 | tail -1
+  done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
