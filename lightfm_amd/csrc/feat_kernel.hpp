@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
         refresh(i);
         if constexpr (HOT) hrec = a.hot_rec + (i - a.begin);
         const int cand_first = pre_cand, lo_first = pre_lo, hi_first = pre_hi;
-        const bool have_cand = pre_cand_ok, have_pos = pre_pos_ok;
+        const bool have_cand = pre_cand_ok, have_bounds = pre_pos_ok;
         pre_cand_ok = pre_pos_ok = false;
         if constexpr (LOSS == LFM_LOSS_BPR_ID) {
             if (i + nw < a.end) {
@@ -676,10 +676,19 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
             uint32_t state = position_seed(base_seed, (uint64_t)i);
             // requested now, made wave-uniform where first needed (so that it travels with later loads)
             int lo_v = lo_first, hi_v = hi_first;
-            if (!(LOSS == LFM_LOSS_BPR_ID && have_pos)) {
+            if (!have_bounds) {
                 lo_v = a.pos.indptr[user];
                 hi_v = a.pos.indptr[user + 1];
             }
+            // (every loss with a positives lookup: the NEXT position's row bounds are requested after this position's first
+            // representation pass, by when its record has arrived)
+            auto prefetch_next_bounds = [&]() {
+                if (i + nw < a.end && !pre_pos_ok) {
+                    pre_lo = a.pos.indptr[cur.x];
+                    pre_hi = a.pos.indptr[cur.x + 1];
+                    pre_pos_ok = true;
+                }
+            };
 
             if constexpr (LOSS == LFM_LOSS_BPR_ID) {
                 // fit_bpr, PYX:1118-1169
@@ -712,11 +721,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                 c1 += (unsigned long long)draws;
                 Entries el;
                 build_reps(lane == 0 ? user : (lane == 1 ? item : neg), lane == 0 ? 1 : 0, lane, 3, &el);
-                if (i + nw < a.end) {  // the next position's record has arrived by now (cur holds it since the top of the loop)
-                    pre_lo = a.pos.indptr[cur.x];
-                    pre_hi = a.pos.indptr[cur.x + 1];
-                    pre_pos_ok = true;
-                }
+                prefetch_next_bounds();  // the next position's record has arrived by now (cur holds it since the top of the loop)
                 float sc = 0.0f;
                 if (lane == 1 || lane == 2) sc = tile_dot(reps, reps + (size_t)lane * TS, d);
                 const double pp = (double)read_lanef(sc, 1), np_ = (double)read_lanef(sc, 2);
@@ -763,6 +768,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                         it = a.pos.indices[lo + (int)(draw(s) % (uint32_t)(hi - lo))];
                     state = (uint32_t)read_lane((int)s, no_pos);
                     build_reps(lane == 0 ? user : it, lane == 0 ? 1 : 0, lane, 1 + no_pos, nullptr);
+                    prefetch_next_bounds();
                     if (lane >= 1 && lane <= no_pos) {
                         pair_idx[lane - 1] = it;
                         pair_val[lane - 1] = tile_dot(reps, reps + (size_t)lane * TS, d);
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                         const int cand = __shfl(myneg, max(lane - 2, 0), WAVE);
                         build_reps(lane == 0 ? user : (lane == 1 ? pos_item : cand), lane == 0 ? 1 : 0,
                                    lane < 2 ? lane : cand_base + lane - 2, 2 + nb, nullptr);
+                        prefetch_next_bounds();
                         lo = uni(lo_v);
                         hi = uni(hi_v);
                     } else {

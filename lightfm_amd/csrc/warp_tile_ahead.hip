@@ -1,22 +1,35 @@
 // warp_tile_ahead.hip -- instantiation and launcher of the gather-ahead variant of the lane-group tile
 // kernel (warp_tile_ahead.hpp): max_sampled = 10 candidates in one batch, the shape every BASELINE
 // configuration trains with (LightFM's default max_sampled).
+#include <stdlib.h>
+
 #include "warp_tile_ahead.hpp"
 
 namespace lfm {
+
+// rows of up to 16 floats take the VEC = 1 instantiation (LIGHTFM_AMD_TILE_NARROW=0: the 64-float layout for every width)
+static bool narrow_rows_enabled()
+{
+    static const bool on = [] { const char *e = getenv("LIGHTFM_AMD_TILE_NARROW"); return !e || atoi(e) != 0; }();
+    return on;
+}
 
 // 0 if (d, max_sampled, first batch) is outside the variant's scope, else its LDS bytes per workgroup
 size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch)
 {
     if (d < 4 || d > 64 || (d & 3) != 0 || max_sampled != 10 || first_batch != 10) return 0;
-    return tile_ahead_smem<10>();
+    return d <= 16 && narrow_rows_enabled() ? tile_ahead_smem<10, 1>() : tile_ahead_smem<10>();
 }
 
 hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used)
 {
     void (*kernel)(FitArgs) = a.shards.n > 0 ? fit_warp_tile_ahead_kernel<10, true> : fit_warp_tile_ahead_kernel<10, false>;
     if (a.shards.n == 0 && a.user_store) kernel = fit_warp_tile_ahead_kernel<10, false, true>;  // user rows by plain stores
-    const size_t smem = tile_ahead_smem<10>();
+    size_t smem = tile_ahead_smem<10>();
+    if (a.shards.n == 0 && a.m.d <= 16 && narrow_rows_enabled()) {  // rows of up to 16 floats: a quarter of the LDS per interaction
+        kernel = a.user_store ? fit_warp_tile_ahead_kernel<10, false, true, 1> : fit_warp_tile_ahead_kernel<10, false, false, 1>;
+        smem = tile_ahead_smem<10, 1>();
+    }
     if (cus > 0) {
         const int per_cu = occupancy_cached(kernel, 256, smem);
         if (per_cu > 0) grid = std::min(grid, per_cu * cus);

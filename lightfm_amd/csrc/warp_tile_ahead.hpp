@@ -104,10 +104,19 @@ struct ItemAddr {
 // same user that are in flight at the same time -- the reference's own Hogwild race -- and a third of C2's float
 // atomics (2 x 64 of 390 per update) leave the atomic unit: C2 1.25 -> 1.44 G interactions/s in a one-box A/B,
 // precision@10 0.1743 against 0.1747 (8 seeds each; profiles/r05_visit_f.txt).
-template <int NBF, bool SHARDED = false, bool USTORE = false>
-__global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
+// VEC (round 6): floats of a row per lane.  4 = rows of up to 64 floats (global_load_lds_dwordx4).  1 = rows of up to 16
+// floats (global_load_lds_dword): the reference's DEFAULT width (no_components = 10: rows of 12 floats on the device) --
+// the tile of an interaction then takes a quarter of the LDS (15 KB instead of 52 KB per workgroup), so that registers,
+// not LDS, bound the residency: a kernel whose passes are chains of dependent round trips (0.83 KB per interaction: it
+// never waits for bandwidth) runs faster with every wavefront more per CU.
+#ifndef LFM_NARROW_BLOCKS
+#define LFM_NARROW_BLOCKS 4  // workgroups per CU the VEC = 1 instantiation is compiled for (5: 96 VGPRs with 20-32 B of scratch)
+#endif
+template <int NBF, bool SHARDED = false, bool USTORE = false, int VEC = 4>
+__global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 {
-    constexpr int LPR = 16, VEC = 4, NG = 4;
+    static_assert(VEC == 4 || VEC == 1, "rows of up to 64 or up to 16 floats");
+    constexpr int LPR = 16, NG = 4;
     constexpr unsigned long long GM = 0xffffull;
     static_assert(NBF >= 1 && NBF <= LPR - 1, "one batch of candidates, one per lane of a group");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -150,6 +159,10 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
     // The whole first-batch gather of one pass: straight-line, every lane takes part (the record of a
     // group past the end of the launch is zero: rows 0 are fetched and never used).  Returns the lane's
     // candidate item and its stream state.
+    auto dma_piece = [&](const float *g_, float *lds_base) {  // VEC floats per lane, memory -> LDS
+        if constexpr (VEC == 4) dma_lane_x4(g_, lds_base);
+        else dma_lane_dword(g_, lds_base);
+    };
     auto issue_gather = [&](int user, int pos, int64_t i, int &myitem, uint32_t &s) {
         const uint32_t state = position_seed(base_seed, (uint64_t)i);
         s = lcgA * state + lcgC;
@@ -157,13 +170,13 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 #pragma nounroll
         for (int gg = 0; gg < NG; ++gg) {  // (the LDS base of an instruction is M0: wave-uniform)
             float *ub = tile + UB + __builtin_amdgcn_readfirstlane(gg) * (US - LPR * VEC);
-            if (g == gg && pc) dma_lane_x4(Wu + (size_t)user * d + VEC * p, ub);
+            if (g == gg && pc) dma_piece(Wu + (size_t)user * d + VEC * p, ub);
         }
-        if (pc) dma_lane_x4(item.Wg(pos, small_items) + VEC * p, tile);  // row 0 of every group
+        if (pc) dma_piece(item.Wg(pos, small_items) + VEC * p, tile);  // row 0 of every group
 #pragma unroll
         for (int k = 1; k <= NBF; ++k) {
             const int neg = row_bcast(myitem, k);
-            if (pc) dma_lane_x4(item.Wg(neg, small_items) + VEC * p, tile + (size_t)k * KS);
+            if (pc) dma_piece(item.Wg(neg, small_items) + VEC * p, tile + (size_t)k * KS);
         }
         dma_lane_dword(item.bscore(myitem), tile + BB);
         dma_lane_dword(bu_tab + user, tile + BB + WAVE);
@@ -437,10 +450,10 @@ __global__ __launch_bounds__(256, 3) void fit_warp_tile_ahead_kernel(FitArgs a)
 }
 
 // LDS bytes per 256-thread workgroup (four wavefronts)
-template <int NBF>
+template <int NBF, int VEC = 4>
 constexpr size_t tile_ahead_smem()
 {
-    return (size_t)WAVES_PER_BLOCK * ((size_t)(NBF + 1) * (4 * WAVE + 4) + 4 * (WAVE + 4) + 2 * WAVE) * sizeof(float);
+    return (size_t)WAVES_PER_BLOCK * ((size_t)(NBF + 1) * (4 * 16 * VEC + 4) + 4 * (16 * VEC + 4) + 2 * WAVE) * sizeof(float);
 }
 
 }  // namespace lfm

@@ -999,6 +999,30 @@ PY
     env $envs timeout 400 python3 tools/quality_c3_full.py 0 2>&1 | tail -1
   done
   ;;
+r6n)
+  # the steady-state tile kernel with rows of <= 16 floats (VEC = 1: the reference's default width): parity suites, then c2 at d = 10 / 16 --
+  # 64-float layout (LIGHTFM_AMD_TILE_NARROW=0), VEC = 1 compiled for 4 (_lib) and 5 (_lib_nb5) workgroups per CU, with / without the plain-store
+  # user rows; c5shard with / without the next-position bounds prefetch (_lib_nopre)
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_hip_parity.py tests/test_baseline_shapes.py tests/test_sharded_items.py tests/test_hip_feat.py tests/test_hot_slices.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-34s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d  ustore %s | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], r.get("user_rows_by_plain_stores"), ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 10 --warmup 3 --config c2"
+  for i in 1 2; do for arm in "d10-wide:_lib:LIGHTFM_AMD_TILE_NARROW=0:10" "d10-narrow4:_lib:X=1:10" "d10-narrow5:_lib_nb5:X=1:10" "d10-narrow4-noustore:_lib:X=1:10:--debug 4096" "d10-narrow5-noustore:_lib_nb5:X=1:10:--debug 4096" "d16-wide:_lib:LIGHTFM_AMD_TILE_NARROW=0:16" "d16-narrow4:_lib:X=1:16"; do
+    IFS=: read name lib envs dd extra <<< "$arm"
+    env $envs LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 300 python3 bench.py $S --no-components $dd $extra > $OUT/c2_${name}_$i.json 2> $OUT/c2_${name}_$i.err; line "c2 $name run $i" $OUT/c2_${name}_$i.json
+  done; done
+  S5="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 2 --warmup 1 --config c5shard --scale 0.25"
+  for i in 1 2; do for lib in _lib _lib_nopre; do
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 400 python3 bench.py $S5 > $OUT/c5_${lib}_$i.json 2> $OUT/c5_${lib}_$i.err; line "c5shard $lib run $i" $OUT/c5_${lib}_$i.json
+  done; done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
