@@ -254,7 +254,7 @@ def committed_traffic(config_name, kernel_name, interactions_per_launch=None):
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         e = table.get(config_name)
-        if e and kernel_name in e.get("kernel", ""):
+        if e and kernel_name.split(" + ")[0] in e.get("kernel", ""):  # ("kernel + companion": the first one is the dominant kernel)
             if interactions_per_launch and e.get("hbm_bytes_per_interaction"):
                 extra = {k: e[k] for k in ("traffic_over_algorithmic_profiled", "updates_per_interaction_profiled",
                                            "draws_per_interaction_profiled", "profiled_epochs", "profiled_scale") if k in e}
@@ -337,9 +337,11 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
             "true" if reg else "false")
     if used == 2:
         hot = bool(int(getattr(stats_last, "plan_flags", 0)) & 32)  # the shared rows in LDS slices (csrc/hot_slices.hip)
-        return "fit_feat_kernel<%d, %d, false, %s, %s>%s" % (
+        ada = bool(getattr(stats_last, "_adadelta", False))
+        return "fit_feat_kernel<%d, %d, false, %s, %s, %s>%s" % (
             N.LOSS_IDS[loss], 1 if dp <= 64 else (2 if dp <= 128 else 4), "true" if reg else "false",
-            "true" if hot else "false", " + hot_slice_kernel<8>" if hot else "")  # <loss id, NC, TIMED, REG, HOT>
+            "true" if hot else "false", "true" if ada else "false",
+            " + hot_slice_kernel<8>" if hot else "")  # <loss id, NC, TIMED, REG, HOT, ADA>
     return "fit_%s_kernel (generic)" % loss.replace("-", "_")
 
 

@@ -7,10 +7,16 @@
 
 namespace lfm {
 
-// rows of up to 16 floats take the VEC = 1 instantiation (LIGHTFM_AMD_TILE_NARROW=0: the 64-float layout for every width)
+// LIGHTFM_AMD_TILE_NARROW=1 (off by default): rows of up to 16 floats take the VEC = 1 instantiation -- a quarter of the LDS per
+// interaction, 16 384-20 480 instead of 12 288 interactions in flight.  Built for the reference's default width and measured
+// SLOWER (C2 at d = 10: 1.66 / 1.62 G/s at 4 / 5 workgroups per CU against 1.71 G/s; d = 16: 1.78 against 1.82;
+// profiles/r06_narrow_tile_ab.txt): at this width the kernel is bound by neither latency nor bytes but by the atomic units'
+// LINE operations -- a 12-float row costs the line operation a 32-float half row costs (~10 G/s chip-wide), and an update is
+// 10 of them (4 embedding rows, 6 bias cells): 0.71 G updates/s x 10 = 0.7 of that rate.  What would help is fewer line
+// operations per update (W, G, b and bG of a narrow row in ONE 128-byte line), not more wavefronts.
 static bool narrow_rows_enabled()
 {
-    static const bool on = [] { const char *e = getenv("LIGHTFM_AMD_TILE_NARROW"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char *e = getenv("LIGHTFM_AMD_TILE_NARROW"); return e && atoi(e) != 0; }();
     return on;
 }
 

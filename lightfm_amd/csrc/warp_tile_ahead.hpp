@@ -426,8 +426,16 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
                 if (bupd) {
                     float *bWp, *bGp;
                     bias_ptrs(chosen, bWp, bGp);
-                    atomicAdd(bWp, __fsub_rn(bnW, obW));
-                    atomicAdd(bGp, __fsub_rn(bnG, obG));
+                    if (USTORE && p == 2) {
+                        // the user's bias cells with the user's row: touched by that user's interactions alone.  (A 4-byte
+                        // atomic costs the atomic units a LINE operation like a 32-float half row: the six bias cells were 6
+                        // of an update's 10 line operations at the reference's default width, profiles/r06_narrow_tile_ab.txt)
+                        *bWp = bnW;
+                        *bGp = bnG;
+                    } else {
+                        atomicAdd(bWp, __fsub_rn(bnW, obW));
+                        atomicAdd(bGp, __fsub_rn(bnG, obG));
+                    }
                 }
             }
         }

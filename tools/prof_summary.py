@@ -65,6 +65,17 @@ if os.path.exists(trace):
                                                                     100.0 * (rows[0][2] - union) / max(1, rows[0][2])))
     except Exception as e:  # schema differences: the per-kernel table above stands on its own
         lines.append("# (union of launch intervals not available: %r)" % (e,))
+    hs = [r for r in rows if "hot_slice_kernel" in r[0]]
+    ff = [r for r in rows if "fit_feat_kernel" in r[0]]
+    if hs and ff:
+        # the hot set (csrc/hot_slices.hip): a launch of the row-stream kernel and the slice kernel that applies its records run
+        # one after the other on one stream -- the PAIR (with the record memset and the snapshot) is what a "launch" of
+        # bench.py's roofline is
+        extra = [r for r in rows if "hot_snapshot_kernel" in r[0] or "fillBuffer" in r[0]]
+        n = ff[0][1]
+        tot_ns = ff[0][2] + hs[0][2] + sum(r[2] for r in extra)
+        lines.append("# hot set: %d launches of (row-stream kernel %.1f us + slice kernel %.1f us + memset / snapshot %.1f us) = %.1f us per "
+                     "launch pair" % (n, ff[0][3] / 1e3, hs[0][3] / 1e3, sum(r[2] for r in extra) / 1e3 / max(1, n), tot_ns / 1e3 / max(1, n)))
     bj = os.path.join(src, "bench_trace.json")
     if os.path.exists(bj):
         lines.append("")
@@ -82,7 +93,7 @@ for sub in sorted(os.listdir(src)):
                  "join kernels k on k.dispatch_id = p.dispatch_id "
                  "group by k.name, p.counter_name order by k.name")
     for name, cname, cnt, val in rows:
-        if "fit_" not in name:
+        if "fit_" not in name and "hot_slice_kernel" not in name:
             continue
         pmc.setdefault(name, {})[cname] = {"dispatches": cnt, "sum": val, "per_launch": val / cnt}
 summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --pmc <counter(s)> -- python bench.py --steps 2 "
@@ -90,9 +101,13 @@ summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --pmc <counter(s)> -
            "kernels": pmc}
 # HBM traffic of the DOMINANT kernel (the epoch also has a few short launches of the other tile
 # variants while the concurrency ramp is below the chip's residency)
-dominant = max((n for n in pmc if "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]),
+dominant = max((n for n in pmc if "fit_" in n and "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]),
                key=lambda n: pmc[n]["FETCH_SIZE"]["sum"], default=None)
 summary["dominant_kernel"] = dominant
+# the hot set (round 6): every launch of the row-stream kernel is followed by one hot_slice_kernel launch that applies its
+# records -- the pair is the unit bench.py times; the slice kernel's bytes are added to the dominant kernel's per launch
+companions = [n for n in pmc if "hot_slice_kernel" in n and "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]]
+summary["companion_kernels"] = companions
 for name, c in pmc.items():
     if name == dominant:
         # FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3); on gfx950 FETCH_SIZE counts
@@ -100,6 +115,9 @@ for name, c in pmc.items():
         # coalesced streams; this kernel's reads are 4 B/lane row gathers (256-B rows), so both
         # the raw and the x2-corrected figures are recorded.
         f, w = c["FETCH_SIZE"]["per_launch"] * 1024.0, c["WRITE_SIZE"]["per_launch"] * 1024.0
+        for comp in companions:
+            f += pmc[comp]["FETCH_SIZE"]["per_launch"] * 1024.0
+            w += pmc[comp]["WRITE_SIZE"]["per_launch"] * 1024.0
         summary["hbm_bytes_per_launch_raw"] = f + w
         summary["hbm_bytes_per_launch"] = 2 * f + w
         summary["fetch_bytes_per_launch_raw"] = f
@@ -111,6 +129,11 @@ for name, c in pmc.items():
         if all(k in c for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
             n = c["TCC_EA0_RDREQ_sum"]["per_launch"]
             n32, n128 = c["TCC_EA0_RDREQ_32B_sum"]["per_launch"], c["TCC_EA0_RDREQ_128B_sum"]["per_launch"]
+            for comp in companions:
+                if all(k in pmc[comp] for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
+                    n += pmc[comp]["TCC_EA0_RDREQ_sum"]["per_launch"]
+                    n32 += pmc[comp]["TCC_EA0_RDREQ_32B_sum"]["per_launch"]
+                    n128 += pmc[comp]["TCC_EA0_RDREQ_128B_sum"]["per_launch"]
             rd = 128.0 * n128 + 32.0 * n32 + 64.0 * max(0.0, n - n128 - n32)
             summary["read_requests_per_launch"] = {"all": n, "32B": n32, "128B": n128, "64B": max(0.0, n - n128 - n32)}
             summary["read_bytes_per_launch_calibrated"] = rd

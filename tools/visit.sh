@@ -1023,6 +1023,24 @@ PY
     LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 400 python3 bench.py $S5 > $OUT/c5_${lib}_$i.json 2> $OUT/c5_${lib}_$i.err; line "c5shard $lib run $i" $OUT/c5_${lib}_$i.json
   done; done
   ;;
+r6o)
+  # user bias cells by plain stores with the user rows (_lib) against by atomics (_lib_prev): tile suites, c2 at d = 64 and d = 10
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-34s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d  ustore %s | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], r.get("user_rows_by_plain_stores"), ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 15 --warmup 5 --config c2"
+  for i in 1 2 3; do for arm in "d64:_lib:64" "d64-prev:_lib_prev:64" "d10:_lib:10" "d10-prev:_lib_prev:10"; do
+    IFS=: read name lib dd <<< "$arm"
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 300 python3 bench.py $S --no-components $dd > $OUT/c2_${name}_$i.json 2> $OUT/c2_${name}_$i.err; line "c2 $name run $i" $OUT/c2_${name}_$i.json
+  done; done
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
