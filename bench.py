@@ -329,8 +329,10 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
     ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
     dp = (d + 3) // 4 * 4
     if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):  # <candidates, owner-sharded item tables, user rows by plain stores>
-        return "fit_warp_tile_ahead_kernel<10, %s, %s>" % ("true" if sharded else "false",
-                                                           "true" if int(getattr(stats_last, "user_store", 0)) else "false")
+        narrow = dp <= 16 and not sharded and os.environ.get("LIGHTFM_AMD_TILE_NARROW", "0") not in ("", "0")
+        return "fit_warp_tile_ahead_kernel<10, %s, %s, %d>" % ("true" if sharded else "false",
+                                                               "true" if int(getattr(stats_last, "user_store", 0)) else "false",
+                                                               1 if narrow else 4)  # <candidates, SHARDED, USTORE, VEC>
     if used == 1:
         return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",

@@ -1041,6 +1041,38 @@ PY
     LIGHTFM_AMD_LIB=$R/lightfm_amd/$lib/liblfm_hip.so timeout 300 python3 bench.py $S --no-components $dd > $OUT/c2_${name}_$i.json 2> $OUT/c2_${name}_$i.err; line "c2 $name run $i" $OUT/c2_${name}_$i.json
   done; done
   ;;
+r6p)
+  # kernel traces + counter passes of the four configurations on the round's final kernels
+  bash tools/profile2.sh r06_c2 --config c2
+  PROF_STEPS=5 PROF_WARMUP=2 bash tools/profile2.sh r06_c3 --config c3
+  PROF_STEPS=8 PROF_WARMUP=3 bash tools/profile2.sh r06_c4shard --config c4shard
+  PROF_STEPS=3 PROF_WARMUP=1 bash tools/profile2.sh r06_c5shard --config c5shard --scale 0.25
+  ls -la $R/gpurun_out/prof_r06_*/bench_fetch.json $R/gpurun_out/prof_r06_*/bench_trace.json 2>/dev/null | head
+  ;;
+r6q)
+  # multi-GPU semantics with the hot set in every emulated rank: C3, K = 1 against K = 8 (sparse merges + hot rows at their cadence), 3 seeds;
+  # C2's per-rank kernel time at N = 8 (rank 0's shard of the strong-scaling split on this one GPU)
+  EMU_SHAPE=c3 EMU_EPOCHS=3 timeout 1500 python3 tools/multi_gpu_emulation.py 1:adagrad:4:16384:0 8:adagrad:4:16384:0:sparse+hot > $OUT/emu_c3.txt 2>&1; grep -a "K=" $OUT/emu_c3.txt
+  timeout 400 python3 bench.py --config c2 --emulate-shard 8 --no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1 --steps 20 --warmup 5 > $OUT/c2_shard8.json 2> $OUT/c2_shard8.err
+  python3 -c "
+import json; d=json.load(open('$OUT/c2_shard8.json')); r=d['roofline']; print('c2 rank-0 shard of 8: %.1f M/s, %.3f ms per epoch, ustore %s, in flight %d' % (d['value']/1e6, d['ms_per_step'], r.get('user_rows_by_plain_stores'), r['interactions_in_flight']))"
+  ;;
+r6z)
+  # the driver's sequence on the final tree: GPU suite, smoke, default bench
+  ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
+  timeout 300 python3 __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+  ( time timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; echo "bench bytes $(wc -c < $OUT/bench.json)"
+  grep -a "failed\|Traceback" $OUT/bench.err | head -5
+  python3 - <<PY
+import json
+d = json.load(open("$OUT/bench.json"))
+print("c2 %.1f M/s frac %.3f  traffic %s" % (d["value"] / 1e6, d["roofline"]["frac"], d["roofline"].get("traffic_over_algorithmic")))
+for k, v in d["config"].get("legs", {}).items():
+    try: print("  %-10s %s  frac %s" % (k, v.get("value"), (v.get("roofline") or {}).get("frac")))
+    except Exception as e: print(k, e)
+print("  fit", (d["config"].get("end_to_end_fit") or {}).get("value"), "quality", d["config"].get("quality"))
+PY
+  ;;
 *)
   echo "unknown step $STEP"; exit 2;;
 esac
