@@ -75,7 +75,21 @@ if os.path.exists(trace):
         n = ff[0][1]
         tot_ns = ff[0][2] + hs[0][2] + sum(r[2] for r in extra)
         lines.append("# hot set: %d launches of (row-stream kernel %.1f us + slice kernel %.1f us + memset / snapshot %.1f us) = %.1f us per "
-                     "launch pair" % (n, ff[0][3] / 1e3, hs[0][3] / 1e3, sum(r[2] for r in extra) / 1e3 / max(1, n), tot_ns / 1e3 / max(1, n)))
+                     "launch pair ON AVERAGE -- the launch length ramps with the training history (clamp(history / 128, 8, 128 Ki) positions), "
+                     "so this mean over short and long launches is NOT the duration of the full-length launch the bench line's "
+                     "algorithmic_bytes_per_launch refers to" % (n, ff[0][3] / 1e3, hs[0][3] / 1e3, sum(r[2] for r in extra) / 1e3 / max(1, n), tot_ns / 1e3 / max(1, n)))
+        try:
+            b = json.load(open(os.path.join(src, "bench_trace.json")))
+            r = b["roofline"]
+            per_epoch = r["algorithmic_bytes_per_launch"] / r["algorithmic_bytes_per_interaction"] * r["launches_per_epoch"]
+            epochs = b["steps"] * b["config"].get("epochs_per_step", 1) + b["warmup"] * b["config"].get("epochs_per_step", 1)
+            total_bytes = per_epoch * epochs * r["algorithmic_bytes_per_interaction"]
+            lines.append("# consistent pair: ALL %d profiled epochs (%.1f M interactions x %.0f B algorithmic = %.3f TB) / ALL these kernels (%.1f ms) "
+                         "= %.3f TB/s = %.3f of 8 TB/s, the first epoch's ramp and the profiler's overhead included; the timed epochs alone: "
+                         "roofline.frac of the line below" % (epochs, per_epoch * epochs / 1e6, r["algorithmic_bytes_per_interaction"], total_bytes / 1e12,
+                                                             tot_ns / 1e6, total_bytes / tot_ns / 1e3, total_bytes / tot_ns / 1e3 / 8.0))
+        except Exception as e:
+            lines.append("# (totals not available: %r)" % (e,))
     bj = os.path.join(src, "bench_trace.json")
     if os.path.exists(bj):
         lines.append("")
