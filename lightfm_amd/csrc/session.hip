@@ -2393,6 +2393,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     const int hot_rep_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_REPLICAS"); return e ? atoi(e) : 0; }();
     const int64_t hot_floor_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_FLOOR"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 8); }();
     const int hot_overlap_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_OVERLAP"); return e ? atoi(e) : 0; }();
+    const int64_t hot_min_env = [] { const char *e = getenv("LIGHTFM_AMD_HOT_MIN"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1 ? v : 2048); }();
     bool use_hot = false;
     if (use_feat && hot_env && !(opts->debug & 16384) && a.update_mode == 0 && item_alpha == 0.0 && user_alpha == 0.0 &&
         !s->adadelta && s->d <= 128 && opts->feat_kernel != 2 && s->shards.n == 0) {
@@ -2551,12 +2552,22 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // around a per cent -- but not below 64 Ki positions for accuracy's sake: past that alpha the model is
             // flattened whatever the scale's third digit is ("excessive regularisation"; see reg_len_cap).
             if (reg) len = std::min<int64_t>(len, reg_len_cap);
+            bool hot_launch = use_hot;
             if (use_hot) {
                 const int64_t hist = history0 + (begin - seg_begin);
                 // (floor: what the in-flight ramp itself starts from -- at history 0 every interaction is a maximum-loss step, and
                 // a launch of 256 positions against frozen hot rows cost the hybrid WARP gate 0.0035 whatever hot_k was)
                 const int64_t hot_len = opts->ramp_k < 0 ? hot_chunk_env : std::min<int64_t>(hot_chunk_env, std::max<int64_t>(hot_floor_env, hist / hot_k_env));
-                len = std::min<int64_t>(len, hot_len);
+                // While history / hot_k is still below hot_min positions (the first 1-2 % of a first epoch) the launches run the
+                // shared rows on the float atomics as ever, at the lengths the in-flight ramp gives them: a pair of launches per 8 ..
+                // 2 000 positions cost the first epoch of C3 ~1 400 launch pairs and twice a later epoch's time.  (A caller's own
+                // launch plan and a disabled ramp -- the parity tests -- take the hot set from the first position.)
+                if (opts->launches_per_epoch <= 0 && opts->ramp_k >= 0 && !fixed_cap && hot_len < hot_min_env) {
+                    hot_launch = false;
+                    len = std::min<int64_t>(len, std::max<int64_t>(1, hot_min_env * hot_k_env - hist));  // (switch on time)
+                } else {
+                    len = std::min<int64_t>(len, hot_len);
+                }
             }
             // ... and the FIRST regularised launch of a session has no measured rate to extrapolate with (reg_live is
             // created zeroed; LightFM.fit_partial opens a session per call): its readers see the launch-start scale
@@ -2618,7 +2629,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                                   &grid_used, tile[ng].dma4));
             }
-            else if (use_feat && use_hot) {
+            else if (use_feat && hot_launch) {
                 lfm_session::HotSet &h = s->hot;
                 const int par = n_launches & 1;
                 // this launch's records may run under the next launch (hot_overlap) once the record length has ramped up

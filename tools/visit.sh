@@ -1057,6 +1057,24 @@ r6q)
   python3 -c "
 import json; d=json.load(open('$OUT/c2_shard8.json')); r=d['roofline']; print('c2 rank-0 shard of 8: %.1f M/s, %.3f ms per epoch, ustore %s, in flight %d' % (d['value']/1e6, d['ms_per_step'], r.get('user_rows_by_plain_stores'), r['interactions_in_flight']))"
   ;;
+r6r)
+  # the hot set taken only once a launch reaches 2 048 positions: suites, gates, C3's first epochs (LightFM.fit of 3 epochs, wall time per epoch)
+  ( time timeout 1500 $PYT tests/test_hot_slices.py tests/test_hip_feat.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  for envs in "LIGHTFM_AMD_HOT_MIN=2048" "LIGHTFM_AMD_HOT_MIN=1" "LIGHTFM_AMD_HOT_SLICES=0"; do
+    env $envs LIGHTFM_AMD_TIMING=1 timeout 400 python3 - 2>&1 <<'PY' | grep -aE "timing|fit\(" | cut -c1-400
+import os, sys, time
+sys.path.insert(0, ".")
+from lightfm_amd import LightFM, synthetic
+data = synthetic.named("ml-20m")
+feats = synthetic.tag_item_features(data.shape[1])
+for rep in range(2):
+    m = LightFM(no_components=128, loss="bpr", random_state=3)
+    t = time.perf_counter(); m.fit(data, item_features=feats, epochs=3); dt = time.perf_counter() - t
+    print("fit(3 epochs) %.1f ms = %.1f M interactions/s  [%s]" % (1e3 * dt, data.nnz * 3 / dt / 1e6, " ".join(k + "=" + v for k, v in os.environ.items() if k.startswith("LIGHTFM_AMD_HOT"))), flush=True)
+PY
+  done
+  timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "shipped:X=1" 2>&1 | tail -10
+  ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
