@@ -149,7 +149,9 @@ typedef struct lfm_opts {
                                    the live table: sides above 2 MiB of biases); bit 2 / 3 = the item / user embedding tables
                                    live in uncached memory; bit 4 = the item embedding table is >= 4 GB (64-bit row offsets
                                    in the tile kernel's gathers); bit 5 = the shared tag rows were accumulated in LDS slices
-                                   (csrc/tag_slices.hip) instead of by float atomics of every interaction             */
+                                   (csrc/hot_slices.hip) instead of by float atomics of every interaction; bit 6 = the narrow-model
+                                   tile kernel ran (rows of <= 16 floats: two interactions per lane group, eight per
+                                   wavefront pass; csrc/warp_tile_narrow.hpp)                                          */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -67,6 +67,10 @@ hipError_t launch_fit_warp_tile(const FitArgs &a, int ng, int vec, int grid, siz
 // pass issued inside the current one (warp_tile_ahead.hpp); smem = 0: outside its scope
 size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch);
 hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used = nullptr);
+// warp_tile_narrow.hpp: the same for rows of <= 16 floats, two interactions per lane group (eight per wavefront pass);
+// per_cu_cap > 0 bounds the workgroups per CU
+size_t warp_tile_narrow_smem(int d, int max_sampled, int first_batch, int64_t n_items);
+hipError_t launch_fit_warp_tile_narrow(const FitArgs &a, int grid, hipStream_t st, int cus, int per_cu_cap, int *grid_used = nullptr);
 // feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...

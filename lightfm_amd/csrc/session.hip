@@ -2242,7 +2242,14 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         if (eligible && !(opts->debug & (4096 | 2048)) && bytes <= ((size_t)192 << 20)) {
             double share = 1.0;
             LFM_TRY(user_pair_share(s, &share));
-            rare_collisions = share * 48.0 * (double)std::max(1, s->cus) <= 0.3;
+            // (interactions in flight per CU at full residency: 48 for the tile kernels, 128 for the narrow-model kernel --
+            // four workgroups of eight per wavefront pass, warp_tile_narrow.hpp)
+            const bool narrow = loss == LFM_LOSS_WARP && s->itf.identity && s->max_sampled == 10 && (opts->first_batch <= 0 || opts->first_batch == 10) &&
+                                opts->warp_kernel == 0 && !(opts->debug & (1024 | 512 | 64)) && item_alpha == 0.0 && user_alpha == 0.0 &&
+                                warp_tile_narrow_smem(s->d, 10, 10, (int64_t)s->itf.rows) != 0;
+            static const int narrow_blocks = [] { const char *e = getenv("LIGHTFM_AMD_NARROW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+            const double per_cu = narrow ? 32.0 * narrow_blocks : 48.0;
+            rare_collisions = share * per_cu * (double)std::max(1, s->cus) <= 0.3;
         }
         base_user_store = a.user_store = (eligible && !(opts->debug & 4096) && (rare_collisions || (opts->debug & 2048))) ? 1 : 0;
     }
@@ -2313,7 +2320,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // the lane-group tile kernel (warp_tile_kernel.hpp), NG interactions per wavefront pass.
     // NG = 4 is the most instruction-efficient mapping; when a launch may keep only few
     // interactions in flight, fewer per wavefront buy more wavefronts (latency hiding).
-    struct TilePlan { bool ok = false, dma4 = false, ahead = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
+    struct TilePlan { bool ok = false, dma4 = false, ahead = false, narrow = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
     TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
     if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
@@ -2342,6 +2349,13 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 if (ahead) {
                     t.ahead = true;
                     t.smem = ahead;
+                    // narrow models (rows of <= 16 floats: the reference's default width): two interactions per lane group,
+                    // eight per wavefront pass (warp_tile_narrow.hpp)
+                    const size_t narrow = s->shards.n == 0 ? warp_tile_narrow_smem(s->d, s->max_sampled, t.first_batch, (int64_t)s->itf.rows) : 0;
+                    if (narrow) {
+                        t.narrow = true;
+                        t.smem = narrow;
+                    }
                 }
             }
             use_tile = true;
@@ -2526,7 +2540,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             if (ng) {
                 const TilePlan &t = tile[ng];
                 lsmem = t.smem;
-                per_wave = ng;
+                per_wave = t.narrow ? 2 * ng : ng;
                 a.tile_rows = t.rows;
                 a.tile_stride = t.stride;
                 a.first_batch = t.first_batch;
@@ -2625,7 +2639,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                         plan_flags |= 1 << side;
                     }
                 }
-                if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
+                if (tile[ng].narrow) {
+                    static const int narrow_blocks_env = [] { const char *e = getenv("LIGHTFM_AMD_NARROW_BLOCKS"); return e ? atoi(e) : 0; }();
+                    HIP_TRY(launch_fit_warp_tile_narrow(a, grid, lst, s->cus, narrow_blocks_env, &grid_used));
+                    plan_flags |= 64;
+                }
+                else if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
                 else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                                   &grid_used, tile[ng].dma4));
             }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "warp_tile_ahead.hpp"
+#include "warp_tile_narrow.hpp"
 
 namespace lfm {
 
@@ -25,6 +26,29 @@ size_t warp_tile_ahead_smem(int d, int max_sampled, int first_batch)
 {
     if (d < 4 || d > 64 || (d & 3) != 0 || max_sampled != 10 || first_batch != 10) return 0;
     return d <= 16 && narrow_rows_enabled() ? tile_ahead_smem<10, 1>() : tile_ahead_smem<10>();
+}
+
+// The narrow-model kernel (warp_tile_narrow.hpp: two interactions per 16-lane group, eight per wavefront pass): LDS bytes per
+// workgroup, 0 outside its scope (LIGHTFM_AMD_TILE_PAIRS=0 keeps narrow models on the wide kernel)
+size_t warp_tile_narrow_smem(int d, int max_sampled, int first_batch, int64_t n_items)
+{
+    static const bool on = [] { const char *e = getenv("LIGHTFM_AMD_TILE_PAIRS"); return !e || atoi(e) != 0; }();
+    if (!on || d < 4 || d > 16 || (d & 3) != 0 || max_sampled != 10 || first_batch != 10 || n_items * (int64_t)d >= (1ll << 30)) return 0;
+    return tile_narrow_smem();
+}
+
+hipError_t launch_fit_warp_tile_narrow(const FitArgs &a, int grid, hipStream_t st, int cus, int per_cu_cap, int *grid_used)
+{
+    void (*kernel)(FitArgs) = a.user_store ? fit_warp_tile_narrow_kernel<10, true> : fit_warp_tile_narrow_kernel<10, false>;
+    const size_t smem = tile_narrow_smem();
+    if (cus > 0) {
+        int per_cu = occupancy_cached(kernel, 256, smem);
+        if (per_cu_cap > 0) per_cu = std::min(per_cu, per_cu_cap);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
 }
 
 hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used)

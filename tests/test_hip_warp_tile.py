@@ -250,9 +250,10 @@ def _conflict_free(nu, ni, n, per_launch, ms, rng, attempts=200):
     raise AssertionError("no conflict-free arrangement found")
 
 
+@pytest.mark.parametrize("d", [64, 16, 10, 4], ids=["d64", "d16-narrow", "d10-narrow", "d4-narrow"])
 @pytest.mark.parametrize("ustore", [False, True], ids=["atomics", "user-rows-stored"])
 @pytest.mark.parametrize("per_launch", [4, 32], ids=["one-pass", "four-waves-two-passes"])
-def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore):
+def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore, d):
     """The kernel bench.py's headline runs on (fit_warp_tile_ahead_kernel: update_mode 0, debug 0 apart from the forced
     lane-group width the session picks at full residency anyway), with NON-ZERO updates under concurrency: four lane
     groups of a wavefront update in the same pass (speculative cU / cP / cN copies, the four-at-once bias cells);
@@ -261,7 +262,7 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore
     "user-rows-stored": the instantiation that writes the user row of an update with plain stores (lfm_opts.user_store;
     the session picks it for models with >= 8 users per interaction in flight -- C2 -- here forced by debug bit 11)."""
     from lightfm_amd.options import options
-    d, ms = 64, 10
+    ms = 10
     nu, ni, n = (400, 40000, 160) if per_launch == 4 else (800, 300000, 256)
     coo, shuffle, seeds = _conflict_free(nu, ni, n, per_launch, ms, np.random.RandomState(23))
     st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
@@ -271,6 +272,8 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore
     options.set(log_samples=True, launches_per_epoch=n // per_launch, update_mode=0, debug=4 | (2048 if ustore else 0), max_waves=16)
     _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
     assert options.last_tile_ahead == 1 and options.last_tile_ng == 4, "the steady-state tile kernel did not run"
+    # rows of <= 16 floats: the narrow-model kernel (csrc/warp_tile_narrow.hpp: two interactions per lane group)
+    assert bool(options.last_plan_flags & 64) == (d <= 16), (d, options.last_plan_flags)
     assert options.last_user_store == int(ustore)  # (a few hundred users: the session's own rule says atomics)
     o = _orc_warp(coo, b, shuffle, seeds, coo.data)
     neg, sampled = options.last_logs
@@ -282,7 +285,8 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore
     H.assert_states_within_ulps(a, b, ulps=4)
 
 
-def test_tile_ahead_reread_branch_updates_match_the_oracle(fast):
+@pytest.mark.parametrize("d", [64, 10, 16], ids=["d64", "d10-narrow", "d16-narrow"])
+def test_tile_ahead_reread_branch_updates_match_the_oracle(fast, d):
     """Dense positives rows (a third of the catalogue per user) and near-zero scores: nearly every candidate violates
     the margin, so the FIRST violator is one of the user's positives in about a third of the interactions; the choice
     is then a later violator whose row the steady-state kernel re-reads from the table (warp_tile_ahead.hpp, `only_neg`)
@@ -290,7 +294,7 @@ def test_tile_ahead_reread_branch_updates_match_the_oracle(fast):
     oracle's after two epochs.  That the branch ran is read off the counters: every position found a negative, so
     each in_positives probe that hit (probes - updates) belongs to a position whose first violator was a positive."""
     from lightfm_amd.options import options
-    nu, ni, d, ms = 24, 60, 64, 10
+    nu, ni, ms = 24, 60, 10
     rng = np.random.RandomState(8)
     dense = rng.rand(nu, ni) < 0.33
     dense[:, 0] = True
@@ -305,6 +309,7 @@ def test_tile_ahead_reread_branch_updates_match_the_oracle(fast):
         shuffle, seeds = H.epoch_inputs(coo, rng)
         _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
         assert options.last_tile_ahead == 1 and options.last_tile_ng == 4
+        assert bool(options.last_plan_flags & 64) == (d <= 16)
         o = _orc_warp(coo, b, shuffle, seeds, coo.data)
         neg, sampled = options.last_logs
         assert np.array_equal(sampled, o.sampled)
@@ -340,3 +345,54 @@ def test_tile_training_learns_like_the_oracle(fast):
     assert ab > 0.8
     assert abs(aa - ab) < 0.04, (aa, ab)  # Hogwild: run-to-run variation
     assert abs(ma - mb) / abs(mb) < 0.2, (ma, mb)
+
+
+@pytest.mark.parametrize("d", [4, 10, 12, 16])
+@pytest.mark.parametrize("waves", [0, 64], ids=["full-grid", "two-workgroups-many-passes"])
+def test_narrow_kernel_frozen_weights_samples_exact(fast, d, waves):
+    """The narrow-model kernel (csrc/warp_tile_narrow.hpp: rows of <= 16 floats, two interactions per lane group, eight per
+    wavefront pass, four rows per LDS-DMA instruction) with frozen weights: every position's negative and sample count and
+    the counters equal the oracle's -- across the whole grid, and with two workgroups walking hundreds of passes each (the
+    record pipeline, the gather issued one pass ahead, launch tails that end inside a pass)."""
+    from lightfm_amd.options import options
+    nu, ni = 3000, 2500
+    coo = H.make_interactions(nu, ni, 60_011, seed=29, ratings=True, zipf=0.7)
+    rng = np.random.RandomState(4)
+    st = oracle.State(ni, nu, d, rng, max_sampled=10)
+    _spread(st)
+    st.item_biases[:] = rng.randn(ni).astype(np.float32) * 0.3
+    st.user_biases[:] = rng.randn(nu).astype(np.float32) * 0.3
+    a, b = st.copy(), st.copy()
+    zeros = np.zeros_like(coo.data)
+    shuffle, seeds = H.epoch_inputs(coo, rng)
+    options.set(log_samples=True, launches_per_epoch=3, ramp_k=-1, max_waves=waves, debug=4)
+    _hip_warp(fast, coo, a, shuffle, seeds, zeros)
+    assert options.last_kernel_used == 1 and options.last_plan_flags & 64, (options.last_kernel_used, options.last_plan_flags)
+    o = _orc_warp(coo, b, shuffle, seeds, zeros)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled), "sample counts differ at %d positions" % int((sampled != o.sampled).sum())
+    assert np.array_equal(neg, o.neg), "negatives differ at %d positions" % int((neg != o.neg).sum())
+    assert options.last_counters == o.counters
+    assert o.counters[2] > 1000
+    H.assert_states_equal(a, st, exact=True)
+
+
+def test_narrow_kernel_training_learns_like_the_wide_one():
+    """Full-concurrency training at the reference's default width (no_components = 10) through the narrow-model kernel and,
+    with LIGHTFM_AMD_TILE_PAIRS-independent means (debug bit 10: the plain tile kernel), through the wide one: both learn."""
+    from lightfm_amd import LightFM
+    from lightfm_amd.options import options
+    coo = H.make_interactions(4000, 3000, 200_000, seed=12, zipf=0.8)
+    rows, cols = np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col)
+    negs = np.random.RandomState(0).randint(0, 3000, size=coo.nnz).astype(np.int32)
+    acc = {}
+    for arm, debug in (("narrow", 0), ("plain", 1024)):
+        options.set(debug=debug)
+        m = LightFM(loss="warp", random_state=7)  # no_components = 10
+        m.fit(coo, epochs=6)
+        st = m._last_epoch_stats[-1]
+        assert st["kernel_used"] == 1 and bool(st["plan_flags"] & 64) == (arm == "narrow"), (arm, st)
+        acc[arm] = float(np.mean(m.predict(rows, cols) > m.predict(rows, negs)))
+    options.set(debug=0)
+    print("pairwise accuracy", acc)
+    assert acc["narrow"] > 0.85 and abs(acc["narrow"] - acc["plain"]) < 0.02, acc

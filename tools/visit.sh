@@ -1075,6 +1075,25 @@ PY
   done
   timeout 2400 python3 tools/hot_gate_sweep.py 8 "off:HOT_SLICES=0" "shipped:X=1" 2>&1 | tail -10
   ;;
+r6s)
+  # the narrow-model tile kernel (two interactions per lane group): tile suites, then c2 at d = 10 / 12 / 16 with it (4 / 3 / 2 workgroups per CU)
+  # and without (LIGHTFM_AMD_TILE_PAIRS=0)
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-30s %8.2f M/s  frac %.3f  launch %.3f ms  in flight %d  ustore %s | steady %8.2f M/s  %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["interactions_in_flight"], r.get("user_rows_by_plain_stores"), ss.get("value", 0) / 1e6, r["kernel"][:50]))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 10 --warmup 3 --config c2"
+  for i in 1 2; do for arm in "d10-wide:LIGHTFM_AMD_TILE_PAIRS=0:10" "d10-pairs4:X=1:10" "d10-pairs3:LIGHTFM_AMD_NARROW_BLOCKS=3:10" "d10-pairs2:LIGHTFM_AMD_NARROW_BLOCKS=2:10" "d10-pairs4-noustore:X=1:10:--debug 4096" "d16-wide:LIGHTFM_AMD_TILE_PAIRS=0:16" "d16-pairs4:X=1:16" "d4-wide:LIGHTFM_AMD_TILE_PAIRS=0:4" "d4-pairs4:X=1:4"; do
+    IFS=: read name envs dd extra <<< "$arm"
+    env $envs timeout 300 python3 bench.py $S --no-components $dd $extra > $OUT/c2_${name}_$i.json 2> $OUT/c2_${name}_$i.err; line "c2 $name run $i" $OUT/c2_${name}_$i.json
+  done; done
+  ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
