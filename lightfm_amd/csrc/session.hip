@@ -2554,7 +2554,14 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const size_t cu_blocks = use_feat ? (size_t)std::max(1, feat_waves / wpb) : 8;
             const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
-            const bool below_residency = allowed / (wpb * per_wave) < max_grid;
+            bool below_residency = allowed / (wpb * per_wave) < max_grid;
+            if (ng && tile[ng].narrow && below_residency && !fixed_cap) {
+                // the narrow-model kernel keeps 128 interactions per CU in flight: on a catalogue of a few ten thousand items it
+                // is the STEADY-STATE bound (never more in flight than the smaller side has rows) that binds, not the history
+                // ramp -- such launches are full-length and alternate between the two streams like any launch at residency
+                const int64_t by_history = opts->ramp_k < 0 ? INT64_MAX / 4 : std::max<int64_t>(8, (history0 + (begin - seg_begin)) / ramp_k);
+                if (by_history / (wpb * per_wave) >= max_grid) below_residency = false;
+            }
             max_grid = (int)std::max<int64_t>(1, std::min<int64_t>(max_grid, allowed / (wpb * per_wave)));
             if (max_grid > s->cus) max_grid -= max_grid % s->cus;  // whole workgroups per CU
             const int64_t flight = (int64_t)max_grid * wpb * per_wave;

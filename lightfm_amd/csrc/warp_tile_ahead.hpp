@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
                 float bnW, bnG, bnM;
                 double blr;
                 cell_math(obW, obG, 0.0f, 1.0, p == 0 ? -lossd : lossd, h, 0.0, bnW, bnG, bnM, blr);
-                if (bupd) {
+                if (bupd && !(a.debug & 32768)) {  // (debug bit 15: experiment -- the bias cells are not published)
                     float *bWp, *bGp;
                     bias_ptrs(chosen, bWp, bGp);
                     if (USTORE && p == 2) {

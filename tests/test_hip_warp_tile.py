@@ -274,7 +274,8 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore
     assert options.last_tile_ahead == 1 and options.last_tile_ng == 4, "the steady-state tile kernel did not run"
     # rows of <= 16 floats: the narrow-model kernel (csrc/warp_tile_narrow.hpp: two interactions per lane group)
     assert bool(options.last_plan_flags & 64) == (d <= 16), (d, options.last_plan_flags)
-    assert options.last_user_store == int(ustore)  # (a few hundred users: the session's own rule says atomics)
+    if d >= 10:  # (at d = 4 the 6 KB user table is not in uncached memory: the forced plain stores do not apply)
+        assert options.last_user_store == int(ustore)  # (a few hundred users: the session's own rule says atomics)
     o = _orc_warp(coo, b, shuffle, seeds, coo.data)
     neg, sampled = options.last_logs
     assert np.array_equal(sampled, o.sampled)

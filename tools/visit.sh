@@ -1089,10 +1089,32 @@ except Exception as e:
 PY
   }
   S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 10 --warmup 3 --config c2"
-  for i in 1 2; do for arm in "d10-wide:LIGHTFM_AMD_TILE_PAIRS=0:10" "d10-pairs4:X=1:10" "d10-pairs3:LIGHTFM_AMD_NARROW_BLOCKS=3:10" "d10-pairs2:LIGHTFM_AMD_NARROW_BLOCKS=2:10" "d10-pairs4-noustore:X=1:10:--debug 4096" "d16-wide:LIGHTFM_AMD_TILE_PAIRS=0:16" "d16-pairs4:X=1:16" "d4-wide:LIGHTFM_AMD_TILE_PAIRS=0:4" "d4-pairs4:X=1:4"; do
+  for i in 1 2; do for arm in "d10-wide:LIGHTFM_AMD_TILE_PAIRS=0:10" "d10-pairs:LIGHTFM_AMD_TILE_PAIRS=1:10" "d10-pairs-ustore:LIGHTFM_AMD_TILE_PAIRS=1:10:--debug 2048" "d16-wide:LIGHTFM_AMD_TILE_PAIRS=0:16" "d16-pairs:LIGHTFM_AMD_TILE_PAIRS=1:16" "d16-pairs-ustore:LIGHTFM_AMD_TILE_PAIRS=1:16:--debug 2048"; do
     IFS=: read name envs dd extra <<< "$arm"
     env $envs timeout 300 python3 bench.py $S --no-components $dd $extra > $OUT/c2_${name}_$i.json 2> $OUT/c2_${name}_$i.err; line "c2 $name run $i" $OUT/c2_${name}_$i.json
   done; done
+  ;;
+r6t)
+  # experiment: what the six bias-cell publications of an update cost (debug bit 15 = 32768: not published) -- the write-side line-operation hypothesis
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-30s %8.2f M/s  frac %.3f  launch %.3f ms  U %.3f | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 10 --warmup 3"
+  for i in 1 2; do for arm in "c2-d64:c2:64:" "c2-d64-nobias:c2:64:--debug 32768" "c2-d10:c2:10:" "c2-d10-nobias:c2:10:--debug 32768" "c4shard:c4shard:64:" "c4shard-nobias:c4shard:64:--debug 32768"; do
+    IFS=: read name cfg dd extra <<< "$arm"
+    LIGHTFM_AMD_TILE_PAIRS=0 timeout 300 python3 bench.py $S --config $cfg --no-components $dd $extra > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "$name run $i" $OUT/${name}_$i.json
+  done; done
+  ;;
+r6u)
+  # the narrow-model kernel on by default: its precision gate at the default width, the tile suites, the default-width leg
+  ( time timeout 1500 $PYT tests/test_precision_parity.py -m gpu -q -s -k "default_width or ml100k or tiny" ) > $OUT/gates.txt 2>&1; grep -aE "delta|passed|failed|real" $OUT/gates.txt
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py tests/test_lightfm_api.py tests/test_reference_suite.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
   ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
