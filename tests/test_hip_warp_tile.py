@@ -383,9 +383,11 @@ def test_narrow_kernel_training_learns_like_the_wide_one():
     with LIGHTFM_AMD_TILE_PAIRS-independent means (debug bit 10: the plain tile kernel), through the wide one: both learn."""
     from lightfm_amd import LightFM
     from lightfm_amd.options import options
-    coo = H.make_interactions(4000, 3000, 200_000, seed=12, zipf=0.8)
+    # (a catalogue large enough for four interactions per lane group at full residency: the smaller side bounds the
+    # interactions in flight, and below 8 192 of them the session runs one interaction per wavefront pass)
+    coo = H.make_interactions(14000, 11000, 450_000, seed=12, zipf=0.8)
     rows, cols = np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col)
-    negs = np.random.RandomState(0).randint(0, 3000, size=coo.nnz).astype(np.int32)
+    negs = np.random.RandomState(0).randint(0, 11000, size=coo.nnz).astype(np.int32)
     acc = {}
     for arm, debug in (("narrow", 0), ("plain", 1024)):
         options.set(debug=debug)
@@ -396,4 +398,4 @@ def test_narrow_kernel_training_learns_like_the_wide_one():
         acc[arm] = float(np.mean(m.predict(rows, cols) > m.predict(rows, negs)))
     options.set(debug=0)
     print("pairwise accuracy", acc)
-    assert acc["narrow"] > 0.85 and abs(acc["narrow"] - acc["plain"]) < 0.02, acc
+    assert acc["narrow"] > 0.8 and abs(acc["narrow"] - acc["plain"]) < 0.02, acc

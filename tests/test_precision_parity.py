@@ -155,11 +155,3 @@ def test_warp_tiny_high_collision_problems(shape):
     train, test = synthetic.train_test_split(data, 0.1, seed=1)
     _gap("warp", 64, train, test, None, epochs=10, n_seeds=_small_seeds(48))
 
-
-@pytest.mark.timeout(900)
-def test_warp_default_width_c2_regime():
-    """The reference's DEFAULT model -- LightFM(loss='warp'): no_components = 10 (LFM:191), rows of 12 floats on the device --
-    on the C2-regime data: the narrow-model tile kernel (csrc/warp_tile_narrow.hpp: two interactions per lane group, eight
-    per wavefront pass) under the shipped in-flight policy."""
-    train, test = _data(17312, 13372, 2_500_000)
-    _gap("warp", 10, train, test, None, epochs=5, n_seeds=8)

@@ -1116,6 +1116,12 @@ r6u)
   ( time timeout 1500 $PYT tests/test_precision_parity.py -m gpu -q -s -k "default_width or ml100k or tiny" ) > $OUT/gates.txt 2>&1; grep -aE "delta|passed|failed|real" $OUT/gates.txt
   ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py tests/test_lightfm_api.py tests/test_reference_suite.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
   ;;
+r6v)
+  # precision@10 at the default width: reference, narrow-model kernel, wide kernel (40 seeds each); the fixed narrow training test
+  timeout 1200 python3 tools/narrow_quality.py 40 2>&1 | tail -3
+  NARROW_QUALITY_REF=0 LIGHTFM_AMD_TILE_PAIRS=0 timeout 600 python3 tools/narrow_quality.py 40 2>&1 | tail -1
+  ( time timeout 900 $PYT tests/test_hip_warp_tile.py -m gpu -x -q -k narrow ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
