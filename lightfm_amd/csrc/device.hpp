@@ -112,6 +112,11 @@ struct FitArgs {
     ItemShards shards;             // owner-sharded item tables (n = 0: none)
     int32_t user_store;            // parallel mode: the USER row of an update (identity user features: touched by that user's
                                    // interactions alone) is written with plain stores instead of float atomics (session.hip)
+    float *bb[2];                  // steady-state tile kernels (warp_tile_ahead.hpp, warp_tile_narrow.hpp): the bias tables of a side
+                                   // as ONE table of (b, bG) pairs, [n_feat][2] -- both cells of a row in one line, so that an
+                                   // update publishes them with one line operation instead of two (session.hip: bias pairs);
+                                   // nullptr = the separate tables m.b / m.bG
+    int32_t b_read_stride[2];      // floats between consecutive rows of b_read[side] (1: a snapshot or m.b; 2: bb)
     const int32_t *hot_slot;       // [n_item_feat] slot of a hot item-feature row, -1 otherwise; nullptr = no hot set (HotRec above)
     HotRec *hot_rec;               // [end - begin] one record per position of the launch
     float *hot_x;                  // [end - begin][d] the vector the hot rows' gradients multiply (the user representation)

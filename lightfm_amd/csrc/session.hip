@@ -539,6 +539,12 @@ struct lfm_session {
     DBuf<float> Y, weight;
     bool weight_aliases_Y = false;
     DBuf<float> bias_snap[2][2];  // per-launch cached copies of the bias tables (tile kernel scoring): [side][launch parity]
+    // Bias PAIRS (steady-state tile kernels): while launches of fit_warp_tile_ahead_kernel / fit_warp_tile_narrow_kernel run, the
+    // live bias cells of a side are ONE table of (b, bG) pairs -- both cells of a row in one line, published by one line
+    // operation (C2 +4.4 % in the timing experiment, profiles/r06_narrow_kernel.txt) -- packed from tab[side][3 / 4] before
+    // the first such launch of an epoch call and unpacked into them before anything else reads the tables
+    DBuf<float> bias_pairs[2];
+    bool pairs_live = false;
     hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
@@ -2054,6 +2060,25 @@ static int validate_inputs(lfm_session *s, int slot, int when, bool recs_in_use)
     return LFM_OK;
 }
 
+__global__ void bias_pack_kernel(const float *b, const float *bG, float *pairs, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        pairs[2 * i] = b[i];
+        pairs[2 * i + 1] = bG[i];
+    }
+}
+__global__ void bias_unpack_kernel(float *b, float *bG, const float *pairs, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        b[i] = pairs[2 * i];
+        bG[i] = pairs[2 * i + 1];
+    }
+}
+__global__ void copy_strided_kernel(float *dst, const float *src, int64_t n, int stride)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i * stride];
+}
+
 // sum_u c_u^2 / n^2 over the uploaded COO, c_u = interactions of user u: the probability that two interactions drawn at
 // random belong to the same user.  Times the interactions in flight it is the share of interactions that have ANOTHER
 // interaction of their user in flight with them -- what the plain-store user rows (FitArgs::user_store) can lose an update
@@ -2151,6 +2176,32 @@ static int build_hot_set(lfm_session *s)
     return LFM_OK;
 }
 
+// Bias pairs (lfm_session::bias_pairs): the live bias cells move between tab[side][3 / 4] and the (b, bG) pair tables
+static int bias_pairs_pack(lfm_session *s, hipStream_t st)
+{
+    for (int side = 0; side < 2; ++side) {
+        const int64_t n = (int64_t)s->n_feat[side];
+        s->bias_pairs[side].flags = s->tab[side][3].flags;
+        LFM_TRY(s->bias_pairs[side].alloc((size_t)(2 * n)));
+        if (n) bias_pack_kernel<<<(int)std::min<int64_t>(1024, (n + 255) / 256), 256, 0, st>>>(s->tab[side][3].p, s->tab[side][4].p, s->bias_pairs[side].p, n);
+    }
+    HIP_TRY(hipGetLastError());
+    s->pairs_live = true;
+    return LFM_OK;
+}
+
+static int bias_pairs_unpack(lfm_session *s, hipStream_t st)
+{
+    for (int side = 0; side < 2; ++side) {
+        const int64_t n = (int64_t)s->n_feat[side];
+        if (n && s->bias_pairs[side].p)
+            bias_unpack_kernel<<<(int)std::min<int64_t>(1024, (n + 255) / 256), 256, 0, st>>>(s->tab[side][3].p, s->tab[side][4].p, s->bias_pairs[side].p, n);
+    }
+    HIP_TRY(hipGetLastError());
+    s->pairs_live = false;
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------------ epoch ---
 
 static void tile_geometry(int d, int want_rows, int *rows, int *stride)
@@ -2170,6 +2221,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (!s) return fail(LFM_EINVAL, "null session");
     if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session (lfm_session_create_scoring) cannot train");
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);  // (left running only by an epoch that failed half-way)
+    if (s->pairs_live) {  // (likewise: the live bias cells are still in the pair tables)
+        HIP_TRY(hipSetDevice(s->device));
+        LFM_TRY(bias_pairs_unpack(s, s->stream));
+    }
     if (s->share && s->share->broken)
         return fail(LFM_EINVAL, "a session this one shares item tables with has been destroyed: its rows are gone");
     if (loss < 0 || loss > 3) return fail(LFM_EINVAL, "unknown loss");
@@ -2632,17 +2687,38 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 // is a fabric request; a cached snapshot taken at the launch boundary (the tables
                 // are tiny) serves them from L1/L2 instead, and no atomic ever drops its lines.
                 // Updates still read and publish the live tables.  (LFM debug bit 5 disables it.)
+                // the steady-state kernels keep the live bias cells as (b, bG) pairs (lfm_session::bias_pairs); LIGHTFM_AMD_BIAS_PAIRS=0:
+                // the separate tables
+                static const bool pairs_env = [] { const char *e = getenv("LIGHTFM_AMD_BIAS_PAIRS"); return !e || atoi(e) != 0; }();
+                const bool want_pairs = pairs_env && tile[ng].ahead && s->shards.n == 0;
+                if (want_pairs && !s->pairs_live) LFM_TRY(bias_pairs_pack(s, s->stream));  // (before the streams fork: both see it)
+                if (!want_pairs && s->pairs_live) {  // (a launch of another kernel after steady-state launches: does not happen in the shipped plan)
+                    if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
+                    LFM_TRY(bias_pairs_unpack(s, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                }
                 a.b_read[0] = a.m.b[0];
                 a.b_read[1] = a.m.b[1];
+                a.b_read_stride[0] = a.b_read_stride[1] = 1;
+                a.bb[0] = a.bb[1] = nullptr;
+                if (s->pairs_live) {
+                    for (int side = 0; side < 2; ++side) {
+                        a.bb[side] = s->bias_pairs[side].p;
+                        a.b_read[side] = s->bias_pairs[side].p;
+                        a.b_read_stride[side] = 2;
+                    }
+                }
                 {
                     for (int side = 0; side < 2; ++side) {
                         if (!snap_side[side]) continue;
                         const int64_t cnt = (int64_t)tab_count(s, side, 3);
                         if (cnt) {
                             const int cgrid = (int)std::min<int64_t>(1024, (cnt + 255) / 256);
-                            copy_kernel<<<cgrid, 256, 0, lst>>>(s->bias_snap[side][par].p, s->tab[side][3].p, cnt);
+                            if (s->pairs_live) copy_strided_kernel<<<cgrid, 256, 0, lst>>>(s->bias_snap[side][par].p, s->bias_pairs[side].p, cnt, 2);
+                            else copy_kernel<<<cgrid, 256, 0, lst>>>(s->bias_snap[side][par].p, s->tab[side][3].p, cnt);
                         }
                         a.b_read[side] = s->bias_snap[side][par].p;
+                        a.b_read_stride[side] = 1;
                         plan_flags |= 1 << side;
                     }
                 }
@@ -2754,6 +2830,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             HIP_TRY(hipEventRecord(s->ev_join, s->stream2));
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
         }
+        if (s->pairs_live) LFM_TRY(bias_pairs_unpack(s, s->stream));  // the bias cells go back to their tables
     }
     if (reg) HIP_TRY(launch_regularize(a.m, serial ? nullptr : s->reg_log.p, serial ? nullptr : s->reg_live.p, 1, s->stream));  // PYX:910-912
     HIP_TRY(hipEventRecord(s->ev1, s->stream));

@@ -35,6 +35,7 @@ struct ItemAddr {
     float *W0, *G0, *b0, *bG0;
     const float *bread0;
     int d;
+    int bstride = 1;  // floats between rows of bread0 (2: the (b, bG) pair table)
     __device__ __forceinline__ static float *pick(float *const (&p)[8], uint32_t j)
     {
         float *a01 = (j & 1u) ? p[1] : p[0], *a23 = (j & 1u) ? p[3] : p[2];
@@ -93,7 +94,7 @@ struct ItemAddr {
     // the bias the SCORING reads: the launch's cached snapshot, or -- sharded -- the owner's live cell
     __device__ __forceinline__ const float *bscore(int row) const
     {
-        if constexpr (!SHARDED) return bread0 + row;
+        if constexpr (!SHARDED) return bread0 + (size_t)row * bstride;
         return b(row);
     }
 };
@@ -136,7 +137,11 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
     const bool pc = VEC * p < d;
     const float *Wu = a.m.W[1];
     const float *bu_tab = a.b_read[1];
-    const ItemAddr<SHARDED> item{a.shards, a.m.W[0], a.m.G[0], a.m.b[0], a.m.bG[0], a.b_read[0], d};
+    const ItemAddr<SHARDED> item{a.shards, a.m.W[0], a.m.G[0], a.m.b[0], a.m.bG[0], a.b_read[0], d, a.b_read_stride[0]};
+    // bias cells as (b, bG) pairs of one line (FitArgs::bb): lanes 16 g + 0 / 1 / 2 hold the W cell of the positive item / the
+    // negative item / the user, lanes 16 g + 3 / 4 / 5 the accumulator cell next to it -- one load and ONE publication
+    // instruction per pass touch both cells of a row with one line operation (the separate tables: two)
+    const bool paired = !SHARDED && a.bb[0] != nullptr;
     const bool small_items = (uint64_t)a.itf.rows * (uint64_t)d < (1ull << 30);  // item table below 4 GB: 32-bit row offsets
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
             if (pc) dma_piece(item.Wg(neg, small_items) + VEC * p, tile + (size_t)k * KS);
         }
         dma_lane_dword(item.bscore(myitem), tile + BB);
-        dma_lane_dword(bu_tab + user, tile + BB + WAVE);
+        dma_lane_dword(bu_tab + (size_t)user * a.b_read_stride[1], tile + BB + WAVE);
     };
 
     // record pipeline, three passes deep (as fit_warp_tile_kernel)
@@ -291,6 +296,12 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
                 bGp = item.bG(irow);
             }
         };
+        // (b, bG) pair table: the cell of lane p < 6 -- role p % 3 (positive item, negative item, user), part p / 3 (W, G)
+        auto pair_ptr = [&](int neg) -> float * {
+            const int role = p < 3 ? p : p - 3;
+            const int row = role == 2 ? c_user : (role == 0 ? c_pos : neg);
+            return a.bb[role == 2 ? 1 : 0] + 2 * (size_t)row + (p < 3 ? 0 : 1);
+        };
         if (__ballot(act) != 0ull) {
             const uint32_t bh = Bloom::mix((uint32_t)myitem);
             uint32_t bword = 0xffffffffu;
@@ -303,7 +314,9 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
             }
             const uint32_t bmask = Bloom::mask(bh);
             const int maybe_pos = ((bword & bmask) == bmask) ? 1 : 0;
-            if (has_viol && p < 3) {  // bias cells of the speculated update
+            if (paired) {
+                if (has_viol && p < 6) obW = *pair_ptr(spec_cand);  // (this lane's cell; the pairs meet after the wait)
+            } else if (has_viol && p < 3) {  // bias cells of the speculated update
                 float *bWp, *bGp;
                 bias_ptrs(spec_cand, bWp, bGp);
                 obW = *bWp;
@@ -352,13 +365,16 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
         const bool bupd = act && chosen >= 0 && p < 3;
         if (upd != 0ull) {
             {   // the first violator was a positive and a later one is the choice: its bias cell (lane 16 g + 1)
-                const bool bre = bupd && p == 1 && chosen != spec_cand;
+                const bool bre = act && chosen >= 0 && chosen != spec_cand && (paired ? (p == 1 || p == 4) : p == 1);
                 if (__ballot(bre) != 0ull) {
                     if (bre) {
-                        float *bWp, *bGp;
-                        bias_ptrs(chosen, bWp, bGp);
-                        obW = *bWp;
-                        obG = *bGp;
+                        if (paired) obW = *pair_ptr(chosen);
+                        else {
+                            float *bWp, *bGp;
+                            bias_ptrs(chosen, bWp, bGp);
+                            obW = *bWp;
+                            obG = *bGp;
+                        }
                     }
                     __builtin_amdgcn_s_waitcnt(0x0F70);
                 }
@@ -422,8 +438,21 @@ __global__ __launch_bounds__(256, VEC == 1 ? LFM_NARROW_BLOCKS : 3) void fit_war
             {
                 float bnW, bnG, bnM;
                 double blr;
+                const float cell_own = obW;
+                if (paired) obG = __shfl(obW, lane + 3, WAVE);  // lanes p < 3: the accumulator cell from the lane that loaded it
                 cell_math(obW, obG, 0.0f, 1.0, p == 0 ? -lossd : lossd, h, 0.0, bnW, bnG, bnM, blr);
-                if (bupd && !(a.debug & 32768)) {  // (debug bit 15: experiment -- the bias cells are not published)
+                if (paired) {
+                    // lanes p < 3 publish the W cell, lanes 3..5 the G cell the lane three below computed: one instruction
+                    const float nG_up = __shfl(bnG, lane - 3, WAVE);
+                    const bool mine = act && chosen >= 0 && p < 6;
+                    const float nv = p < 3 ? bnW : nG_up;
+                    if (mine) {
+                        float *cp = pair_ptr(chosen);
+                        if (USTORE && (p == 2 || p == 5)) *cp = nv;
+                        else atomicAdd(cp, __fsub_rn(nv, cell_own));
+                    }
+                } else
+                if (bupd) {
                     float *bWp, *bGp;
                     bias_ptrs(chosen, bWp, bGp);
                     if (USTORE && p == 2) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
             const float *src = (k == KU ? Wu + (size_t)user * d : Wi + (uint32_t)it * (uint32_t)d) + 4 * piece;  // (item table < 4 GB: one 32-bit multiply)
             if (pc) dma_lane_x4(src, tile + (q * 3 + t) * QUAD);
         }
-        const float *bsrc = p == KU ? bu_tab + user : bi_tab + myitem;
+        const float *bsrc = p == KU ? bu_tab + (size_t)user * a.b_read_stride[1] : bi_tab + (size_t)myitem * a.b_read_stride[0];
         if (p <= KU) dma_lane_dword(bsrc, tile + BB + q * WAVE);
     };
 
@@ -177,6 +177,14 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
         // ---- Bloom pre-filter probes of the violators, the accumulator cells of the speculated updates, their bias cells
         float gP[Q], gN[Q], gU[Q], obW[Q], obG[Q];
         int maybe_pos[Q];
+        // bias cells as (b, bG) pairs of one line (FitArgs::bb): lanes 16 g + 0 / 1 / 2 hold the W cell of the positive item / the
+        // negative item / the user, lanes 16 g + 3 / 4 / 5 the accumulator cell next to it (as in warp_tile_ahead.hpp)
+        const bool paired = a.bb[0] != nullptr;
+        auto pair_ptr = [&](int q, int neg) -> float * {
+            const int role = p < 3 ? p : p - 3;
+            const int row = role == 2 ? cur[q].x : (role == 0 ? cur[q].y : neg);
+            return a.bb[role == 2 ? 1 : 0] + 2 * (size_t)row + (p < 3 ? 0 : 1);
+        };
         auto bias_ptrs = [&](int q, int neg, float *&bWp, float *&bGp) {
             if (p == 2) {
                 bWp = a.m.b[1] + cur[q].x;
@@ -203,7 +211,9 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
                     gN[q] = (Gi + (size_t)spec_cand[q] * d)[cc];
                     gU[q] = (Gu + (size_t)cur[q].x * d)[cc];
                 }
-                if (has_viol && p < 3) {
+                if (paired) {
+                    if (has_viol && p < 6) obW[q] = *pair_ptr(q, spec_cand[q]);
+                } else if (has_viol && p < 3) {
                     float *bWp, *bGp;
                     bias_ptrs(q, spec_cand[q], bWp, bGp);
                     obW[q] = *bWp;
@@ -270,7 +280,9 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
                         gN[q] = (Gi + (size_t)chosen[q] * d)[cc];
                         cN[q] = (WiW + (size_t)chosen[q] * d)[cc];
                     }
-                    if (re && p == 1) {
+                    if (paired) {
+                        if (re && (p == 1 || p == 4)) obW[q] = *pair_ptr(q, chosen[q]);
+                    } else if (re && p == 1) {
                         obW[q] = a.m.b[0][chosen[q]];
                         obG[q] = a.m.bG[0][chosen[q]];
                     }
@@ -305,7 +317,18 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
             {
                 float bnW, bnG, bnM;
                 double blr;
+                const float cell_own = obW[q];
+                if (paired) obG[q] = __shfl(obW[q], lane + 3, WAVE);
                 cell_math(obW[q], obG[q], 0.0f, 1.0, p == 0 ? -loss : loss, h, 0.0, bnW, bnG, bnM, blr);
+                if (paired) {
+                    const float nG_up = __shfl(bnG, lane - 3, WAVE);
+                    const float nv = p < 3 ? bnW : nG_up;
+                    if (upd && p < 6) {
+                        float *cp = pair_ptr(q, chosen[q]);
+                        if (USTORE && (p == 2 || p == 5)) *cp = nv;
+                        else atomicAdd(cp, __fsub_rn(nv, cell_own));
+                    }
+                } else
                 if (upd && p < 3) {
                     float *bWp, *bGp;
                     bias_ptrs(q, chosen[q], bWp, bGp);

@@ -75,11 +75,16 @@ def test_gather_ahead_kernel_budget_and_waits(tmp_path):
     variant is about -- no wait for outstanding memory operations between the top of a pass and the gather of the
     next one (a compiler-placed vmcnt(0) there would wait for the previous pass's atomics)."""
     k = _usage("warp_tile_ahead.hip", tmp_path)
-    FRAGS = ("fit_warp_tile_ahead_kernelILi10ELb0ELb0EEE", "fit_warp_tile_ahead_kernelILi10ELb1ELb0EEE",   # plain, owner-sharded items,
-             "fit_warp_tile_ahead_kernelILi10ELb0ELb1EEE")                                                  # user rows by plain stores
+    # <candidates, owner-sharded items, user rows by plain stores, floats of a row per lane>
+    FRAGS = ("fit_warp_tile_ahead_kernelILi10ELb0ELb0ELi4EEE", "fit_warp_tile_ahead_kernelILi10ELb1ELb0ELi4EEE",
+             "fit_warp_tile_ahead_kernelILi10ELb0ELb1ELi4EEE")
+    for frag in ("fit_warp_tile_narrow_kernelILi10ELb0EEE", "fit_warp_tile_narrow_kernelILi10ELb1EEE"):
+        u = _one(k, frag)  # the narrow-model kernel (warp_tile_narrow.hpp): four workgroups per CU, no scratch
+        assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 4, (frag, u)
     for frag in FRAGS:
         u = _one(k, frag)
-        assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 3, (frag, u)
+        # (three workgroups per CU -- the LDS tile's bound -- need <= 168 registers)
+        assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 168 and u["Occupancy"] >= 3, (frag, u)
     bodies = _asm("warp_tile_ahead.hip", tmp_path)
     for frag in FRAGS:
         lines = [b for n, b in bodies.items() if frag in n][0].splitlines()

@@ -1106,7 +1106,7 @@ except Exception as e:
 PY
   }
   S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 10 --warmup 3"
-  for i in 1 2; do for arm in "c2-d64:c2:64:" "c2-d64-nobias:c2:64:--debug 32768" "c2-d10:c2:10:" "c2-d10-nobias:c2:10:--debug 32768" "c4shard:c4shard:64:" "c4shard-nobias:c4shard:64:--debug 32768"; do
+  for i in 1 2; do for arm in "c2-d64:c2:64:" "c2-d64-nobias:c2:64:--debug 32768" "c2-d64-pairedbias:c2:64:--debug 65536" "c2-d10:c2:10:" "c2-d10-pairedbias:c2:10:--debug 65536"; do
     IFS=: read name cfg dd extra <<< "$arm"
     LIGHTFM_AMD_TILE_PAIRS=0 timeout 300 python3 bench.py $S --config $cfg --no-components $dd $extra > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "$name run $i" $OUT/${name}_$i.json
   done; done
@@ -1121,6 +1121,24 @@ r6v)
   timeout 1200 python3 tools/narrow_quality.py 40 2>&1 | tail -3
   NARROW_QUALITY_REF=0 LIGHTFM_AMD_TILE_PAIRS=0 timeout 600 python3 tools/narrow_quality.py 40 2>&1 | tail -1
   ( time timeout 900 $PYT tests/test_hip_warp_tile.py -m gpu -x -q -k narrow ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  ;;
+r6w)
+  # bias cells as (b, bG) pairs in the steady-state tile kernels: exactness suites, then A/B (LIGHTFM_AMD_BIAS_PAIRS=0) on c2 at d = 64 / 10 and the C4 shard
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py tests/test_hbm_shapes.py tests/test_sharded_items.py tests/test_hip_parity.py tests/test_lightfm_api.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-26s %8.2f M/s  frac %.3f  launch %.3f ms  U %.3f | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"], ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 15 --warmup 5"
+  for i in 1 2; do for arm in "c2-d64-pairs:c2:64:1" "c2-d64-separate:c2:64:0" "c2-d10-pairs:c2:10:1" "c2-d10-separate:c2:10:0" "c4shard-pairs:c4shard:64:1" "c4shard-separate:c4shard:64:0"; do
+    IFS=: read name cfg dd pairs <<< "$arm"
+    LIGHTFM_AMD_BIAS_PAIRS=$pairs timeout 300 python3 bench.py $S --config $cfg --no-components $dd > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "$name run $i" $OUT/${name}_$i.json
+  done; done
   ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
