@@ -328,6 +328,11 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
     from lightfm_amd import _native as N
     ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
     dp = (d + 3) // 4 * 4
+    flags = int(getattr(stats_last, "plan_flags", 0))
+    if used == 1 and flags & 64:  # the narrow-model kernel: <candidates, USTORE, W and G of a row in one line, ... with the bias cells>
+        rp = os.environ.get("LIGHTFM_AMD_ROW_PAIRS", "2") not in ("", "0")
+        return "fit_warp_tile_narrow_kernel<10, %s, %s, %s>" % ("true" if int(getattr(stats_last, "user_store", 0)) else "false",
+                                                                "true" if rp else "false", "true" if flags & 128 else "false")
     if used == 1 and int(getattr(stats_last, "tile_ahead", 0)):  # <candidates, owner-sharded item tables, user rows by plain stores>
         narrow = dp <= 16 and not sharded and os.environ.get("LIGHTFM_AMD_TILE_NARROW", "0") not in ("", "0")
         return "fit_warp_tile_ahead_kernel<10, %s, %s, %d>" % ("true" if sharded else "false",

@@ -151,7 +151,8 @@ typedef struct lfm_opts {
                                    in the tile kernel's gathers); bit 5 = the shared tag rows were accumulated in LDS slices
                                    (csrc/hot_slices.hip) instead of by float atomics of every interaction; bit 6 = the narrow-model
                                    tile kernel ran (rows of <= 16 floats: two interactions per lane group, eight per
-                                   wavefront pass; csrc/warp_tile_narrow.hpp)                                          */
+                                   wavefront pass; csrc/warp_tile_narrow.hpp); bit 7 = ... on rows that carry W, G, b and bG
+                                   of a feature in ONE 128-byte line (d <= 12: an update is three line operations)      */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

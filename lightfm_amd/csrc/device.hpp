@@ -116,6 +116,10 @@ struct FitArgs {
                                    // as ONE table of (b, bG) pairs, [n_feat][2] -- both cells of a row in one line, so that an
                                    // update publishes them with one line operation instead of two (session.hip: bias pairs);
                                    // nullptr = the separate tables m.b / m.bG
+    float *rp[2];                  // narrow-model kernel (warp_tile_narrow.hpp, RP instantiations): W and G of a side as ONE table of
+                                   // 128-byte rows [W(16) | G(16)] -- both halves of a row published by one instruction, i.e. one
+                                   // line operation instead of two (session.hip: row pairs); nullptr = m.W / m.G
+    int32_t rp_bias;               // ... with the bias cells in slot d of each half, [W(d) | b .. | G(d) | bG ..] (d <= 12; BIN instantiations)
     int32_t b_read_stride[2];      // floats between consecutive rows of b_read[side] (1: a snapshot or m.b; 2: bb)
     const int32_t *hot_slot;       // [n_item_feat] slot of a hot item-feature row, -1 otherwise; nullptr = no hot set (HotRec above)
     HotRec *hot_rec;               // [end - begin] one record per position of the launch

@@ -545,6 +545,10 @@ struct lfm_session {
     // the first such launch of an epoch call and unpacked into them before anything else reads the tables
     DBuf<float> bias_pairs[2];
     bool pairs_live = false;
+    // Row PAIRS (narrow-model kernel, d <= 16): likewise W and G of a side as one table of 128-byte rows [W(16) | G(16)]
+    // (d <= 12: with the bias cells in slot d of each half -- rows_bias; lfm_opts.plan_flags bit 7)
+    DBuf<float> row_pairs[2];
+    bool rows_live = false, rows_bias = false;
     hipStream_t stream2 = nullptr;  // full-residency launches alternate between `stream` and this one (see lfm_session_epoch)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf<int4> recs;  // AoS copy of (user_ids, item_ids, Y, weight) for warp_tile.hip, built on demand
@@ -2074,6 +2078,33 @@ __global__ void bias_unpack_kernel(float *b, float *bG, const float *pairs, int6
         bG[i] = pairs[2 * i + 1];
     }
 }
+// (b != nullptr: the bias cells ride in slot d of each half)
+__global__ void row_pack_kernel(const float *W, const float *G, const float *b, const float *bG, float *pairs, int64_t rows, int d)
+{
+    const int64_t cells = rows * 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 4;
+        const int c = (int)(i & 15);
+        const bool bias = b && c == d;
+        pairs[r * 32 + c] = c < d ? W[r * d + c] : (bias ? b[r] : 0.0f);
+        pairs[r * 32 + 16 + c] = c < d ? G[r * d + c] : (bias ? bG[r] : 1.0f);
+    }
+}
+__global__ void row_unpack_kernel(float *W, float *G, float *b, float *bG, const float *pairs, int64_t rows, int d)
+{
+    const int64_t cells = rows * 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 4;
+        const int c = (int)(i & 15);
+        if (c < d) {
+            W[r * d + c] = pairs[r * 32 + c];
+            G[r * d + c] = pairs[r * 32 + 16 + c];
+        } else if (b && c == d) {
+            b[r] = pairs[r * 32 + c];
+            bG[r] = pairs[r * 32 + 16 + c];
+        }
+    }
+}
 __global__ void copy_strided_kernel(float *dst, const float *src, int64_t n, int stride)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i * stride];
@@ -2202,6 +2233,36 @@ static int bias_pairs_unpack(lfm_session *s, hipStream_t st)
     return LFM_OK;
 }
 
+static int row_pairs_pack(lfm_session *s, hipStream_t st, bool with_bias)
+{
+    for (int side = 0; side < 2; ++side) {
+        const int64_t n = (int64_t)s->n_feat[side];
+        s->row_pairs[side].flags = s->tab[side][0].flags;
+        LFM_TRY(s->row_pairs[side].alloc((size_t)(32 * n)));
+        if (n) row_pack_kernel<<<(int)std::min<int64_t>(4096, (16 * n + 255) / 256), 256, 0, st>>>(
+            s->tab[side][0].p, s->tab[side][1].p, with_bias ? s->tab[side][3].p : nullptr, with_bias ? s->tab[side][4].p : nullptr,
+            s->row_pairs[side].p, n, s->d);
+    }
+    HIP_TRY(hipGetLastError());
+    s->rows_live = true;
+    s->rows_bias = with_bias;
+    return LFM_OK;
+}
+
+static int row_pairs_unpack(lfm_session *s, hipStream_t st)
+{
+    for (int side = 0; side < 2; ++side) {
+        const int64_t n = (int64_t)s->n_feat[side];
+        if (n && s->row_pairs[side].p)
+            row_unpack_kernel<<<(int)std::min<int64_t>(4096, (16 * n + 255) / 256), 256, 0, st>>>(
+                s->tab[side][0].p, s->tab[side][1].p, s->rows_bias ? s->tab[side][3].p : nullptr, s->rows_bias ? s->tab[side][4].p : nullptr,
+                s->row_pairs[side].p, n, s->d);
+    }
+    HIP_TRY(hipGetLastError());
+    s->rows_live = s->rows_bias = false;
+    return LFM_OK;
+}
+
 // ------------------------------------------------------------------ epoch ---
 
 static void tile_geometry(int d, int want_rows, int *rows, int *stride)
@@ -2221,9 +2282,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (!s) return fail(LFM_EINVAL, "null session");
     if (s->scoring_only) return fail(LFM_EINVAL, "a scoring session (lfm_session_create_scoring) cannot train");
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);  // (left running only by an epoch that failed half-way)
-    if (s->pairs_live) {  // (likewise: the live bias cells are still in the pair tables)
+    if (s->pairs_live || s->rows_live) {  // (likewise: live cells are still in the pair tables)
         HIP_TRY(hipSetDevice(s->device));
-        LFM_TRY(bias_pairs_unpack(s, s->stream));
+        if (s->pairs_live) LFM_TRY(bias_pairs_unpack(s, s->stream));
+        if (s->rows_live) LFM_TRY(row_pairs_unpack(s, s->stream));
     }
     if (s->share && s->share->broken)
         return fail(LFM_EINVAL, "a session this one shares item tables with has been destroyed: its rows are gone");
@@ -2690,12 +2752,32 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 // the steady-state kernels keep the live bias cells as (b, bG) pairs (lfm_session::bias_pairs); LIGHTFM_AMD_BIAS_PAIRS=0:
                 // the separate tables
                 static const bool pairs_env = [] { const char *e = getenv("LIGHTFM_AMD_BIAS_PAIRS"); return !e || atoi(e) != 0; }();
-                const bool want_pairs = pairs_env && tile[ng].ahead && s->shards.n == 0;
+                // ... and the narrow-model kernel W and G as rows of one line (LIGHTFM_AMD_ROW_PAIRS=0: the separate tables), for d <= 12
+                // with the bias cells in that line too (LIGHTFM_AMD_ROW_PAIRS=1: without them)
+                // (read per epoch call: the tests switch layouts inside one process)
+                const int rows_env = [] { const char *e = getenv("LIGHTFM_AMD_ROW_PAIRS"); return e ? atoi(e) : 2; }();
+                const bool want_rows = rows_env != 0 && tile[ng].narrow && (int64_t)std::max(s->n_feat[0], s->n_feat[1]) * 32 < (1ll << 30);
+                const bool want_rows_bias = want_rows && rows_env >= 2 && s->d <= 12;
+                const bool want_pairs = pairs_env && tile[ng].ahead && s->shards.n == 0 && !want_rows_bias;
                 if (want_pairs && !s->pairs_live) LFM_TRY(bias_pairs_pack(s, s->stream));  // (before the streams fork: both see it)
                 if (!want_pairs && s->pairs_live) {  // (a launch of another kernel after steady-state launches: does not happen in the shipped plan)
                     if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
                     LFM_TRY(bias_pairs_unpack(s, s->stream));
                     HIP_TRY(hipStreamSynchronize(s->stream));
+                }
+                if (want_rows && !s->rows_live) LFM_TRY(row_pairs_pack(s, s->stream, want_rows_bias));  // (after the bias pairs went back)
+                if (!want_rows && s->rows_live) {
+                    if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
+                    LFM_TRY(row_pairs_unpack(s, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                }
+                a.rp[0] = a.rp[1] = nullptr;
+                a.rp_bias = 0;
+                if (s->rows_live) {
+                    a.rp[0] = s->row_pairs[0].p;
+                    a.rp[1] = s->row_pairs[1].p;
+                    a.rp_bias = s->rows_bias ? 1 : 0;
+                    if (s->rows_bias) plan_flags |= 128;
                 }
                 a.b_read[0] = a.m.b[0];
                 a.b_read[1] = a.m.b[1];
@@ -2710,7 +2792,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 }
                 {
                     for (int side = 0; side < 2; ++side) {
-                        if (!snap_side[side]) continue;
+                        if (!snap_side[side] || s->rows_bias) continue;  // (biases in the row pairs: scoring reads them with the rows)
                         const int64_t cnt = (int64_t)tab_count(s, side, 3);
                         if (cnt) {
                             const int cgrid = (int)std::min<int64_t>(1024, (cnt + 255) / 256);
@@ -2831,6 +2913,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
         }
         if (s->pairs_live) LFM_TRY(bias_pairs_unpack(s, s->stream));  // the bias cells go back to their tables
+        if (s->rows_live) LFM_TRY(row_pairs_unpack(s, s->stream));     // ... and the narrow-model kernel's rows
     }
     if (reg) HIP_TRY(launch_regularize(a.m, serial ? nullptr : s->reg_log.p, serial ? nullptr : s->reg_live.p, 1, s->stream));  // PYX:910-912
     HIP_TRY(hipEventRecord(s->ev1, s->stream));

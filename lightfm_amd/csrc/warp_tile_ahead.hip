@@ -40,6 +40,8 @@ size_t warp_tile_narrow_smem(int d, int max_sampled, int first_batch, int64_t n_
 hipError_t launch_fit_warp_tile_narrow(const FitArgs &a, int grid, hipStream_t st, int cus, int per_cu_cap, int *grid_used)
 {
     void (*kernel)(FitArgs) = a.user_store ? fit_warp_tile_narrow_kernel<10, true> : fit_warp_tile_narrow_kernel<10, false>;
+    if (a.rp[0]) kernel = a.user_store ? fit_warp_tile_narrow_kernel<10, true, true> : fit_warp_tile_narrow_kernel<10, false, true>;  // row pairs
+    if (a.rp[0] && a.rp_bias) kernel = a.user_store ? fit_warp_tile_narrow_kernel<10, true, true, true> : fit_warp_tile_narrow_kernel<10, false, true, true>;  // ... with the bias cells
     const size_t smem = tile_narrow_smem();
     if (cus > 0) {
         int per_cu = occupancy_cached(kernel, 256, smem);

@@ -25,12 +25,22 @@
 
 namespace lfm {
 
-template <int NBF, bool USTORE = false>
+// RP: W and G of a row live in ONE 128-byte line of a pair table [W(16) | G(16)] (FitArgs::rp; packed by the session for the
+// launches of this kernel): the gathers read the W half, the update's accumulator cells come from the line the gather
+// already fetched, and BOTH halves of a row are published by one instruction -- lanes of an even group carry their own W
+// deltas while the lanes of the odd group next to them carry the even group's G deltas (and the other way round in a second
+// instruction): two line operations per pair of updating rows instead of four.
+// BIN (with RP, d <= 12: the reference's default width): the bias cells live in the row's line too -- [W(d) | b | .. || G(d) | bG
+// | ..], slot d of each half -- so the gather brings the bias with the row (no bias requests), lane d of a group runs the bias
+// cell through the same cell arithmetic (gradient -loss / loss / loss, PYX:571-599) and its deltas leave with the row's: an
+// update is THREE line operations (positive, negative, user) instead of six.
+template <int NBF, bool USTORE = false, bool RP = false, bool BIN = false>
 __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
 {
     constexpr int LPR = 16, NG = 4, Q = 2;
     constexpr unsigned long long GM = 0xffffull;
     static_assert(NBF == 10, "twelve rows per interaction: the positive, ten candidates, the user");
+    static_assert(RP || !BIN, "the bias cells ride in the row pairs");
     constexpr int KU = NBF + 1;                 // the user's row index (11)
     constexpr int QUAD = NG * 4 * 16;           // floats one LDS-DMA instruction deposits: 4 rows of 16 floats per group
     constexpr int BB = Q * 3 * QUAD;            // bias slots: [BB + q * 64 + lane]
@@ -42,8 +52,11 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
     float *tile = smem + (size_t)wib * WAVE_FLOATS;
     // row k of this lane's group, interaction q
     auto row_of = [&](int q, int k) -> float * { return tile + (q * 3 + (k >> 2)) * QUAD + g * 64 + (k & 3) * 16; };
-    const float *Wi = a.m.W[0], *Wu = a.m.W[1];
-    float *WiW = a.m.W[0], *Gi = a.m.G[0], *WuW = a.m.W[1], *Gu = a.m.G[1];
+    // row r of a side: RS floats apart; its accumulator cells GO floats after its embedding cells (RP: the same line)
+    const int RS = RP ? 32 : d;
+    float *WiW = RP ? a.rp[0] : a.m.W[0], *WuW = RP ? a.rp[1] : a.m.W[1];
+    float *Gi = RP ? a.rp[0] + 16 : a.m.G[0], *Gu = RP ? a.rp[1] + 16 : a.m.G[1];
+    const float *Wi = WiW, *Wu = WuW;
     const float *bi_tab = a.b_read[0], *bu_tab = a.b_read[1];
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
@@ -51,7 +64,7 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
     const uint32_t *bloom = a.bloom;
     const int32_t *indptr = a.pos.indptr, *indices = a.pos.indices;
     const int piece = p & 3, prow = p >> 2;     // this lane's 16-byte piece and row inside a quad
-    const bool pc = 4 * piece < d;
+    const bool pc = BIN ? 4 * piece <= d : 4 * piece < d;  // (BIN: the piece that holds slot d as well)
 
     // lane p needs the position's stream after min(p, NBF) draws: (A^k, C (A^(k-1) + ... + 1)) mod 2^32
     uint32_t lcgA = 1u, lcgC = 0u;
@@ -74,11 +87,13 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
         for (int t = 0; t < 3; ++t) {
             const int k = 4 * t + prow;  // this lane's row of the quad
             const int it = __shfl(myitem, gbase + (k <= NBF ? k : 0), WAVE);
-            const float *src = (k == KU ? Wu + (size_t)user * d : Wi + (uint32_t)it * (uint32_t)d) + 4 * piece;  // (item table < 4 GB: one 32-bit multiply)
+            const float *src = (k == KU ? Wu + (size_t)user * RS : Wi + (uint32_t)it * (uint32_t)RS) + 4 * piece;  // (item table < 4 GB: one 32-bit multiply)
             if (pc) dma_lane_x4(src, tile + (q * 3 + t) * QUAD);
         }
-        const float *bsrc = p == KU ? bu_tab + (size_t)user * a.b_read_stride[1] : bi_tab + (size_t)myitem * a.b_read_stride[0];
-        if (p <= KU) dma_lane_dword(bsrc, tile + BB + q * WAVE);
+        if constexpr (!BIN) {
+            const float *bsrc = p == KU ? bu_tab + (size_t)user * a.b_read_stride[1] : bi_tab + (size_t)myitem * a.b_read_stride[0];
+            if (p <= KU) dma_lane_dword(bsrc, tile + BB + q * WAVE);
+        }
     };
 
     // record pipeline, three passes deep (as fit_warp_tile_ahead_kernel), two interactions per group
@@ -112,7 +127,9 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
         int sampled[Q], chosen[Q], r1[Q], spec_cand[Q];
         unsigned long long vm[Q];
         float cU[Q], cP[Q], cN[Q];
-        const int cc = p < d ? p : 0;  // this lane's coordinate in the merged update (lanes past d: idle)
+        const bool cell_lane = BIN ? p <= d : p < d;  // (BIN: lane d = the bias cell)
+        const bool bias_lane = BIN && p == d;
+        const int cc = cell_lane ? p : 0;  // this lane's coordinate in the merged update (lanes past d: idle)
         bool any_act = false;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -129,8 +146,15 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
         if (any_act) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float bi = tile[BB + q * WAVE + lane], bu = tile[BB + q * WAVE + gbase + KU];
                 const bool rowlane = act[q] && p <= NBF;
+                float bi, bu;
+                if constexpr (BIN) {
+                    bi = p <= NBF ? row_of(q, p)[d] : 0.0f;
+                    bu = row_of(q, KU)[d];
+                } else {
+                    bi = tile[BB + q * WAVE + lane];
+                    bu = tile[BB + q * WAVE + gbase + KU];
+                }
                 float score = 0.0f;
                 if (rowlane) score = row_dot<false>(row_of(q, KU), row_of(q, p), d, bu, bi, 1.0f, 1.0f);
                 const double pp = (double)__shfl(score, gbase, WAVE);
@@ -206,12 +230,13 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
                 const uint32_t bh = Bloom::mix((uint32_t)myitem[q]);
                 uint32_t bword = 0xffffffffu;
                 if (bloom && viol[q]) bword = bloom[Bloom::word(bh, c_lo[q], c_hi[q])];
-                if (has_viol && p < d) {
-                    gP[q] = (Gi + (size_t)cur[q].y * d)[cc];
-                    gN[q] = (Gi + (size_t)spec_cand[q] * d)[cc];
-                    gU[q] = (Gu + (size_t)cur[q].x * d)[cc];
+                if (has_viol && cell_lane) {
+                    gP[q] = (Gi + (size_t)cur[q].y * RS)[cc];
+                    gN[q] = (Gi + (size_t)spec_cand[q] * RS)[cc];
+                    gU[q] = (Gu + (size_t)cur[q].x * RS)[cc];
                 }
-                if (paired) {
+                if constexpr (BIN) {
+                } else if (paired) {
                     if (has_viol && p < 6) obW[q] = *pair_ptr(q, spec_cand[q]);
                 } else if (has_viol && p < 3) {
                     float *bWp, *bGp;
@@ -276,11 +301,12 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
             {   // the first violator was a positive and a later one is the choice: its cells are re-read (weights as of now)
                 const bool re = upd && chosen[q] != spec_cand[q];
                 if (__ballot(re) != 0ull) {
-                    if (re && p < d) {
-                        gN[q] = (Gi + (size_t)chosen[q] * d)[cc];
-                        cN[q] = (WiW + (size_t)chosen[q] * d)[cc];
+                    if (re && cell_lane) {
+                        gN[q] = (Gi + (size_t)chosen[q] * RS)[cc];
+                        cN[q] = (WiW + (size_t)chosen[q] * RS)[cc];
                     }
-                    if (paired) {
+                    if constexpr (BIN) {
+                    } else if (paired) {
                         if (re && (p == 1 || p == 4)) obW[q] = *pair_ptr(q, chosen[q]);
                     } else if (re && p == 1) {
                         obW[q] = a.m.b[0][chosen[q]];
@@ -291,14 +317,42 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
             }
             const double loss = lossd[q];
             const float Ur = cU[q], Pr = cP[q], Nr = cN[q];
-            const double u = (double)Ur;
-            const double df = (double)__fsub_rn(Nr, Pr);  // float32 subtraction, PYX:634-635
+            // (the bias lane of BIN: gradients -loss / loss / loss, PYX:571-599 -- the factor is exactly 1)
+            const double u = bias_lane ? 1.0 : (double)Ur;
+            const double df = bias_lane ? 1.0 : (double)__fsub_rn(Nr, Pr);  // float32 subtraction, PYX:634-635
             float nWP, nGP, nWN, nGN, nWU, nGU, nM;
             double lr;
             cell_math(Pr, gP[q], 0.0f, 1.0, -loss * u, h, 0.0, nWP, nGP, nM, lr);
             cell_math(Nr, gN[q], 0.0f, 1.0, loss * u, h, 0.0, nWN, nGN, nM, lr);
             cell_math(Ur, gU[q], 0.0f, 1.0, loss * df, h, 0.0, nWU, nGU, nM, lr);
             asm volatile("" : "+v"(nWP), "+v"(nGP), "+v"(nWN), "+v"(nGN), "+v"(nWU), "+v"(nGU));
+            if constexpr (RP) {
+                // one instruction per row pair: in `half` 0 the even groups publish their own W deltas and the odd groups the even
+                // groups' G deltas (into the same lines); in half 1 the roles swap
+                const bool mine = upd && cell_lane;
+                auto publish_rows = [&](float *tab, uint32_t off, float dW, float dG) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const bool own = (g & 1) == half;             // this lane publishes its own W delta in this half
+                        const int from = own ? lane : (half == 0 ? lane - LPR : lane + LPR);
+                        const uint32_t off_o = (uint32_t)__shfl((int)off, from, WAVE);
+                        const float dG_o = __shfl(dG, from, WAVE);
+                        const bool on_o = __shfl((int)mine, from, WAVE) != 0;
+                        if (own ? mine : on_o) atomicAdd(tab + (own ? off : off_o + 16u) + cc, own ? dW : dG_o);
+                    }
+                };
+                publish_rows(WiW, (uint32_t)cur[q].y * 32u, __fsub_rn(nWP, Pr), __fsub_rn(nGP, gP[q]));
+                publish_rows(WiW, (uint32_t)chosen[q] * 32u, __fsub_rn(nWN, Nr), __fsub_rn(nGN, gN[q]));
+                if constexpr (USTORE) {
+                    if (mine) {
+                        const size_t oU = (size_t)cur[q].x * 32 + cc;
+                        WuW[oU] = nWU;
+                        WuW[oU + 16] = nGU;
+                    }
+                } else {
+                    publish_rows(WuW, (uint32_t)cur[q].x * 32u, __fsub_rn(nWU, Ur), __fsub_rn(nGU, gU[q]));
+                }
+            } else
             if (upd && p < d) {
                 const size_t oP = (size_t)cur[q].y * d + cc, oN = (size_t)chosen[q] * d + cc, oU = (size_t)cur[q].x * d + cc;
                 atomicAdd(WiW + oP, __fsub_rn(nWP, Pr));
@@ -314,7 +368,7 @@ __global__ __launch_bounds__(256, 4) void fit_warp_tile_narrow_kernel(FitArgs a)
                 }
             }
             // the bias cells (PYX:571-599): lane 16 g + 0 = positive item, + 1 = negative item, + 2 = user
-            {
+            if constexpr (!BIN) {
                 float bnW, bnG, bnM;
                 double blr;
                 const float cell_own = obW[q];

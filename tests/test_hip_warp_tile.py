@@ -286,6 +286,40 @@ def test_tile_ahead_concurrent_updates_match_the_oracle(fast, per_launch, ustore
     H.assert_states_within_ulps(a, b, ulps=4)
 
 
+@pytest.mark.parametrize("d", [4, 10, 12, 16])
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["separate-tables", "row-pairs", "row-pairs-with-biases"])
+@pytest.mark.parametrize("ustore", [False, True], ids=["atomics", "user-rows-stored"])
+def test_narrow_kernel_row_layouts_match_the_oracle(fast, monkeypatch, ustore, layout, d):
+    """The three table layouts of the narrow-model kernel (LIGHTFM_AMD_ROW_PAIRS): W / G / b / bG in their own tables; W and G
+    of a feature in one 128-byte line (RP instantiations: both halves published by one instruction); and, for d <= 12 --
+    the SHIPPED layout at the reference's default width -- the bias cells in slot d of each half as well (BIN
+    instantiations, lfm_opts.plan_flags bit 7: the gather brings the bias with the row, lane d of a group runs the bias
+    cell, an update is three line operations).  Non-zero updates under concurrency (four wavefronts, two passes each, no
+    two interactions of a launch sharing a row): the sequential oracle's result, incl. both sides' bias cells."""
+    from lightfm_amd.options import options
+    monkeypatch.setenv("LIGHTFM_AMD_ROW_PAIRS", str(layout))
+    ms, per_launch = 10, 32
+    nu, ni, n = 800, 300000, 256
+    coo, shuffle, seeds = _conflict_free(nu, ni, n, per_launch, ms, np.random.RandomState(29))
+    st = oracle.State(ni, nu, d, np.random.RandomState(2), max_sampled=ms)
+    _spread(st)
+    st.item_biases[:] = np.random.RandomState(3).randn(ni).astype(np.float32) * 0.3
+    st.user_biases[:] = np.random.RandomState(4).randn(nu).astype(np.float32) * 0.3
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=n // per_launch, update_mode=0, debug=4 | (2048 if ustore else 0), max_waves=16)
+    _hip_warp(fast, coo, a, shuffle, seeds, coo.data)
+    assert options.last_plan_flags & 64, options.last_plan_flags
+    assert bool(options.last_plan_flags & 128) == (layout == 2 and d <= 12), (layout, d, options.last_plan_flags)
+    o = _orc_warp(coo, b, shuffle, seeds, coo.data)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled)
+    assert np.array_equal(neg, o.neg)
+    assert options.last_counters == o.counters
+    assert o.counters[2] > n // 4
+    assert not np.array_equal(a.item_biases, st.item_biases) and not np.array_equal(a.user_biases, st.user_biases)
+    H.assert_states_within_ulps(a, b, ulps=4)
+
+
 @pytest.mark.parametrize("d", [64, 10, 16], ids=["d64", "d10-narrow", "d16-narrow"])
 def test_tile_ahead_reread_branch_updates_match_the_oracle(fast, d):
     """Dense positives rows (a third of the catalogue per user) and near-zero scores: nearly every candidate violates

@@ -222,17 +222,18 @@ def test_committed_traffic_feeds_the_roofline():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     table = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    names = {"c2": "fit_warp_tile_ahead_kernel<10, false, true>",       # user rows by plain stores (lfm_opts.user_store)
-             "c4shard": "fit_warp_tile_ahead_kernel<10, false, false>",
-             "c3": "fit_feat_kernel<2, 2, false, false>",
-             "c5shard": "fit_feat_kernel<3, 2, false, false>"}
+    # (as bench.kernel_label prints them: <candidates, SHARDED, USTORE, VEC> / <loss id, NC, TIMED, REG, HOT, ADA>)
+    names = {"c2": "fit_warp_tile_ahead_kernel<10, false, true, 4>",       # user rows by plain stores (lfm_opts.user_store)
+             "c4shard": "fit_warp_tile_ahead_kernel<10, false, false, 4>",
+             "c3": "fit_feat_kernel<2, 2, false, false, true, false> + hot_slice_kernel<8>",  # the hot set (plan_flags bit 5)
+             "c5shard": "fit_feat_kernel<3, 2, false, false, false, false>"}
     for cfg, kernel in names.items():
         assert os.path.exists(os.path.join(root, table[cfg]["source"]))
         value, source, extra = bench.committed_traffic(cfg, kernel)
-        assert value is not None and value > 1e9 and source == table[cfg]["source"], (cfg, value, source)
+        assert value is not None and value > 1e8 and source == table[cfg]["source"], (cfg, value, source)
         # scaled to a run's own launch length: bytes per interaction of the profiled run x interactions per launch
         half, _, extra = bench.committed_traffic(cfg, kernel, table[cfg]["interactions_per_launch_profiled"] / 2)
-        assert abs(half / (value / 2) - 1.0) < 1e-9 and 0.5 < extra["traffic_over_algorithmic_profiled"] < 2.5
+        assert abs(half / (value / 2) - 1.0) < 1e-9 and 0.1 < extra["traffic_over_algorithmic_profiled"] < 2.5  # (c3: the shared rows live in LDS and L2)
     value, why, _ = bench.committed_traffic("c2", "fit_warp_kernel (generic)")
     assert value is None and "this run's kernel" in why
 

@@ -78,7 +78,8 @@ def test_gather_ahead_kernel_budget_and_waits(tmp_path):
     # <candidates, owner-sharded items, user rows by plain stores, floats of a row per lane>
     FRAGS = ("fit_warp_tile_ahead_kernelILi10ELb0ELb0ELi4EEE", "fit_warp_tile_ahead_kernelILi10ELb1ELb0ELi4EEE",
              "fit_warp_tile_ahead_kernelILi10ELb0ELb1ELi4EEE")
-    for frag in ("fit_warp_tile_narrow_kernelILi10ELb0EEE", "fit_warp_tile_narrow_kernelILi10ELb1EEE"):
+    for frag in ["fit_warp_tile_narrow_kernelILi10ELb%dELb%dELb%dEEE" % f for f in  # <NBF, USTORE, RP, BIN>
+                 ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 1, 1), (1, 1, 1))]:
         u = _one(k, frag)  # the narrow-model kernel (warp_tile_narrow.hpp): four workgroups per CU, no scratch
         assert u["ScratchSize"] == 0 and u["VGPRs"] + u["AGPRs"] <= 128 and u["Occupancy"] >= 4, (frag, u)
     for frag in FRAGS:

@@ -126,6 +126,25 @@ def test_warp_identity_c2_regime_regularised():
     _gap("warp", 64, train, test, None, epochs=5, item_alpha=1e-6, user_alpha=1e-6)
 
 
+@pytest.mark.timeout(900)
+def test_logistic_with_explicit_negatives():
+    """fit_logistic (PYX:694-781) in the SHIPPED (parallel) mode -- round-5 verdict, weak #3: the one loss without a quality
+    gate of its own.  Logistic needs both labels: the train split's positives plus as many uniformly drawn (user, item)
+    pairs with the value -1 (PYX:744-748: y <= 0 is the label 0); precision@10 on the held-out positives, as for the
+    other losses.  Identity features, no_components = 64: the row-stream kernel's logistic instantiation."""
+    import scipy.sparse as sp
+    train, test = _data(8656, 6686, 1_000_000)
+    rng = np.random.RandomState(5)
+    nu, ni = train.shape
+    neg_r = rng.randint(0, nu, size=train.nnz).astype(np.int32)
+    neg_c = rng.randint(0, ni, size=train.nnz).astype(np.int32)
+    order = rng.permutation(2 * train.nnz)
+    both = sp.coo_matrix((np.concatenate([np.ones(train.nnz, np.float32), -np.ones(train.nnz, np.float32)])[order],
+                          (np.concatenate([train.row, neg_r])[order], np.concatenate([train.col, neg_c])[order])),
+                         shape=train.shape, dtype=np.float32)
+    _gap("logistic", 64, both, test, None, epochs=5, n_seeds=8)
+
+
 def _small_seeds(default):
     return int(os.environ.get("LFM_SMALL_GATE_SEEDS", default))
 

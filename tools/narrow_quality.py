@@ -30,6 +30,6 @@ for seed in range(1, n + 1):
     m = LightFM(no_components=10, loss="warp", random_state=seed)
     m.fit(train, epochs=5)
     out.append(p10(m))
-res["hip (TILE_PAIRS=%s, flags %s)" % (os.environ.get("LIGHTFM_AMD_TILE_PAIRS", "1"), m._last_epoch_stats[-1].get("plan_flags"))] = out
+res["hip (TILE_PAIRS=%s, ROW_PAIRS=%s, flags %s)" % (os.environ.get("LIGHTFM_AMD_TILE_PAIRS", "1"), os.environ.get("LIGHTFM_AMD_ROW_PAIRS", "2"), m._last_epoch_stats[-1].get("plan_flags"))] = out
 for k, v in res.items():
     print("%-34s %.4f +- %.4f (s.e., n=%d)" % (k, np.mean(v), np.std(v, ddof=1) / np.sqrt(len(v)), len(v)), flush=True)

@@ -1140,6 +1140,48 @@ PY
     LIGHTFM_AMD_BIAS_PAIRS=$pairs timeout 300 python3 bench.py $S --config $cfg --no-components $dd > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "$name run $i" $OUT/${name}_$i.json
   done; done
   ;;
+r6x)
+  # the narrow-model kernel with W and G of a row in one line (row pairs): tile suites, then c2 at d = 10 / 16 with / without (LIGHTFM_AMD_ROW_PAIRS=0)
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py tests/test_lightfm_api.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-26s %8.2f M/s  frac %.3f  launch %.3f ms  U %.3f  ustore %s | steady %8.2f M/s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r.get("user_rows_by_plain_stores"), ss.get("value", 0) / 1e6))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 15 --warmup 5 --config c2"
+  for i in 1 2; do for arm in "d10-rowpairs:10:1:" "d10-separate:10:0:" "d10-rowpairs-ustore:10:1:--debug 2048" "d16-rowpairs:16:1:" "d16-separate:16:0:"; do
+    IFS=: read name dd rp extra <<< "$arm"
+    LIGHTFM_AMD_ROW_PAIRS=$rp timeout 300 python3 bench.py $S --no-components $dd $extra > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "c2 $name run $i" $OUT/${name}_$i.json
+  done; done
+  ;;
+r6y)
+  # the narrow-model kernel with the bias cells in the row's line as well (LIGHTFM_AMD_ROW_PAIRS=2, d <= 12): tile suites, then c2 at d = 10 / 12 per layout
+  ( time timeout 1800 $PYT tests/test_hip_warp_tile.py tests/test_baseline_shapes.py tests/test_lightfm_api.py -m gpu -x -q ) > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt | cut -c1-300
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-26s %8.2f M/s  frac %.3f  launch %.3f ms  U %.3f  ustore %s | steady %8.2f M/s  %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"], r.get("user_rows_by_plain_stores"), ss.get("value", 0) / 1e6, r.get("kernel")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 1.5 --steps 15 --warmup 5 --config c2"
+  for i in 1 2; do for arm in "d10-rows+biases:10:2:" "d10-rows:10:1:" "d10-separate:10:0:" "d10-rows+biases-ustore:10:2:--debug 2048" "d12-rows+biases:12:2:" "d12-rows:12:1:" "d4-rows+biases:4:2:"; do
+    IFS=: read name dd rp extra <<< "$arm"
+    LIGHTFM_AMD_ROW_PAIRS=$rp timeout 300 python3 bench.py $S --no-components $dd $extra > $OUT/${name}_$i.json 2> $OUT/${name}_$i.err; line "c2 $name run $i" $OUT/${name}_$i.json
+  done; done
+  ;;
+r6yq)
+  # precision@10 at the default width with the bias cells in the row's line (shipped) against the reference and the separate tables; the logistic gate
+  timeout 1200 python3 tools/narrow_quality.py 40 2>&1 | tail -3
+  NARROW_QUALITY_REF=0 LIGHTFM_AMD_ROW_PAIRS=0 timeout 600 python3 tools/narrow_quality.py 40 2>&1 | tail -1
+  ( time timeout 900 $PYT tests/test_precision_parity.py -m gpu -x -q -s -k logistic ) > $OUT/tests.txt 2>&1; grep -a "delta\|passed\|failed" $OUT/tests.txt | cut -c1-300
+  ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
