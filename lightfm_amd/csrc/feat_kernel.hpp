@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                                 else publish_cell(Wp + c, Gp + c, Mp + c, oW, oG, oM, nW, nG, nM, wt, gcell, h, al, um);
                             } else {
                                 publish(Wp + c, nW, oW, (st_ && ustore) ? 1 : um);
-                                publish(Gp + c, nG, oG, (st_ && ustore) ? 1 : um);
+                                if (!(a.debug & 65536)) publish(Gp + c, nG, oG, (st_ && ustore) ? 1 : um);  // (timing experiment, WRONG results: no accumulator rows)
                             }
                             if constexpr (REG) lr_sum += c < a.m.d_real ? lr : 0.0;
                         }
@@ -528,8 +528,10 @@ __global__ __launch_bounds__(256, LFM_FEAT_MIN_BLOCKS(LOSS, TIMED, ADA)) void fi
                         if (um == 0) lr = publish_adadelta(bp, bgp, bmp, obW, obG, obM, (double)e.w, gb, h, alb);
                         else publish_cell(bp, bgp, bmp, obW, obG, obM, nW, nG, nM, (double)e.w, gb, h, alb, um);
                     } else {
-                        publish(bp, nW, obW, (e.eside && ustore) ? 1 : um);
-                        publish(bgp, nG, obG, (e.eside && ustore) ? 1 : um);
+                        if (!(a.debug & 32768)) {  // (timing experiment, WRONG results: no bias publication)
+                            publish(bp, nW, obW, (e.eside && ustore) ? 1 : um);
+                            publish(bgp, nG, obG, (e.eside && ustore) ? 1 : um);
+                        }
                     }
                     if constexpr (REG) lr_sum += lr;
                 }

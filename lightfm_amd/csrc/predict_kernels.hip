@@ -826,10 +826,33 @@ void ranks_mfma3_kernel(RanksArgs a)
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(off) : "v"(tm), "n"(iA));
                 acc[r] = __int_as_float(off & (int)0xff800000);
             }
+#if LFM_R3X == 4
+            // timing experiment (WRONG ranks): the products on the bf16 matrix pipe -- two-way split operands in the SAME registers
+            // (KSTEPS / 8 steps of 16 components x {hi hi, hi lo, lo hi}) + one step for the item bias, the user bias by VALU
+            {
+                typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+                typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(acc[r], bu);
+#pragma unroll
+                for (int st = 0; st < KSTEPS / 8; ++st) {
+                    const f32x4 a1 = {av[8 * st], av[8 * st + 1], av[8 * st + 2], av[8 * st + 3]};
+                    const f32x4 a2 = {av[8 * st + 4], av[8 * st + 5], av[8 * st + 6], av[8 * st + 7]};
+                    const f32x4 b1 = {ub[8 * st], ub[8 * st + 1], ub[8 * st + 2], ub[8 * st + 3]};
+                    const f32x4 b2 = {ub[8 * st + 4], ub[8 * st + 5], ub[8 * st + 6], ub[8 * st + 7]};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b2), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                }
+                const f32x4 ax = {av_x, 0.0f, 0.0f, 0.0f}, bx = {ub_x, 0.0f, 0.0f, 0.0f};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax), __builtin_bit_cast(bf16x8, bx), acc, 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int kk = 0; kk < (LFM_R3X == 3 ? 1 : KSTEPS); ++kk)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], ub[kk], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_x, ub_x, acc, 0, 0, 0);
+#endif
             // the MFMAs have read this tile's operands: request the next tile's now
             if (j0 + 32 < je) load_tile(j0 + 32);
             unsigned band;

@@ -138,8 +138,11 @@ def test_logistic_with_explicit_negatives():
     nu, ni = train.shape
     neg_r = rng.randint(0, nu, size=train.nnz).astype(np.int32)
     neg_c = rng.randint(0, ni, size=train.nnz).astype(np.int32)
-    order = rng.permutation(2 * train.nnz)
-    both = sp.coo_matrix((np.concatenate([np.ones(train.nnz, np.float32), -np.ones(train.nnz, np.float32)])[order],
+    taken = np.concatenate([train.row.astype(np.int64) * ni + train.col, test.row.astype(np.int64) * ni + test.col])
+    free = ~np.isin(neg_r.astype(np.int64) * ni + neg_c, taken)  # (a drawn pair that is a positive of either split is dropped)
+    neg_r, neg_c = neg_r[free], neg_c[free]
+    order = rng.permutation(train.nnz + len(neg_r))
+    both = sp.coo_matrix((np.concatenate([np.ones(train.nnz, np.float32), -np.ones(len(neg_r), np.float32)])[order],
                           (np.concatenate([train.row, neg_r])[order], np.concatenate([train.col, neg_c])[order])),
                          shape=train.shape, dtype=np.float32)
     _gap("logistic", 64, both, test, None, epochs=5, n_seeds=8)

@@ -1182,6 +1182,36 @@ r6yq)
   NARROW_QUALITY_REF=0 LIGHTFM_AMD_ROW_PAIRS=0 timeout 600 python3 tools/narrow_quality.py 40 2>&1 | tail -1
   ( time timeout 900 $PYT tests/test_precision_parity.py -m gpu -x -q -s -k logistic ) > $OUT/tests.txt 2>&1; grep -a "delta\|passed\|failed" $OUT/tests.txt | cut -c1-300
   ;;
+r6la)
+  # what the row-stream kernels' atomic LINE operations cost (timing experiments, WRONG results): debug bit 15 = no bias publication,
+  # bit 16 = no accumulator rows published -- C5 shard at --scale 0.25 and C3
+  line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); r = d["roofline"]; ss = d["config"].get("steady_state", {})
+    print("  %-26s %8.2f M/s  frac %.3f  launch %.3f ms  U %.3f | steady %8.2f M/s  %s" % (sys.argv[1], d["value"] / 1e6, r["frac"], r["avg_launch_ms"], r["updates_per_interaction"], ss.get("value", 0) / 1e6, r.get("kernel")))
+except Exception as e:
+    print("  %s: no result: %r" % (sys.argv[1], e))
+PY
+  }
+  S5="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 0 --steps 2 --warmup 1 --config c5shard --scale 0.25"
+  S3="--no-cpu-baseline --no-quality --no-fit --no-extra --fits 1 --steady-seconds 0 --steps 4 --warmup 2 --config c3"
+  for i in 1 2; do for dbg in 0 32768 65536 98304; do
+    timeout 400 python3 bench.py $S5 --debug $dbg > $OUT/c5_${dbg}_$i.json 2> $OUT/c5_${dbg}_$i.err; line "c5shard debug $dbg run $i" $OUT/c5_${dbg}_$i.json
+  done; done
+  for dbg in 0 32768 65536 98304; do
+    timeout 400 python3 bench.py $S3 --debug $dbg > $OUT/c3_${dbg}.json 2> $OUT/c3_${dbg}.err; line "c3 debug $dbg" $OUT/c3_${dbg}.json
+  done
+  ;;
+r6pa)
+  # predict_ranks: the matrix products on the bf16 pipe (timing experiment x4: two-way split operands in the same registers, WRONG ranks)
+  # against the fp32 products without exact re-checks (x9) and the shipped kernel; tools/build_variants.sh x4 -DLFM_R3X=4 / x9 -DLFM_R3X=9
+  for v in _lib _lib_x9 _lib_x4 $*; do
+    [ -f $R/lightfm_amd/$v/liblfm_hip.so ] || continue
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
+    echo "$v: $(grep -a 'mode 3' $OUT/t$v.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-150)"
+  done
+  ;;
 r6z)
   # the driver's sequence on the final tree: GPU suite, smoke, default bench
   ( time timeout 2400 $PYT tests -m gpu -x -q ) > $OUT/suite.txt 2>&1; tail -3 $OUT/suite.txt | cut -c1-300
