@@ -575,6 +575,11 @@ constexpr unsigned R3_CNT = 0x3ffffffu;  // hist_s: bucket count in the low 26 b
 #ifndef LFM_R3X
 #define LFM_R3X 0
 #endif
+// LFM_RANKS3_KAPPA_MULT: timing experiment (ranks stay exact: a wider band is still a band) -- what the sweep costs with the
+// rounding band the bf16-split products would need
+#ifndef LFM_RANKS3_KAPPA_MULT
+#define LFM_RANKS3_KAPPA_MULT 1.0f
+#endif
 // (a & mask) | c and (m & a) | (~m & b) as the single instructions they are (the compiler's own forms of the
 // expressions below are compare + select chains)
 __device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned c)
@@ -713,7 +718,7 @@ void ranks_mfma3_kernel(RanksArgs a)
     const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
     const int d = a.d, I = a.test.cols;
     const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
-    const float kappa = 4.0f * (float)(d + 2) * 5.9604645e-8f;
+    const float kappa = LFM_RANKS3_KAPPA_MULT * 4.0f * (float)(d + 2) * 5.9604645e-8f;
     const float INF = __int_as_float(0x7f800000);
     // s - eps and s + eps are rounded: each by at most u |s| (1 + ...) <= eps / (4 (d + 2)), as eps >= kappa |s|; twice that
     // is added to eps so that "x_lo > threshold" still implies "s - threshold > eps"
@@ -934,7 +939,7 @@ bool ranks_mfma3_supported(int d, int64_t n_items, int item_rows)
 hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus)
 {
     if (a.n_ulist <= 0 || a.n_work <= 0) return hipSuccess;
-    const float kappa = 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
+    const float kappa = LFM_RANKS3_KAPPA_MULT * 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
     item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
     test_scores_kernel<<<(int)((a.test_nnz + 255) / 256), 256, 0, st>>>(a);
     if (a.d <= 32) return launch_ranks_mfma3_k<16>(a, st, cus);
