@@ -577,6 +577,11 @@ constexpr unsigned R3_CNT = 0x3ffffffu;  // hist_s: bucket count in the low 26 b
 #endif
 // LFM_RANKS3_KAPPA_MULT: timing experiment (ranks stay exact: a wider band is still a band) -- what the sweep costs with the
 // rounding band the bf16-split products would need
+// LFM_RANKS3_DEFER 0: scores inside a band are re-decided on the spot (band_recheck3: the path of rounds 4-5, and the
+// cross-check of the deferred queue)
+#ifndef LFM_RANKS3_DEFER
+#define LFM_RANKS3_DEFER 1
+#endif
 #ifndef LFM_RANKS3_KAPPA_MULT
 #define LFM_RANKS3_KAPPA_MULT 1.0f
 #endif
@@ -658,12 +663,12 @@ __device__ __forceinline__ unsigned count_tile(const f32x16 &acc, float ejq, flo
 // the same float32 operations as the reference's loop, without its d dependent memory round trips (one lane walking
 // the d components alone cost ~5 000 cycles per score, a third of the sweep's time at ML-20M: visit r4q).
 __device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, int m, float nu2, float eu2, int user,
-                                           const float *user_rep, int rs, const float *vT, int I, int d,
+                                           const float *user_rep, int rs, const float *vT, const float *v_rows, int I, int d,
                                            const float *sc_s, const float *ej_s, const float *nj_s, const float *srt_s,
                                            const unsigned *hist_s, const int32_t *tids, float *ranks)
 {
     const int half = lane >> 5, col = lane & 31;
-    asm volatile("" : "+s"(I), "+s"(d), "+s"(vT));  // rare path: nothing of its address arithmetic is hoisted into the sweep
+    asm volatile("" : "+s"(I), "+s"(d), "+s"(vT), "+s"(v_rows));  // rare path: nothing of its address arithmetic is hoisted into the sweep
     while (__ballot(band != 0u) != 0ull) {
         bool pend = false;
         int item = 0, k = 0;
@@ -689,10 +694,17 @@ __device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, i
             todo &= todo - 1ull;
             const int usr = read_lane(user, L), itm = read_lane(item, L);
             const float *ur = user_rep + (size_t)usr * rs;
-            float p0 = 0.0f, p1 = 0.0f;
-            if (lane < d) p0 = __fmul_rn(ur[lane], vT[(size_t)lane * I + itm]);
-            if (lane + WAVE < d) p1 = __fmul_rn(ur[lane + WAVE], vT[(size_t)(lane + WAVE) * I + itm]);
-            float ex = __fadd_rn(ur[d], vT[(size_t)d * I + itm]);
+            float p0 = 0.0f, p1 = 0.0f, ex;
+            if (v_rows) {  // the item's row-major representation: ONE coalesced request instead of a line per component
+                const float *vr = v_rows + (size_t)itm * rs;
+                if (lane < d) p0 = __fmul_rn(ur[lane], vr[lane]);
+                if (lane + WAVE < d) p1 = __fmul_rn(ur[lane + WAVE], vr[lane + WAVE]);
+                ex = __fadd_rn(ur[d], vr[d]);
+            } else {
+                if (lane < d) p0 = __fmul_rn(ur[lane], vT[(size_t)lane * I + itm]);
+                if (lane + WAVE < d) p1 = __fmul_rn(ur[lane + WAVE], vT[(size_t)(lane + WAVE) * I + itm]);
+                ex = __fadd_rn(ur[d], vT[(size_t)d * I + itm]);
+            }
             const int d0 = min(d, WAVE);
             for (int c = 0; c < d0; ++c) ex = __fadd_rn(ex, read_lanef(p0, c));
             for (int c = WAVE; c < d; ++c) ex = __fadd_rn(ex, read_lanef(p1, c - WAVE));
@@ -702,6 +714,53 @@ __device__ __forceinline__ void band_recheck3(unsigned band, int lane, int j0, i
                     if (item != tids[slot] && ex >= srt_s[t * 32 + col]) atomicAdd(&ranks[slot], 1.0f);
                 }
             }
+        }
+    }
+}
+
+// Deferred re-checks (round 6).  A score with a threshold inside its band is QUEUED -- (item, user column), x_lo, x_hi, three
+// words in the wavefront's sorting scratch -- instead of being re-decided on the spot, and the queue is worked off when it
+// is full and at the end of the work item: one entry per LANE, every lane running the reference's sequential dot
+// (PYX:320-334: the operations of test_scores_kernel) of ITS pair from the two row-major representations.  The search, the
+// own-item test and the exact comparison are band_recheck3's; only the order of the (commuting, integer) additions to the
+// ranks changes.  A re-check costs a few instructions of a lane instead of ~300 of the whole wavefront (the band
+// measured 1.1 ms per unit of its width before: profiles/r06_ranks_bf16_experiment.txt).
+constexpr int R3_QCAP = 320;  // entries of 12 bytes in the 4 KB of sc_s (a tile appends at most 64 per step)
+
+__device__ __forceinline__ void ranks3_flush(int qn, int lane, const unsigned *q_s, const float *srt_s, const unsigned *hist_s,
+                                             const RanksArgs &a, int tile, int p0, int d)
+{
+    for (int e = lane; e < qn; e += WAVE) {
+        const unsigned packed = q_s[3 * e];
+        const float xl = __uint_as_float(q_s[3 * e + 1]), xh = __uint_as_float(q_s[3 * e + 2]);
+        const int item = (int)(packed & 0x3ffffffu), c = (int)(packed >> 26);
+        const int user = a.ulist[tile * 32 + c];  // (a queued column always holds a user)
+        const int t_lo = a.test.indptr[user], t_hi = a.test.indptr[user + 1];
+        const int m = max(0, min(R3_ROWS - 1, (t_hi - t_lo) - p0));
+        const int32_t *tids = a.test.indices + t_lo + p0;
+        float *ranks = a.ranks + t_lo + p0;
+        // the thresholds in [x_lo, x_hi] are the ranks k, k + 1, ... (k = thresholds below x_lo; rows >= m hold +inf)
+        int k = 0;
+        for (int step = R3_ROWS / 2; step >= 1; step >>= 1)
+            if (xl > srt_s[(k + step - 1) * 32 + c]) k += step;
+        bool pend = false;
+        for (int t = k; t < m && srt_s[t * 32 + c] <= xh; ++t) pend = pend || item != tids[hist_s[t * 32 + c] >> 26];
+        if (!pend) continue;
+        const float *u = a.user_rep + (size_t)user * a.rs, *v = a.item_rows_rm + (size_t)item * a.rs;
+        float ex = __fadd_rn(u[d], v[d]);
+        int cc = 0;
+#pragma unroll 2
+        for (; cc + 4 <= d; cc += 4) {
+            const float4 x = *(const float4 *)(u + cc), y = *(const float4 *)(v + cc);
+            ex = __fadd_rn(ex, __fmul_rn(x.x, y.x));
+            ex = __fadd_rn(ex, __fmul_rn(x.y, y.y));
+            ex = __fadd_rn(ex, __fmul_rn(x.z, y.z));
+            ex = __fadd_rn(ex, __fmul_rn(x.w, y.w));
+        }
+        for (; cc < d; ++cc) ex = __fadd_rn(ex, __fmul_rn(u[cc], v[cc]));
+        for (int t = k; t < m && srt_s[t * 32 + c] <= xh; ++t) {
+            const int slot = (int)(hist_s[t * 32 + c] >> 26);
+            if (item != tids[slot] && ex >= srt_s[t * 32 + c]) atomicAdd(&ranks[slot], 1.0f);
         }
     }
 }
@@ -775,6 +834,9 @@ void ranks_mfma3_kernel(RanksArgs a)
             hist_s[rk * 32 + col] = (unsigned)t << 26;
         }
         wave_sync();
+        int qn = 0;  // queued re-checks of this work item (sc_s is free between the sort above and the next work item)
+        unsigned *q_s = (unsigned *)sc_s;
+        const bool deferred = a.item_rows_rm != nullptr && LFM_RANKS3_DEFER;
         const int levels = __ballot(m > 15) != 0ull ? 5 : (__ballot(m > 7) != 0ull ? 4 : 3);
         // the thresholds of the first two steps of every search of this pass
         const int rows = 1 << levels;
@@ -865,7 +927,35 @@ void ranks_mfma3_kernel(RanksArgs a)
             else if (levels == 4) band = count_tile<4>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
             else band = count_tile<3>(acc, ejq, njq, nu2, eu2, cb, t0, t1a, t1b, srt_b, hist_b);
             if (LFM_R3X) band = 0u;
-            if (__ballot(band != 0u) != 0ull) {
+            if (deferred) {
+                while (true) {
+                    const bool has = band != 0u;
+                    const unsigned long long hm = __ballot(has);
+                    if (hm == 0ull) break;
+                    const int nh = __popcll(hm);
+                    if (qn + nh > R3_QCAP) {  // (wave-uniform)
+                        wave_sync();
+                        ranks3_flush(qn, lane, q_s, srt_s, hist_s, a, tile, p0, d);
+                        wave_sync();
+                        qn = 0;
+                    }
+                    const int bit = has ? __ffs((int)band) - 1 : 0;
+                    band &= band - 1u;
+                    const int r = 15 - bit;
+                    float sc = acc[0];
+#pragma unroll
+                    for (int rr = 1; rr < 16; ++rr) sc = r == rr ? acc[rr] : sc;
+                    // the octet's bound, as count_tile took it (items 8 g .. 8 g + 7 of the tile: g = r / 4)
+                    const float eps = __fmaf_rn(nu2, __shfl(njq, 8 * (r >> 2), WAVE), __fadd_rn(eu2, __shfl(ejq, 8 * (r >> 2), WAVE)));
+                    if (has) {
+                        const int idx = qn + __popcll(hm & ((1ull << lane) - 1ull));
+                        q_s[3 * idx] = (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * half) | ((unsigned)col << 26);
+                        q_s[3 * idx + 1] = __float_as_uint(__fsub_rn(sc, eps));
+                        q_s[3 * idx + 2] = __float_as_uint(__fadd_rn(sc, eps));
+                    }
+                    qn += nh;
+                }
+            } else if (__ballot(band != 0u) != 0ull) {
                 if (half == 0) {
                     ej_s[col] = ejq;
                     nj_s[col] = njq;
@@ -873,9 +963,13 @@ void ranks_mfma3_kernel(RanksArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc_s[r * WAVE + lane] = acc[r];
                 wave_sync();
-                band_recheck3(band, lane, j0, m, nu2, eu2, user, a.user_rep, a.rs, vT, I, d, sc_s, ej_s, nj_s, srt_s, hist_s, tids, ranks);
+                band_recheck3(band, lane, j0, m, nu2, eu2, user, a.user_rep, a.rs, vT, a.item_rows_rm, I, d, sc_s, ej_s, nj_s, srt_s, hist_s, tids, ranks);
                 wave_sync();
             }
+        }
+        if (qn) {
+            wave_sync();
+            ranks3_flush(qn, lane, q_s, srt_s, hist_s, a, tile, p0, d);
         }
         // counts: threshold of rank r is exceeded by the scores of every bucket above r
         wave_sync();
