@@ -52,6 +52,8 @@ struct RanksArgs {
     int32_t item_rows;      // ranks_mfma3_kernel: rows of item_rep (it reads the table through a buffer descriptor)
     const float *item_rows_rm;  // optional [n_items][rs] row-major item representations (bias at [d]): test_scores_kernel reads
                                 // two contiguous rows per test interaction instead of d + 1 lines of the component-major table
+    void *item_bf;              // optional, ranks_mfma3_kernel: room for the table of bf16 pieces (ranks_mfma3_bf_bytes) -- set: the
+                                // products run on the bf16 matrix pipe (split operands); nullptr: fp32 products
 };
 
 // grid_used (optional): the grid actually launched (after the residency clamp)
@@ -139,6 +141,7 @@ hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus);
 int ranks_mfma3_waves_per_cu(int d);
 int ranks_mfma3_pass_items();
 bool ranks_mfma3_supported(int d, int64_t n_items, int item_rows);  // the table must fit one 2 GB buffer
+size_t ranks_mfma3_bf_bytes(int d, int64_t n_items);  // RanksArgs::item_bf: bytes of the table of bf16 pieces (0: not available)
 hipError_t launch_auc(const DCsr &ranks, const int32_t *num_train_positives, float *rank_data,
                       float *auc, hipStream_t st);
 

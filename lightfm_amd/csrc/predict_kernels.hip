@@ -765,11 +765,94 @@ __device__ __forceinline__ void ranks3_flush(int qn, int lane, const unsigned *q
     }
 }
 
-template <int KSTEPS>
+// BF (round 6, the default): the products run on the bf16 matrix pipe, which -- unlike the fp32 MFMA, which executes on the
+// VALU's own lanes (SQ_VALU_MFMA_COEXEC_CYCLES = 0) -- CO-EXECUTES with the search.  Every float32 operand is split into two
+// bf16 pieces, x = h + l + r with h = bf16(x), l = bf16(x - h) (round to nearest: |x - h| <= 2^-8 |x|, |r| <= 2^-16 |x|), and a
+// step of 16 components is THREE v_mfma_f32_32x32x16_bf16 (h h, h l, l h) on operands that occupy the registers the fp32
+// operands did: 3 d / 16 + 1 instructions of 8 passes per tile instead of d / 2 + 1 of 16.  The item pieces come from a
+// table built once per call (item_bf_kernel: [step][piece][item][half] x 16 bytes, one buffer_load_dwordx4 per operand), the
+// user pieces are split when a work item starts; the item bias is one more step (three pieces against ones: exact to
+// 2^-24 |b_j|), the user bias the accumulator's initial value.  What this costs is a wider rounding band (ranks_bf_kappa
+// below: ~5 x the fp32 sweep's at d = 64), which the deferred re-checks make cheap (ranks3_flush).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// round to nearest even (finite values)
+__device__ __forceinline__ unsigned bf16_rn(float f)
+{
+    const unsigned x = __float_as_uint(f);
+    return (x + 0x7fffu + ((x >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split(float f, unsigned &h, unsigned &l)
+{
+    h = bf16_rn(f);
+    l = bf16_rn(__fsub_rn(f, __uint_as_float(h << 16)));  // (the difference is exact)
+}
+
+// Rounding band of the bf16-split sweep, as multiples of T = |b_u| + |b_j| + |u| |v_j| (kT) and of |u| |v_j| alone (kS):
+//   reference, PYX:320-334: d + 2 roundings of at most 2^-24 T each;
+//   the sweep: 16 (3 NS + 1) accumulations (NS = steps of 16 components) whose internal rounding the ISA does not specify --
+//   taken as 2^-23 each (faithful), on partial sums of at most (1 + 2^-8)^2 (1 + 2^-7) T;
+//   the split: sum_k |l_u l_v + r_u v + u r_v| <= 3.03 x 2^-16 sum_k |u_k v_k| <= 3.03 x 2^-16 |u| |v_j|; the bias pieces 2^-24 |b_j|;
+// each with a quarter on top.  (d = 64: kT = 3.7e-5, kS = 4.7e-5 against the fp32 sweep's 4 (d + 2) 2^-24 = 1.6e-5.)
+__host__ __device__ __forceinline__ float ranks_bf_kappa_t(int d, int ns)
+{
+    return 1.25f * 5.9604645e-8f * ((float)(d + 2) + 1.02f * 2.0f * 16.0f * (float)(3 * ns + 1) + 1.0f);
+}
+__host__ __device__ __forceinline__ float ranks_bf_kappa_s() { return 1.25f * 3.03f * 1.52587890625e-5f; }
+__host__ __device__ __forceinline__ int ranks_bf_steps(int d) { return d <= 32 ? 2 : (d <= 64 ? 4 : 8); }
+
+// [step 0..NS][piece][item][half] x 16 bytes (step NS = the bias step: piece 0 only)
+__global__ void item_bf_kernel(const float *vT, int n_items, int d, int ns, u32x4 *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_step = (int64_t)n_items * 2;
+    if (t >= per_step * (ns + 1)) return;
+    const int st = (int)(t / per_step), j = (int)((t % per_step) >> 1), half = (int)(t & 1);
+    unsigned h[8], l[8];
+    if (st < ns) {
+        for (int i = 0; i < 8; ++i) {
+            const int k = 16 * st + 8 * half + i;
+            bf16_split(k < d ? vT[(size_t)k * n_items + j] : 0.0f, h[i], l[i]);
+        }
+        u32x4 H = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        u32x4 L = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        out[((size_t)(2 * st) * n_items + j) * 2 + half] = H;
+        out[((size_t)(2 * st + 1) * n_items + j) * 2 + half] = L;
+    } else {
+        u32x4 B = {0u, 0u, 0u, 0u};
+        if (half == 0) {
+            const float bj = vT[(size_t)d * n_items + j];
+            unsigned b1, b2, b3;
+            bf16_split(bj, b1, b2);
+            b3 = bf16_rn(__fsub_rn(__fsub_rn(bj, __uint_as_float(b1 << 16)), __uint_as_float(b2 << 16)));
+            B.x = b1 | (b2 << 16);
+            B.y = b3;
+        }
+        out[((size_t)(2 * ns) * n_items + j) * 2 + half] = B;
+    }
+}
+
+// the item-side terms of the bf16-split sweep's band: kT |b_j| and (kT + kS) |v_j|
+__global__ void item_eps_bf_kernel(const float *vT, int n_items, int d, float kt, float ks, float *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_items) return;
+    float n2 = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const float v = vT[(size_t)k * n_items + j];
+        n2 += v * v;
+    }
+    out[j] = kt * fabsf(vT[(size_t)d * n_items + j]);
+    out[(size_t)n_items + j] = (kt + ks) * (sqrtf(n2) * 1.0000005f);
+}
+
+template <int KSTEPS, bool BF = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KSTEPS > 32 ? 2 : 3, KSTEPS > 32 ? 2 : 3)))
 void ranks_mfma3_kernel(RanksArgs a)
 {
     constexpr int ROWS = R3_ROWS, MT = ROWS - 1;
+    constexpr int NS = KSTEPS / 8;  // BF: steps of 16 components
     __shared__ float srt_s[ROWS * 32];      // [rank][user column] thresholds of the pass, ascending, +inf beyond
     __shared__ unsigned hist_s[ROWS * 32];  // [bucket][user column] scores with `bucket` thresholds below | slot of the rank << 26
     __shared__ float sc_s[16 * WAVE];       // sorting scratch [slot][user column]; slow path: the tile's scores [r][lane]
@@ -777,7 +860,7 @@ void ranks_mfma3_kernel(RanksArgs a)
     const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
     const int d = a.d, I = a.test.cols;
     const float *vT = a.item_rep;  // [rs][I] component-major, row d = item bias
-    const float kappa = LFM_RANKS3_KAPPA_MULT * 4.0f * (float)(d + 2) * 5.9604645e-8f;
+    const float kappa = BF ? ranks_bf_kappa_t(d, NS) : LFM_RANKS3_KAPPA_MULT * 4.0f * (float)(d + 2) * 5.9604645e-8f;
     const float INF = __int_as_float(0x7f800000);
     // s - eps and s + eps are rounded: each by at most u |s| (1 + ...) <= eps / (4 (d + 2)), as eps >= kappa |s|; twice that
     // is added to eps so that "x_lo > threshold" still implies "s - threshold > eps"
@@ -786,6 +869,10 @@ void ranks_mfma3_kernel(RanksArgs a)
     const unsigned row2 = 8u * (unsigned)I;  // bytes of two table rows
     const __amdgpu_buffer_rsrc_t vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vT, 0, (int)(4u * (unsigned)I * (unsigned)a.item_rows), 0x00020000);
     const __amdgpu_buffer_rsrc_t esrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.item_eps, 0, (int)row2, 0x00020000);
+    // BF: the table of bf16 pieces, 32 I bytes per (step, piece)
+    const unsigned bstep = 32u * (unsigned)I;
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(BF ? (const void *)a.item_bf : (const void *)vT), 0,
+                                                                          BF ? (int)(bstep * (unsigned)(2 * NS + 1)) : 0, 0x00020000);
     const unsigned cb = 4u * (unsigned)col;
     const char *srt_b = (const char *)srt_s;
     char *hist_b = (char *)hist_s;
@@ -795,13 +882,33 @@ void ranks_mfma3_kernel(RanksArgs a)
         const bool uok = ui < a.n_ulist;
         const int user = uok ? a.ulist[ui] : 0;
         const float *urow = a.user_rep + (size_t)user * a.rs;
-        float ub[KSTEPS];
+        float ub[KSTEPS];   // fp32: component 2 kk + half; BF: the pieces, ub[8 st .. + 3] = h and ub[8 st + 4 .. + 7] = l of
+                            // components 16 st + 8 half + 0..7 (two bf16 per register)
         float n2 = 0.0f;
+        if constexpr (BF) {
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int k = 2 * kk + half;
-            ub[kk] = (uok && k < d) ? urow[k] : 0.0f;
-            n2 += ub[kk] * ub[kk];
+            for (int st = 0; st < NS; ++st) {
+                unsigned h[8], l[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * st + 8 * half + i;
+                    const float x = (uok && k < d) ? urow[k] : 0.0f;
+                    n2 += x * x;
+                    bf16_split(x, h[i], l[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ub[8 * st + i] = __uint_as_float(h[2 * i] | (h[2 * i + 1] << 16));
+                    ub[8 * st + 4 + i] = __uint_as_float(l[2 * i] | (l[2 * i + 1] << 16));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int k = 2 * kk + half;
+                ub[kk] = (uok && k < d) ? urow[k] : 0.0f;
+                n2 += ub[kk] * ub[kk];
+            }
         }
         n2 += __shfl_xor(n2, 32, WAVE);
         const float bu = uok ? urow[d] : 0.0f;
@@ -836,7 +943,7 @@ void ranks_mfma3_kernel(RanksArgs a)
         wave_sync();
         int qn = 0;  // queued re-checks of this work item (sc_s is free between the sort above and the next work item)
         unsigned *q_s = (unsigned *)sc_s;
-        const bool deferred = a.item_rows_rm != nullptr && LFM_RANKS3_DEFER;
+        const bool deferred = BF || (a.item_rows_rm != nullptr && LFM_RANKS3_DEFER);  // (BF: the session hands over both tables)
         const int levels = __ballot(m > 15) != 0ull ? 5 : (__ballot(m > 7) != 0ull ? 4 : 3);
         // the thresholds of the first two steps of every search of this pass
         const int rows = 1 << levels;
@@ -858,14 +965,29 @@ void ranks_mfma3_kernel(RanksArgs a)
         }
         // A operand of a tile: V[item j0 + col][2 kk + half], walked down the component-major table through ONE
         // buffer descriptor: a 32-bit lane offset, the row as the scalar offset (no per-load address arithmetic)
-        float av[KSTEPS], bj = 0.0f, ej = 0.0f, njk = 0.0f;
+        float av[KSTEPS], bj = 0.0f, bj2 = 0.0f, ej = 0.0f, njk = 0.0f;
         auto load_tile = [&](int j0) {
             const unsigned jc = (unsigned)min(j0 + col, I - 1);
             const unsigned voff = 4u * (jc + (unsigned)half * (unsigned)I);
+            if constexpr (BF) {
+                const unsigned boff = 16u * (2u * jc + (unsigned)half);
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
-                av[kk] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, voff, (unsigned)kk * row2, 0));
-            bj = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, 4u * jc, (unsigned)d * (row2 >> 1), 0));
+                for (int q = 0; q < 2 * NS; ++q) {  // (step q / 2, piece q % 2): registers av[4 q .. 4 q + 3]
+                    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(bsrc, boff, (unsigned)q * bstep, 0);
+                    av[4 * q] = __uint_as_float(x.x);
+                    av[4 * q + 1] = __uint_as_float(x.y);
+                    av[4 * q + 2] = __uint_as_float(x.z);
+                    av[4 * q + 3] = __uint_as_float(x.w);
+                }
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(bsrc, boff, (unsigned)(2 * NS) * bstep, 0);
+                bj = __uint_as_float(x.x);   // the bias step's A operand: (b1, b2 | b3, 0 | 0 ...) in half 0, zeros in half 1
+                bj2 = __uint_as_float(x.y);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    av[kk] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, voff, (unsigned)kk * row2, 0));
+                bj = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, 4u * jc, (unsigned)d * (row2 >> 1), 0));
+            }
             ej = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(esrc, 4u * jc, 0, 0));
             njk = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(esrc, 4u * jc, row2 >> 1, 0));
         };
@@ -892,7 +1014,24 @@ void ranks_mfma3_kernel(RanksArgs a)
                 int off;  // 0 / -1 (written as the instruction: the compiler's own form is and + compare + select)
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(off) : "v"(tm), "n"(iA));
                 acc[r] = __int_as_float(off & (int)0xff800000);
+                if constexpr (BF) acc[r] = __fadd_rn(acc[r], bu);  // (the user bias: the accumulator's initial value)
             }
+            if constexpr (BF) {
+                const u32x4 bjs = {__float_as_uint(bj), __float_as_uint(bj2), 0u, 0u};
+                // against ones in the first three components of half 0 (1.0 = 0x3f80)
+                const u32x4 ones = {half ? 0u : 0x3f803f80u, half ? 0u : 0x00003f80u, 0u, 0u};
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const u32x4 ah = {__float_as_uint(av[8 * st]), __float_as_uint(av[8 * st + 1]), __float_as_uint(av[8 * st + 2]), __float_as_uint(av[8 * st + 3])};
+                    const u32x4 al = {__float_as_uint(av[8 * st + 4]), __float_as_uint(av[8 * st + 5]), __float_as_uint(av[8 * st + 6]), __float_as_uint(av[8 * st + 7])};
+                    const u32x4 bh = {__float_as_uint(ub[8 * st]), __float_as_uint(ub[8 * st + 1]), __float_as_uint(ub[8 * st + 2]), __float_as_uint(ub[8 * st + 3])};
+                    const u32x4 bl = {__float_as_uint(ub[8 * st + 4]), __float_as_uint(ub[8 * st + 5]), __float_as_uint(ub[8 * st + 6]), __float_as_uint(ub[8 * st + 7])};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bjs), __builtin_bit_cast(bf16x8, ones), acc, 0, 0, 0);
+            } else {
 #if LFM_R3X == 4
             // timing experiment (WRONG ranks): the products on the bf16 matrix pipe -- two-way split operands in the SAME registers
             // (KSTEPS / 8 steps of 16 components x {hi hi, hi lo, lo hi}) + one step for the item bias, the user bias by VALU
@@ -920,6 +1059,7 @@ void ranks_mfma3_kernel(RanksArgs a)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], ub[kk], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_x, ub_x, acc, 0, 0, 0);
 #endif
+            }
             // the MFMAs have read this tile's operands: request the next tile's now
             if (j0 + 32 < je) load_tile(j0 + 32);
             unsigned band;
@@ -1010,13 +1150,13 @@ static hipError_t launch_ranks_mfma2_k(const RanksArgs &a, hipStream_t st, int c
     return hipGetLastError();
 }
 
-template <int KSTEPS>
+template <int KSTEPS, bool BF>
 static hipError_t launch_ranks_mfma3_k(const RanksArgs &a, hipStream_t st, int cus)
 {
     int per_cu = 0, grid = a.n_work;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma3_kernel<KSTEPS>, 64, 0) == hipSuccess && per_cu > 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ranks_mfma3_kernel<KSTEPS, BF>, 64, 0) == hipSuccess && per_cu > 0)
         grid = std::min(a.n_work, per_cu * std::max(cus, 1));
-    ranks_mfma3_kernel<KSTEPS><<<grid, 64, 0, st>>>(a);
+    ranks_mfma3_kernel<KSTEPS, BF><<<grid, 64, 0, st>>>(a);
     return hipGetLastError();
 }
 
@@ -1034,12 +1174,30 @@ hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus)
 {
     if (a.n_ulist <= 0 || a.n_work <= 0) return hipSuccess;
     const float kappa = LFM_RANKS3_KAPPA_MULT * 4.0f * (float)(a.d + 2) * 5.9604645e-8f;
-    item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
     test_scores_kernel<<<(int)((a.test_nnz + 255) / 256), 256, 0, st>>>(a);
-    if (a.d <= 32) return launch_ranks_mfma3_k<16>(a, st, cus);
-    if (a.d <= 64) return launch_ranks_mfma3_k<32>(a, st, cus);
-    if (a.d <= 128) return launch_ranks_mfma3_k<64>(a, st, cus);
+    if (a.item_bf) {  // the products on the bf16 matrix pipe (split operands; the deferred re-checks need the row-major rows)
+        const int ns = ranks_bf_steps(a.d);
+        item_eps_bf_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, ranks_bf_kappa_t(a.d, ns), ranks_bf_kappa_s(), a.item_eps);
+        const int64_t cells = (int64_t)a.test.cols * 2 * (ns + 1);
+        item_bf_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(a.item_rep, a.test.cols, a.d, ns, (u32x4 *)a.item_bf);
+        if (a.d <= 32) return launch_ranks_mfma3_k<16, true>(a, st, cus);
+        if (a.d <= 64) return launch_ranks_mfma3_k<32, true>(a, st, cus);
+        if (a.d <= 128) return launch_ranks_mfma3_k<64, true>(a, st, cus);
+        return hipErrorInvalidValue;
+    }
+    item_eps_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, kappa, a.item_eps);
+    if (a.d <= 32) return launch_ranks_mfma3_k<16, false>(a, st, cus);
+    if (a.d <= 64) return launch_ranks_mfma3_k<32, false>(a, st, cus);
+    if (a.d <= 128) return launch_ranks_mfma3_k<64, false>(a, st, cus);
     return hipErrorInvalidValue;
+}
+
+// bytes of the table of bf16 pieces launch_ranks_mfma3 fills when RanksArgs::item_bf is set; 0 = outside the variant's scope
+size_t ranks_mfma3_bf_bytes(int d, int64_t n_items)
+{
+    if (!ranks_mfma_supported(d)) return 0;
+    const int64_t bytes = (int64_t)(2 * ranks_bf_steps(d) + 1) * 32 * n_items;
+    return bytes < ((int64_t)1 << 31) ? (size_t)bytes : 0;
 }
 
 int ranks_mfma2_item_rows(int d) { return std::max(d + 1, d <= 32 ? 32 : (d <= 64 ? 64 : 128)); }

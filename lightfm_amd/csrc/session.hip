@@ -3145,7 +3145,7 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     if (test->nnz == 0) return LFM_OK;
     HIP_TRY(hipSetDevice(s->device));
     DevCsr dtest;
-    DBuf<float> urep, irep, irows, dranks, ieps, tscores;
+    DBuf<float> urep, irep, irows, dranks, ieps, tscores, ibf;
     DBuf<int32_t> ulist, work;
     DrainOnExit drain(s->stream);
     // LIGHTFM_AMD_TIMING=1: host wall time of the call's phases on stderr
@@ -3206,11 +3206,12 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
     a.item_rows = irows_n;
     a.item_rows_rm = irows.p;
     // LIGHTFM_AMD_RANKS_MFMA: 0 the scalar kernel, 1 the first MFMA formulation (users as tile rows), 2 the
-    // second (a lane owns a user, compare chain), unset / 3 the third (a lane owns a user, bucket search); the
-    // tests compare all four
+    // second (a lane owns a user, compare chain), 3 the third (a lane owns a user, bucket search, fp32 products), unset / 4
+    // the third with the products on the bf16 matrix pipe (split operands); the tests compare all five
     const char *mfma_env = getenv("LIGHTFM_AMD_RANKS_MFMA");
-    int mfma_mode = mfma_env == nullptr ? 3 : atoi(mfma_env);
-    if (mfma_mode < 0 || mfma_mode > 3) mfma_mode = 3;  // anything but the four documented values: the default kernel
+    int mfma_mode = mfma_env == nullptr ? 4 : atoi(mfma_env);
+    if (mfma_mode < 0 || mfma_mode > 4) mfma_mode = 4;  // anything but the five documented values: the default kernel
+    a.item_bf = nullptr;
     // the MFMA sweeps mask train positives by walking each user's train row alongside the item tiles: they
     // need ascending column indices (tocsr() of a COO gives them; a CSR handed in by the caller may not).
     // Unsorted rows run the scalar kernel, whose lookup is the reference's binary search.  Checked on the
@@ -3318,6 +3319,13 @@ extern "C" int lfm_session_predict_ranks(lfm_session *s, const lfm_csr *test, co
             LFM_TRY(work.upload(wl.data(), wl.size()));
             a.work = work.p;
             a.n_work = (int32_t)(wl.size() / (bucket_search ? 4 : 2));
+            if (bucket_search && mfma_mode == 4) {
+                const size_t bf_bytes = ranks_mfma3_bf_bytes(s->d, itf.rows);
+                if (bf_bytes) {
+                    LFM_TRY(ibf.alloc((bf_bytes + 3) / 4));
+                    a.item_bf = ibf.p;
+                }
+            }
             if (bucket_search) HIP_TRY(launch_ranks_mfma3(a, s->stream, s->cus));
             else HIP_TRY(launch_ranks_mfma2(a, s->stream, s->cus));
         }

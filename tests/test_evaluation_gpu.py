@@ -98,7 +98,8 @@ def test_intersecting_train_and_test_is_rejected(fitted):
     precision_at_k(model, train, train_interactions=train, check_intersections=False)
 
 
-_RANK_KERNELS = (("bucket-search", "3"), ("lane-per-user", "2"), ("users-as-rows", "1"), ("scalar", "0"))
+# (the default -- unset / "4" -- is the bucket search with its products on the bf16 matrix pipe, split operands)
+_RANK_KERNELS = (("bucket-search-bf16", "4"), ("bucket-search", "3"), ("lane-per-user", "2"), ("users-as-rows", "1"), ("scalar", "0"))
 
 
 def _ranks_by_kernel(model, test, train=None, **kw):
@@ -126,6 +127,7 @@ def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
     m = LightFM(no_components=64, loss="warp", random_state=1).fit(train, epochs=3)
     ranks = _ranks_by_kernel(m, test, train)
     assert len(ranks["scalar"]) == test.nnz and ranks["scalar"].max() > 100
+    assert np.array_equal(ranks["bucket-search-bf16"], ranks["scalar"])
     assert np.array_equal(ranks["bucket-search"], ranks["scalar"])
     assert np.array_equal(ranks["lane-per-user"], ranks["scalar"])
     assert np.array_equal(ranks["users-as-rows"], ranks["scalar"])
@@ -134,6 +136,7 @@ def test_mfma_prefiltered_ranks_equal_the_scalar_kernel_at_scale():
     heavy = sp.coo_matrix((np.ones(300, np.float32), (np.repeat([3, 4000], 150), np.tile(np.arange(150) * 7, 2))),
                           shape=test.shape, dtype=np.float32)
     out = _ranks_by_kernel(m2, heavy)
+    assert np.array_equal(out["bucket-search-bf16"], out["scalar"])
     assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
     assert np.array_equal(out["users-as-rows"], out["scalar"])
@@ -153,6 +156,7 @@ def test_mfma_ranks_shapes_and_ties(d, n_items):
     m.item_embeddings[h:2 * h] = m.item_embeddings[:h]
     m.item_biases[h:2 * h] = m.item_biases[:h]
     out = _ranks_by_kernel(m, test, train)
+    assert np.array_equal(out["bucket-search-bf16"], out["scalar"])
     assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
     assert np.array_equal(out["users-as-rows"], out["scalar"])
@@ -169,6 +173,7 @@ def test_mfma_ranks_shapes_and_ties(d, n_items):
     fresh._initialize(d, n_items, 300)
     fresh.item_embeddings *= 1e-3
     out = _ranks_by_kernel(fresh, test, train)
+    assert np.array_equal(out["bucket-search-bf16"], out["scalar"])
     assert np.array_equal(out["bucket-search"], out["scalar"])
     assert np.array_equal(out["lane-per-user"], out["scalar"])
 

@@ -10,7 +10,7 @@ from lightfm_amd import LightFM
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.RandomState(7)
-bad = 0
+bad = bad4 = 0
 for c in range(cases):
     nu, ni, d = int(rng.randint(5, 70)), int(rng.randint(20, 400)), int(rng.choice([3, 10, 32, 33, 64, 100]))
     train = sp.rand(nu, ni, density=0.1, format="csr", random_state=int(rng.randint(1 << 30)))
@@ -24,9 +24,14 @@ for c in range(cases):
         dense.data[:] = 1.0
     tr = train if c % 2 else None
     out = {}
-    for mode in ("3", "0"):
+    for mode in ("4", "3", "0"):
         os.environ["LIGHTFM_AMD_RANKS_MFMA"] = mode
         out[mode] = m.predict_rank(dense, train_interactions=tr, check_intersections=False).toarray()
+    if not np.array_equal(out["4"], out["0"]):
+        bad4 += 1
+        u, i = np.nonzero(out["4"] != out["0"])
+        print("case %d (nu %d ni %d d %d train %s): %d cells differ between the bf16-pipe sweep and the scalar kernel; first: user %d item %d: %.0f vs %.0f"
+              % (c, nu, ni, d, tr is not None, len(u), u[0], i[0], out["4"][u[0], i[0]], out["0"][u[0], i[0]]), flush=True)
     if not np.array_equal(out["3"], out["0"]):
         bad += 1
         u, i = np.nonzero(out["3"] != out["0"])
@@ -37,7 +42,7 @@ for c in range(cases):
         pos = int(np.where(order == i[0])[0][0])
         print("   scores around it:", [(int(order[k]), float(s[order[k]])) for k in range(max(0, pos - 2), min(ni, pos + 3))], flush=True)
 os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
-print("%d of %d cases differ" % (bad, cases))
+print("%d of %d cases differ (fp32 products), %d (bf16 pipe)" % (bad, cases, bad4))
 
 # the shape of tests/test_lightfm_api.py::test_predict_rank_known_answers, many unseeded models: both kernels, and
 # whether the ranks of a row are a permutation (an exact tie of two float32 scores gives a repeated rank in the
@@ -47,13 +52,15 @@ nu, ni = 10, 100
 train = sp.rand(nu, ni, density=0.1, format="csr", random_state=42)
 train.data[:] = 1.0
 dense = sp.csr_matrix(np.ones((nu, ni), np.float32))
-differ = ties = 0
+differ = differ4 = ties = 0
 for c in range(reps):
     m = LightFM().fit_partial(train)
     out = {}
-    for mode in ("3", "0"):
+    for mode in ("4", "3", "0"):
         os.environ["LIGHTFM_AMD_RANKS_MFMA"] = mode
         out[mode] = m.predict_rank(dense, num_threads=2).toarray()
+    if not np.array_equal(out["4"], out["0"]):
+        differ4 += 1
     if not np.array_equal(out["3"], out["0"]):
         differ += 1
         u, i = np.nonzero(out["3"] != out["0"])
@@ -65,4 +72,4 @@ for c in range(reps):
             print("api case %d row %d: scalar ranks not a permutation; distinct scores %d of %d" % (c, row, len(np.unique(s)), ni), flush=True)
 os.environ.pop("LIGHTFM_AMD_RANKS_MFMA", None)
 if reps:
-    print("api shape: %d of %d models differ between the kernels; %d rows with repeated ranks in the scalar kernel" % (differ, reps, ties))
+    print("api shape: %d (fp32 products) / %d (bf16 pipe) of %d models differ between the kernels; %d rows with repeated ranks in the scalar kernel" % (differ, differ4, reps, ties))

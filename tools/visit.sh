@@ -609,8 +609,8 @@ r4q)
   timeout 300 python tools/ranks_stress.py 200 500 > $OUT/stress.txt 2>&1; grep -a "differ" $OUT/stress.txt | tail -3
   for v in _lib _lib_x9 _lib_lock _lib_x1 _lib_x2 _lib_x3 $*; do
     [ -f $R/lightfm_amd/$v/liblfm_hip.so ] || continue
-    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
-    echo "$v: $(grep -a 'mode 3' $OUT/t$v.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-110)"
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=4,3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
+    echo "$v: $(grep -a "mode [34]" $OUT/t$v.txt | sed -n "3p;6p" | sed 's/.*wall/wall/' | cut -c1-110)"
   done
   [ -n "$SKIP_PMC" ] && exit 0
   cd /tmp && export TMPDIR=/tmp
@@ -1206,10 +1206,10 @@ PY
 r6pa)
   # predict_ranks: the matrix products on the bf16 pipe (timing experiment x4: two-way split operands in the same registers, WRONG ranks)
   # against the fp32 products without exact re-checks (x9) and the shipped kernel; tools/build_variants.sh x4 -DLFM_R3X=4 / x9 -DLFM_R3X=9
-  for v in _lib _lib_nodefer _lib_k5 $*; do
+  for v in _lib $*; do
     [ -f $R/lightfm_amd/$v/liblfm_hip.so ] || continue
-    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
-    echo "$v: $(grep -a 'mode 3' $OUT/t$v.txt | tail -1 | sed 's/.*wall/wall/' | cut -c1-150)"
+    LIGHTFM_AMD_LIB=$R/lightfm_amd/$v/liblfm_hip.so RANKS_TIMING_MODES=4,3 timeout 200 python tools/ranks_timing.py > $OUT/t$v.txt 2>&1
+    echo "$v: $(grep -a "mode [34]" $OUT/t$v.txt | sed -n "3p;6p" | sed 's/.*wall/wall/' | cut -c1-150)"
   done
   ;;
 r6z)
