@@ -190,6 +190,12 @@ int lfm_device_pool_stats(int64_t *reserved, int64_t *cached);
  * *mismatches = cells whose new (W, G) bit patterns differ (the variant is bit-identical by construction: 0), *fallbacks =
  * cells for which the variant took its exact fallback (results too close to a float32 rounding boundary). */
 int lfm_selftest_adagrad_cell(int64_t n, uint32_t seed, float learning_rate, int64_t *mismatches, int64_t *fallbacks);
+/* Device self-test (tests): `tiles` pseudo-random 32 x 32 tiles of (user, item) pairs with no_components = d (components and
+ * biases of random sign over `spread` binades) through the instruction sequence of predict_ranks' default sweep -- the products on
+ * the bf16 matrix pipe with two-way split operands (csrc/predict_kernels.hip: ranks_mfma3_kernel<.., true>) -- against the
+ * reference's sequential float32 dot (PYX:320-334): *worst_fraction = the largest |difference| / (the rounding band the sweep takes
+ * for the pair), *beyond = pairs outside their band (the band's assumption about the pipe's internal rounding holds iff 0). */
+int lfm_selftest_ranks_bf16_band(int64_t tiles, uint32_t seed, int32_t d, int32_t spread, float *worst_fraction, int64_t *beyond);
 
 /* ------------------------------------------------------------------------
  * One-shot epoch drivers: upload, run ONE epoch on device 0, download.

@@ -74,7 +74,7 @@ EXPORTS = (
     "lfm_session_predict_ranks", "lfm_session_sync_to_host", "lfm_session_load_model",
     "lfm_session_build_positives", "lfm_session_download_positives", "lfm_session_representations",
     "lfm_session_destroy",
-    "lfm_device_trim", "lfm_device_pool_stats", "lfm_selftest_adagrad_cell", "lfm_host_scan_f32", "lfm_host_mt19937_table", "lfm_host_checksum_u32",
+    "lfm_device_trim", "lfm_device_pool_stats", "lfm_selftest_adagrad_cell", "lfm_selftest_ranks_bf16_band", "lfm_host_scan_f32", "lfm_host_mt19937_table", "lfm_host_checksum_u32",
     "lfm_comm_preload", "lfm_comm_unique_id", "lfm_session_comm_init", "lfm_session_comm_merge", "lfm_session_comm_merge_sparse", "lfm_session_comm_merge_flush", "lfm_session_set_merge_dense_fraction",
     "lfm_sessions_merge_local_sparse", "lfm_sessions_merge_local_flush", "lfm_session_merge_begin",
     "lfm_session_set_hot_rows", "lfm_session_comm_merge_hot", "lfm_sessions_merge_local_hot",

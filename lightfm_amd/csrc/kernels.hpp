@@ -105,6 +105,9 @@ struct HotArgs {
 int hot_slice_components(int hot_n, int d);  // components per LDS slice (8, 4, 2), 0 = the hot set does not fit
 hipError_t launch_hot_slices(const HotArgs &a, int cs, int threads, hipStream_t st);
 hipError_t launch_selftest_adagrad(int64_t n, uint32_t seed, float lr, unsigned long long *out, hipStream_t st);
+// predict_kernels.hip: the bf16-split sweep's scores against the sequential dot, as a fraction of its rounding band (out[0] = largest
+// fraction, float bits; out[1] = pairs beyond the band)
+hipError_t launch_ranks_bf_band_selftest(int64_t tiles, uint32_t seed, int d, int spread, unsigned *out, hipStream_t st);
 hipError_t launch_column_counts(const int32_t *indices, int64_t nnz, int32_t cols, int32_t *counts, hipStream_t st);
 // csr_build.hip: the Bloom filter over the positives lookup (device.hpp: Bloom); bloom has Bloom::words(nnz) words
 hipError_t build_positives_bloom(const int32_t *indptr, const int32_t *indices, int32_t n_rows, int64_t nnz, uint32_t *bloom,

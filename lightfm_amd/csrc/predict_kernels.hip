@@ -1192,6 +1192,105 @@ hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus)
     return hipErrorInvalidValue;
 }
 
+// Device self-test of the bf16-split sweep's rounding band (lfm_selftest_ranks_bf16_band).  One wavefront per 32 x 32 tile of
+// pseudo-random users and items (components and biases of random sign over a range of exponents; `spread` binades): the scores
+// through EXACTLY the instruction sequence of ranks_mfma3_kernel<.., true> (bf16_split pieces, l h / h l / h h per step, the bias
+// step, the user bias as the initial value) against the reference's sequential float32 dot (PYX:320-334), as a fraction of the
+// band the sweep would take for the pair, kT (|b_u| + |b_j| + |u| |v_j|) + kS |u| |v_j| (without the margins).  out[0] = the largest
+// fraction seen (float bits), out[1] = pairs beyond 1.0 -- the band's assumption about the matrix pipe's internal rounding
+// holds iff that is 0.
+template <int NS>
+__global__ __launch_bounds__(64) void ranks_bf_band_selftest_kernel(int64_t tiles, uint32_t seed, int d, int spread, unsigned *out)
+{
+    __shared__ float U[32 * 132], V[32 * 132];  // [row][d + 1], bias at [d]
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    unsigned worst = 0u, beyond = 0u;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        __syncthreads();
+        for (int i = lane; i < 32 * (d + 1); i += WAVE) {
+            for (int side = 0; side < 2; ++side) {
+                uint32_t x = seed ^ (uint32_t)(t * 2654435761ull) ^ (uint32_t)(i * 40503u + side * 977u);
+                x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+                const int e = 127 - 6 + (int)((x >> 23) % (unsigned)max(spread, 1));
+                const float v = __uint_as_float((x & 0x80000000u) | ((unsigned)e << 23) | (x & 0x7fffffu));
+                (side ? V : U)[(i / (d + 1)) * 132 + (i % (d + 1))] = v;
+            }
+        }
+        __syncthreads();
+        // B operand: user `col`; A operand: item `col`
+        u32x4 ah[NS], al[NS], bh[NS], bl[NS];
+        float nu = 0.0f, nv = 0.0f;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            unsigned h[8], l[8], hv[8], lv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * st + 8 * half + i;
+                const float xu = k < d ? U[col * 132 + k] : 0.0f, xv = k < d ? V[col * 132 + k] : 0.0f;
+                nu += xu * xu;
+                nv += xv * xv;
+                bf16_split(xu, h[i], l[i]);
+                bf16_split(xv, hv[i], lv[i]);
+            }
+            bh[st] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            bl[st] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+            ah[st] = u32x4{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+            al[st] = u32x4{lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16), lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16)};
+        }
+        nu += __shfl_xor(nu, 32, WAVE);
+        nv += __shfl_xor(nv, 32, WAVE);
+        const float bu = U[col * 132 + d], bj = V[col * 132 + d];
+        u32x4 bjs = {0u, 0u, 0u, 0u};
+        if (half == 0) {
+            unsigned b1, b2;
+            bf16_split(bj, b1, b2);
+            const unsigned b3 = bf16_rn(__fsub_rn(__fsub_rn(bj, __uint_as_float(b1 << 16)), __uint_as_float(b2 << 16)));
+            bjs.x = b1 | (b2 << 16);
+            bjs.y = b3;
+        }
+        const u32x4 ones = {half ? 0u : 0x3f803f80u, half ? 0u : 0x00003f80u, 0u, 0u};
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(0.0f, bu);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[st]), __builtin_bit_cast(bf16x8, bh[st]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[st]), __builtin_bit_cast(bf16x8, bl[st]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[st]), __builtin_bit_cast(bf16x8, bh[st]), acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bjs), __builtin_bit_cast(bf16x8, ones), acc, 0, 0, 0);
+        const float kt = ranks_bf_kappa_t(d, NS), ks = ranks_bf_kappa_s();
+        const float unorm = sqrtf(nu);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = (r & 3) + 8 * (r >> 2) + 4 * half;  // row of the tile; column = this lane's user
+            const float *ur = U + col * 132, *vr = V + item * 132;
+            float ex = __fadd_rn(ur[d], vr[d]), vn = 0.0f;
+            for (int c = 0; c < d; ++c) {
+                ex = __fadd_rn(ex, __fmul_rn(ur[c], vr[c]));
+                vn += vr[c] * vr[c];
+            }
+            const float uv = unorm * sqrtf(vn);
+            const float band = kt * (fabsf(ur[d]) + fabsf(vr[d]) + uv) + ks * uv;
+            const float frac = fabsf(__fsub_rn(acc[r], ex)) / band;
+            worst = max(worst, __float_as_uint(frac));
+            beyond += frac > 1.0f ? 1u : 0u;
+        }
+    }
+    atomicMax(out, worst);
+    if (beyond) atomicAdd(out + 1, beyond);
+}
+
+hipError_t launch_ranks_bf_band_selftest(int64_t tiles, uint32_t seed, int d, int spread, unsigned *out, hipStream_t st)
+{
+    const int grid = (int)std::min<int64_t>(tiles, 8192);
+    if (d <= 32) ranks_bf_band_selftest_kernel<2><<<grid, 64, 0, st>>>(tiles, seed, d, spread, out);
+    else if (d <= 64) ranks_bf_band_selftest_kernel<4><<<grid, 64, 0, st>>>(tiles, seed, d, spread, out);
+    else if (d <= 128) ranks_bf_band_selftest_kernel<8><<<grid, 64, 0, st>>>(tiles, seed, d, spread, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // bytes of the table of bf16 pieces launch_ranks_mfma3 fills when RanksArgs::item_bf is set; 0 = outside the variant's scope
 size_t ranks_mfma3_bf_bytes(int d, int64_t n_items)
 {

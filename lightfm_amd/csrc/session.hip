@@ -892,6 +892,23 @@ extern "C" int lfm_selftest_adagrad_cell(int64_t n, uint32_t seed, float learnin
     return LFM_OK;
 }
 
+extern "C" int lfm_selftest_ranks_bf16_band(int64_t tiles, uint32_t seed, int32_t d, int32_t spread, float *worst_fraction, int64_t *beyond)
+{
+    if (tiles < 0 || d < 1 || d > 128 || spread < 1 || spread > 64 || !worst_fraction || !beyond) return fail(LFM_EINVAL, "bad self-test arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LFM_ENODEV, "no HIP device");
+    HIP_TRY(hipSetDevice(0));
+    DBuf<unsigned> out;
+    LFM_TRY(out.alloc(2));
+    HIP_TRY(hipMemset(out.p, 0, 2 * sizeof(unsigned)));
+    HIP_TRY(launch_ranks_bf_band_selftest(tiles, seed, d, spread, out.p, nullptr));
+    unsigned h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    memcpy(worst_fraction, &h[0], sizeof(float));
+    *beyond = (int64_t)h[1];
+    return LFM_OK;
+}
+
 extern "C" int lfm_session_set_features(lfm_session *s, const lfm_csr *item_features, const lfm_csr *user_features)
 {
     if (!s) return fail(LFM_EINVAL, "null session");

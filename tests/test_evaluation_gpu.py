@@ -363,3 +363,22 @@ def test_resident_train_matrix_is_revalidated_between_calls():
     np.testing.assert_array_equal(model.predict_rank(test, train_interactions=train_b).toarray(), r_a)
     # no train matrix
     np.testing.assert_array_equal(model.predict_rank(test).toarray(), _fresh_copy(model).predict_rank(test).toarray())
+
+
+@pytest.mark.parametrize("d", [3, 10, 32, 33, 64, 100, 128])
+def test_bf16_split_scores_stay_inside_their_rounding_band(d):
+    """predict_ranks' default sweep takes its products from the bf16 matrix pipe (two-way split operands) and re-decides every
+    comparison inside a rounding band with the reference's sequential dot; the band (csrc/predict_kernels.hip:
+    ranks_bf_kappa_t / _s) bounds the split's truncation and the accumulations, whose internal rounding the ISA leaves
+    unspecified (taken as faithful).  The device self-test runs 2 x 10^5 random 32 x 32 tiles per setting through the sweep's own
+    instruction sequence: no pair may leave its band, and the largest fraction of the band actually used is printed
+    (components of equal magnitude and spread over 6 / 14 binades)."""
+    import ctypes as C
+    from lightfm_amd import _native as N
+    assert N.device_count() > 0
+    for spread in (1, 6, 14):
+        worst, beyond = C.c_float(-1.0), C.c_int64(-1)
+        N.check(N.lib().lfm_selftest_ranks_bf16_band(C.c_int64(200_000), C.c_uint32(1234 + d), C.c_int32(d), C.c_int32(spread),
+                                                     C.byref(worst), C.byref(beyond)))
+        print("d %d, %d binades: largest |bf16-split score - sequential dot| = %.3f of the band, %d pairs beyond it" % (d, spread, worst.value, beyond.value))
+        assert beyond.value == 0 and 0.0 < worst.value < 1.0, (d, spread, worst.value, beyond.value)
