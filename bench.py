@@ -700,7 +700,10 @@ def ranks_leg(env, pieces):
            "roofline": {"bound": "mfma", "achieved": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": 2.0 * d * pairs / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                         "frac_of_call": 2.0 * d * pairs / wall / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "ranks_mfma3_kernel + test_scores / sortedness passes (HIP events around the call's kernels)"}}
+                        "kernel": "ranks_mfma3_kernel<.., bf16 pipe> + piece table / test_scores / sortedness passes (HIP events around the call's kernels)",
+                        "products": "2 d flops per pair, priced against the fp32 matrix peak (the arithmetic the ranks are exact in); they RUN as three "
+                                    "v_mfma_f32_32x32x16_bf16 per 16 components on two-way split operands (6 d flops per pair on a 2.5 PFLOP/s pipe) so that "
+                                    "they co-execute with the VALU search that bounds the kernel"}}
     if not env.args.no_cpu_baseline:
         try:
             from oracle import oracle
