@@ -771,8 +771,8 @@ __device__ __forceinline__ void ranks3_flush(int qn, int lane, const unsigned *q
 // step of 16 components is THREE v_mfma_f32_32x32x16_bf16 (h h, h l, l h) on operands that occupy the registers the fp32
 // operands did: 3 d / 16 + 1 instructions of 8 passes per tile instead of d / 2 + 1 of 16.  The item pieces come from a
 // table built once per call (item_bf_kernel: [step][piece][item][half] x 16 bytes, one buffer_load_dwordx4 per operand), the
-// user pieces are split when a work item starts; the item bias is one more step (three pieces against ones: exact to
-// 2^-24 |b_j|), the user bias the accumulator's initial value.  What this costs is a wider rounding band (ranks_bf_kappa
+// user pieces are split when a work item starts; the two biases stay ONE fp32 step, (b_j, 1) . (1, b_u), as in the fp32 sweep
+// (two registers; its 16 passes are 8 % of a tile's matrix time).  What this costs is a wider rounding band (ranks_bf_kappa
 // below: ~5 x the fp32 sweep's at d = 64), which the deferred re-checks make cheap (ranks3_flush).
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -793,7 +793,8 @@ __device__ __forceinline__ void bf16_split(float f, unsigned &h, unsigned &l)
 //   reference, PYX:320-334: d + 2 roundings of at most 2^-24 T each;
 //   the sweep: 16 (3 NS + 1) accumulations (NS = steps of 16 components) whose internal rounding the ISA does not specify --
 //   taken as 2^-23 each (faithful), on partial sums of at most (1 + 2^-8)^2 (1 + 2^-7) T;
-//   the split: sum_k |l_u l_v + r_u v + u r_v| <= 3.03 x 2^-16 sum_k |u_k v_k| <= 3.03 x 2^-16 |u| |v_j|; the bias pieces 2^-24 |b_j|;
+//   the split: sum_k |l_u l_v + r_u v + u r_v| <= 3.03 x 2^-16 sum_k |u_k v_k| <= 3.03 x 2^-16 |u| |v_j|; (the bias step is exact fp32 arithmetic:
+//   counted among the accumulations);
 // each with a quarter on top.  (d = 64: kT = 3.7e-5, kS = 4.7e-5 against the fp32 sweep's 4 (d + 2) 2^-24 = 1.6e-5.)
 __host__ __device__ __forceinline__ float ranks_bf_kappa_t(int d, int ns)
 {
@@ -802,35 +803,22 @@ __host__ __device__ __forceinline__ float ranks_bf_kappa_t(int d, int ns)
 __host__ __device__ __forceinline__ float ranks_bf_kappa_s() { return 1.25f * 3.03f * 1.52587890625e-5f; }
 __host__ __device__ __forceinline__ int ranks_bf_steps(int d) { return d <= 32 ? 2 : (d <= 64 ? 4 : 8); }
 
-// [step 0..NS][piece][item][half] x 16 bytes (step NS = the bias step: piece 0 only)
+// [step][piece][item][half] x 16 bytes
 __global__ void item_bf_kernel(const float *vT, int n_items, int d, int ns, u32x4 *out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per_step = (int64_t)n_items * 2;
-    if (t >= per_step * (ns + 1)) return;
+    if (t >= per_step * ns) return;
     const int st = (int)(t / per_step), j = (int)((t % per_step) >> 1), half = (int)(t & 1);
     unsigned h[8], l[8];
-    if (st < ns) {
-        for (int i = 0; i < 8; ++i) {
-            const int k = 16 * st + 8 * half + i;
-            bf16_split(k < d ? vT[(size_t)k * n_items + j] : 0.0f, h[i], l[i]);
-        }
-        u32x4 H = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-        u32x4 L = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-        out[((size_t)(2 * st) * n_items + j) * 2 + half] = H;
-        out[((size_t)(2 * st + 1) * n_items + j) * 2 + half] = L;
-    } else {
-        u32x4 B = {0u, 0u, 0u, 0u};
-        if (half == 0) {
-            const float bj = vT[(size_t)d * n_items + j];
-            unsigned b1, b2, b3;
-            bf16_split(bj, b1, b2);
-            b3 = bf16_rn(__fsub_rn(__fsub_rn(bj, __uint_as_float(b1 << 16)), __uint_as_float(b2 << 16)));
-            B.x = b1 | (b2 << 16);
-            B.y = b3;
-        }
-        out[((size_t)(2 * ns) * n_items + j) * 2 + half] = B;
+    for (int i = 0; i < 8; ++i) {
+        const int k = 16 * st + 8 * half + i;
+        bf16_split(k < d ? vT[(size_t)k * n_items + j] : 0.0f, h[i], l[i]);
     }
+    u32x4 H = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    u32x4 L = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    out[((size_t)(2 * st) * n_items + j) * 2 + half] = H;
+    out[((size_t)(2 * st + 1) * n_items + j) * 2 + half] = L;
 }
 
 // the item-side terms of the bf16-split sweep's band: kT |b_j| and (kT + kS) |v_j|
@@ -872,7 +860,7 @@ void ranks_mfma3_kernel(RanksArgs a)
     // BF: the table of bf16 pieces, 32 I bytes per (step, piece)
     const unsigned bstep = 32u * (unsigned)I;
     const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(BF ? (const void *)a.item_bf : (const void *)vT), 0,
-                                                                          BF ? (int)(bstep * (unsigned)(2 * NS + 1)) : 0, 0x00020000);
+                                                                          BF ? (int)(bstep * (unsigned)(2 * NS)) : 0, 0x00020000);
     const unsigned cb = 4u * (unsigned)col;
     const char *srt_b = (const char *)srt_s;
     char *hist_b = (char *)hist_s;
@@ -965,7 +953,7 @@ void ranks_mfma3_kernel(RanksArgs a)
         }
         // A operand of a tile: V[item j0 + col][2 kk + half], walked down the component-major table through ONE
         // buffer descriptor: a 32-bit lane offset, the row as the scalar offset (no per-load address arithmetic)
-        float av[KSTEPS], bj = 0.0f, bj2 = 0.0f, ej = 0.0f, njk = 0.0f;
+        float av[KSTEPS], bj = 0.0f, ej = 0.0f, njk = 0.0f;
         auto load_tile = [&](int j0) {
             const unsigned jc = (unsigned)min(j0 + col, I - 1);
             const unsigned voff = 4u * (jc + (unsigned)half * (unsigned)I);
@@ -979,9 +967,7 @@ void ranks_mfma3_kernel(RanksArgs a)
                     av[4 * q + 2] = __uint_as_float(x.z);
                     av[4 * q + 3] = __uint_as_float(x.w);
                 }
-                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(bsrc, boff, (unsigned)(2 * NS) * bstep, 0);
-                bj = __uint_as_float(x.x);   // the bias step's A operand: (b1, b2 | b3, 0 | 0 ...) in half 0, zeros in half 1
-                bj2 = __uint_as_float(x.y);
+                bj = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vsrc, 4u * jc, (unsigned)d * (row2 >> 1), 0));
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk)
@@ -1014,12 +1000,8 @@ void ranks_mfma3_kernel(RanksArgs a)
                 int off;  // 0 / -1 (written as the instruction: the compiler's own form is and + compare + select)
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(off) : "v"(tm), "n"(iA));
                 acc[r] = __int_as_float(off & (int)0xff800000);
-                if constexpr (BF) acc[r] = __fadd_rn(acc[r], bu);  // (the user bias: the accumulator's initial value)
             }
             if constexpr (BF) {
-                const u32x4 bjs = {__float_as_uint(bj), __float_as_uint(bj2), 0u, 0u};
-                // against ones in the first three components of half 0 (1.0 = 0x3f80)
-                const u32x4 ones = {half ? 0u : 0x3f803f80u, half ? 0u : 0x00003f80u, 0u, 0u};
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
                     const u32x4 ah = {__float_as_uint(av[8 * st]), __float_as_uint(av[8 * st + 1]), __float_as_uint(av[8 * st + 2]), __float_as_uint(av[8 * st + 3])};
@@ -1030,7 +1012,7 @@ void ranks_mfma3_kernel(RanksArgs a)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bjs), __builtin_bit_cast(bf16x8, ones), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_x, ub_x, acc, 0, 0, 0);  // the biases: one fp32 step, (b_j, 1) . (1, b_u)
             } else {
 #if LFM_R3X == 4
             // timing experiment (WRONG ranks): the products on the bf16 matrix pipe -- two-way split operands in the SAME registers
@@ -1178,7 +1160,7 @@ hipError_t launch_ranks_mfma3(const RanksArgs &a, hipStream_t st, int cus)
     if (a.item_bf) {  // the products on the bf16 matrix pipe (split operands; the deferred re-checks need the row-major rows)
         const int ns = ranks_bf_steps(a.d);
         item_eps_bf_kernel<<<(a.test.cols + 255) / 256, 256, 0, st>>>(a.item_rep, a.test.cols, a.d, ranks_bf_kappa_t(a.d, ns), ranks_bf_kappa_s(), a.item_eps);
-        const int64_t cells = (int64_t)a.test.cols * 2 * (ns + 1);
+        const int64_t cells = (int64_t)a.test.cols * 2 * ns;
         item_bf_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(a.item_rep, a.test.cols, a.d, ns, (u32x4 *)a.item_bf);
         if (a.d <= 32) return launch_ranks_mfma3_k<16, true>(a, st, cus);
         if (a.d <= 64) return launch_ranks_mfma3_k<32, true>(a, st, cus);
@@ -1240,25 +1222,16 @@ __global__ __launch_bounds__(64) void ranks_bf_band_selftest_kernel(int64_t tile
         nu += __shfl_xor(nu, 32, WAVE);
         nv += __shfl_xor(nv, 32, WAVE);
         const float bu = U[col * 132 + d], bj = V[col * 132 + d];
-        u32x4 bjs = {0u, 0u, 0u, 0u};
-        if (half == 0) {
-            unsigned b1, b2;
-            bf16_split(bj, b1, b2);
-            const unsigned b3 = bf16_rn(__fsub_rn(__fsub_rn(bj, __uint_as_float(b1 << 16)), __uint_as_float(b2 << 16)));
-            bjs.x = b1 | (b2 << 16);
-            bjs.y = b3;
-        }
-        const u32x4 ones = {half ? 0u : 0x3f803f80u, half ? 0u : 0x00003f80u, 0u, 0u};
         f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = __fadd_rn(0.0f, bu);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[st]), __builtin_bit_cast(bf16x8, bh[st]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[st]), __builtin_bit_cast(bf16x8, bl[st]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[st]), __builtin_bit_cast(bf16x8, bh[st]), acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bjs), __builtin_bit_cast(bf16x8, ones), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 1.0f : bj, half ? bu : 1.0f, acc, 0, 0, 0);
         const float kt = ranks_bf_kappa_t(d, NS), ks = ranks_bf_kappa_s();
         const float unorm = sqrtf(nu);
 #pragma unroll
@@ -1295,7 +1268,7 @@ hipError_t launch_ranks_bf_band_selftest(int64_t tiles, uint32_t seed, int d, in
 size_t ranks_mfma3_bf_bytes(int d, int64_t n_items)
 {
     if (!ranks_mfma_supported(d)) return 0;
-    const int64_t bytes = (int64_t)(2 * ranks_bf_steps(d) + 1) * 32 * n_items;
+    const int64_t bytes = (int64_t)(2 * ranks_bf_steps(d)) * 32 * n_items;
     return bytes < ((int64_t)1 << 31) ? (size_t)bytes : 0;
 }
 
