@@ -152,7 +152,9 @@ typedef struct lfm_opts {
                                    (csrc/hot_slices.hip) instead of by float atomics of every interaction; bit 6 = the narrow-model
                                    tile kernel ran (rows of <= 16 floats: two interactions per lane group, eight per
                                    wavefront pass; csrc/warp_tile_narrow.hpp); bit 7 = ... on rows that carry W, G, b and bG
-                                   of a feature in ONE 128-byte line (d <= 12: an update is three line operations)      */
+                                   of a feature in ONE 128-byte line (d <= 12: an update is three line operations); bit 8 = the
+                                   logistic lane-group kernel ran on such rows (csrc/logistic_tile.hip: identity features,
+                                   d <= 12 -- the reference's default LightFM())                                        */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

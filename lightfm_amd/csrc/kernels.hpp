@@ -73,6 +73,10 @@ hipError_t launch_fit_warp_tile_ahead(const FitArgs &a, int grid, hipStream_t st
 // per_cu_cap > 0 bounds the workgroups per CU
 size_t warp_tile_narrow_smem(int d, int max_sampled, int first_batch, int64_t n_items);
 hipError_t launch_fit_warp_tile_narrow(const FitArgs &a, int grid, hipStream_t st, int cus, int per_cu_cap, int *grid_used = nullptr);
+// logistic_tile.hip: fit_logistic for narrow identity models (d <= 12: the reference's default LightFM()) on the one-line-per-feature
+// rows (FitArgs::rp with the bias cells); 0 = outside its scope, else the LDS bytes of a workgroup
+size_t logistic_tile_smem(int d, int64_t n_users, int64_t n_items);
+hipError_t launch_fit_logistic_tile(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used = nullptr);
 // feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...

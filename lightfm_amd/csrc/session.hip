@@ -2513,10 +2513,23 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                       "features, adagrad, no regularisation, d <= 64, max_sampled = 10)");
     // Every other parallel-mode adagrad model (with or without L2 regularisation): the pipelined row-stream kernels
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
+    // fit_logistic of a NARROW identity model (the reference's default LightFM(): logistic, no_components = 10): the
+    // lane-group kernel on one-line-per-feature rows (logistic_tile.hip) -- adagrad, no L2 penalty, atomic publication
+    const bool use_ltile = !serial && !use_tile && loss == LFM_LOSS_LOGISTIC && s->itf.identity && s->usf.identity && !s->adadelta &&
+                           item_alpha == 0.0 && user_alpha == 0.0 && a.update_mode == 0 && opts->feat_kernel == 0 && s->shards.n == 0 &&
+                           s->n > 0 && logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]) != 0;
+    if (use_ltile) {
+        if (!s->recs_valid) {
+            LFM_TRY(s->recs.alloc((size_t)s->n));
+            HIP_TRY(launch_pack_records(a.user_ids, a.item_ids, a.Y, a.weight, s->n, s->recs.p, s->stream));
+            s->recs_valid = true;
+        }
+        a.recs = s->recs.p;
+    }
     FeatPlan fplan;
     bool use_feat = false;
     // (adadelta: the ADA instantiations, d <= 128 and not the instrumented build; wider adadelta models run the generic kernels)
-    if (!serial && !use_tile && opts->feat_kernel != 1 && !(s->adadelta && (s->d > 128 || opts->feat_kernel == 2)) && s->itf.rows >= 1 && s->n > 0) {
+    if (!serial && !use_tile && !use_ltile && opts->feat_kernel != 1 && !(s->adadelta && (s->d > 128 || opts->feat_kernel == 2)) && s->itf.rows >= 1 && s->n > 0) {
         auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
         const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
         use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan);
@@ -2679,6 +2692,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 a.tile_stride = t.stride;
                 a.first_batch = t.first_batch;
             }
+            if (use_ltile) {
+                lsmem = logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]);
+                per_wave = 8;
+            }
             // row-stream kernels: 8 wavefronts per CU publish fastest (C3: 43 M/s at 2 048 interactions
             // in flight against 35 M/s at 3 072 -- the float atomics queue up in the fabric)
             // (LIGHTFM_AMD_FEAT_WAVES_PER_CU: experiments with the row-stream kernels' residency; their LDS budget per
@@ -2689,7 +2706,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
             bool below_residency = allowed / (wpb * per_wave) < max_grid;
-            if (ng && tile[ng].narrow && below_residency && !fixed_cap) {
+            if (((ng && tile[ng].narrow) || use_ltile) && below_residency && !fixed_cap) {
                 // the narrow-model kernel keeps 128 interactions per CU in flight: on a catalogue of a few ten thousand items it
                 // is the STEADY-STATE bound (never more in flight than the smaller side has rows) that binds, not the history
                 // ramp -- such launches are full-length and alternate between the two streams like any launch at residency
@@ -2744,7 +2761,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // (tile kernel only: its grid IS the hardware's residency.  The row-stream and generic kernels are launched
             // with fewer workgroups than would fit -- 8 wavefronts per CU publish fastest -- and two of their launches
             // side by side would double the interactions in flight: C3 fell from 42.5 to 37.6 M interactions/s)
-            if (two_streams && ng && !below_residency && !fixed_cap) {
+            if (two_streams && (ng || use_ltile) && !below_residency && !fixed_cap) {
                 par = n_full++ & 1;
                 if (par) {
                     if (!s->stream2) {
@@ -2829,6 +2846,18 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 else if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
                 else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                                   &grid_used, tile[ng].dma4));
+            }
+            else if (use_ltile) {
+                if (s->pairs_live) {  // (does not happen: no other kernel of a logistic epoch packs them)
+                    if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
+                    LFM_TRY(bias_pairs_unpack(s, s->stream));
+                }
+                if (!s->rows_live) LFM_TRY(row_pairs_pack(s, s->stream, true));  // (before the streams fork: both see it)
+                a.rp[0] = s->row_pairs[0].p;
+                a.rp[1] = s->row_pairs[1].p;
+                a.rp_bias = 1;
+                HIP_TRY(launch_fit_logistic_tile(a, grid, lst, s->cus, &grid_used));
+                plan_flags |= 128 | 256;
             }
             else if (use_feat && hot_launch) {
                 lfm_session::HotSet &h = s->hot;
@@ -2943,7 +2972,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     for (int i = 0; i < 4; ++i) opts->counters[i] = (int64_t)c[i];
     for (int i = 0; i < 8; ++i) opts->phase_cycles[i] = (int64_t)c[4 + i];
     opts->tile_ng = tile_ng_used;
-    opts->kernel_used = tile_ng_used ? 1 : (use_feat ? 2 : 0);
+    opts->kernel_used = (tile_ng_used || use_ltile) ? 1 : (use_feat ? 2 : 0);
     opts->in_flight = in_flight;
     opts->launches = n_launches;
     opts->streams_used = used_second_stream ? 2 : 1;
