@@ -10,7 +10,7 @@ namespace lfm {
 // (+ 3 * pair_cap k-OS slots).  The budget per wavefront decides how many wavefronts a CU holds
 // (160 KiB LDS): many rows in flight per wavefront against many wavefronts.
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap,
-               bool few_atomics)
+               bool few_atomics, bool no_shared_rows)
 {
     if (d < 4 || d > 256 || (d & 3) != 0 || max_sampled < 0) return false;
     FeatPlan g;
@@ -51,9 +51,12 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     int waves_per_cu = 8, min_sr = 8;
     // (few_atomics: BPR / logistic whose shared rows are accumulated in LDS slices, session.hip: HotSet -- no longer bound by
     // the atomic unit, they take the twelve wavefronts too: C3 80.8 -> 83.5 M/s, profiles/r06_hot_overlap_ab.txt)
-    if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID || few_atomics)) {
+    // (no_shared_rows: BPR / logistic / WARP over identity features on both sides -- every row has few concurrent writers, the
+    // atomic unit is not what bounds them: sixteen wavefronts too.  ML-20M shape, d = 64: logistic 327 -> 553 M interactions/s,
+    // BPR 226 -> 378, profiles/r06_logistic_tile.txt)
+    if (budget_kb <= 0 && (loss == LFM_LOSS_WARP_ID || loss == LFM_LOSS_WARP_KOS_ID || few_atomics || no_shared_rows)) {
         const size_t b12 = (size_t)(156 * 1024 / 12) & ~(size_t)255, b16 = (size_t)(160 * 1024 / 16);
-        if (loss == LFM_LOSS_WARP_KOS_ID && b16 >= tile_bytes + 2 * WAVE * 4 + (size_t)6 * d * 4) {
+        if ((loss == LFM_LOSS_WARP_KOS_ID || no_shared_rows) && b16 >= tile_bytes + 2 * WAVE * 4 + (size_t)6 * d * 4) {
             budget = b16;
             waves_per_cu = 16;
             min_sr = 6;

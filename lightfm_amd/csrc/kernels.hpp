@@ -85,8 +85,10 @@ struct FeatPlan {
     size_t smem;  // LDS bytes per workgroup
 };
 // rows_hint: rows of a typical update list (f_user + 2 f_item), so that one chunk covers it
+// no_shared_rows: identity features on both sides -- no row has many concurrent writers, the atomic unit is not the bound:
+// sixteen wavefronts per CU where a sixteenth of the LDS holds the plan
 bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batch, int rows_hint, FeatPlan *p, size_t budget_cap = 0,
-               bool few_atomics = false);
+               bool few_atomics = false, bool no_shared_rows = false);
 hipError_t launch_fit_feat(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus,
                            int *grid_used = nullptr, bool timed = false);
 // feat_kernels_ada.hip: the adadelta instantiations of the row-stream kernels (d <= 128)

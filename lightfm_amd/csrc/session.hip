@@ -2532,7 +2532,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     if (!serial && !use_tile && !use_ltile && opts->feat_kernel != 1 && !(s->adadelta && (s->d > 128 || opts->feat_kernel == 2)) && s->itf.rows >= 1 && s->n > 0) {
         auto avg_len = [](const DevCsr &f) { return f.identity || f.rows <= 0 ? 1.0 : (double)f.nnz / (double)f.rows; };
         const int rows_hint = (int)(avg_len(s->usf) + 2.0 * avg_len(s->itf) + 0.999);
-        use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan);
+        const bool no_shared_rows = s->itf.identity && s->usf.identity && !s->adadelta;
+        use_feat = feat_plan(loss, s->d, s->max_sampled, n_positives, opts->first_batch, rows_hint, &fplan, 0, false, no_shared_rows);
         if (use_feat && loss != LFM_LOSS_WARP_KOS) {
             if (!s->recs_valid) {
                 LFM_TRY(s->recs.alloc((size_t)s->n));
