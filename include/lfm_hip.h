@@ -154,7 +154,7 @@ typedef struct lfm_opts {
                                    wavefront pass; csrc/warp_tile_narrow.hpp); bit 7 = ... on rows that carry W, G, b and bG
                                    of a feature in ONE 128-byte line (d <= 12: an update is three line operations); bit 8 = the
                                    logistic lane-group kernel ran on such rows (csrc/logistic_tile.hip: identity features,
-                                   d <= 12 -- the reference's default LightFM())                                        */
+                                   d <= 12 -- the reference's default LightFM()); bit 9 = its BPR counterpart ran       */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

@@ -77,6 +77,10 @@ hipError_t launch_fit_warp_tile_narrow(const FitArgs &a, int grid, hipStream_t s
 // rows (FitArgs::rp with the bias cells); 0 = outside its scope, else the LDS bytes of a workgroup
 size_t logistic_tile_smem(int d, int64_t n_users, int64_t n_items);
 hipError_t launch_fit_logistic_tile(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used = nullptr);
+// ... and fit_bpr for the same models (needs FitArgs::pos, item_ids, seeds)
+size_t bpr_tile_smem(int d, int64_t n_users, int64_t n_items);
+int bpr_tile_per_wave();  // interactions of a wavefront pass
+hipError_t launch_fit_bpr_tile(const FitArgs &a, int grid, hipStream_t st, int cus, int *grid_used = nullptr);
 // feat_kernels.hip: pipelined row-stream kernels (feature CSRs, BPR, k-OS, logistic; feat_kernel.hpp)
 struct FeatPlan {
     int rr, ts, sr, cand_base, pair_cap, first_batch;  // tile rows / stride, stage rows, ...

@@ -2515,9 +2515,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
     // fit_logistic of a NARROW identity model (the reference's default LightFM(): logistic, no_components = 10): the
     // lane-group kernel on one-line-per-feature rows (logistic_tile.hip) -- adagrad, no L2 penalty, atomic publication
-    const bool use_ltile = !serial && !use_tile && loss == LFM_LOSS_LOGISTIC && s->itf.identity && s->usf.identity && !s->adadelta &&
+    // ... and fit_bpr of the same models (three lines per interaction, candidates drawn from the interaction list)
+    const size_t ltile_smem = loss == LFM_LOSS_LOGISTIC ? logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0])
+                              : (loss == LFM_LOSS_BPR ? bpr_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]) : 0);
+    const bool use_ltile = !serial && !use_tile && s->itf.identity && s->usf.identity && !s->adadelta &&
                            item_alpha == 0.0 && user_alpha == 0.0 && a.update_mode == 0 && opts->feat_kernel == 0 && s->shards.n == 0 &&
-                           s->n > 0 && logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]) != 0;
+                           s->n > 0 && ltile_smem != 0 && (loss == LFM_LOSS_LOGISTIC || (s->pos.indptr.p != nullptr && s->item_ids.p != nullptr));
     if (use_ltile) {
         if (!s->recs_valid) {
             LFM_TRY(s->recs.alloc((size_t)s->n));
@@ -2694,8 +2697,8 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 a.first_batch = t.first_batch;
             }
             if (use_ltile) {
-                lsmem = logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]);
-                per_wave = 8;
+                lsmem = ltile_smem;
+                per_wave = loss == LFM_LOSS_LOGISTIC ? 8 : bpr_tile_per_wave();
             }
             // row-stream kernels: 8 wavefronts per CU publish fastest (C3: 43 M/s at 2 048 interactions
             // in flight against 35 M/s at 3 072 -- the float atomics queue up in the fabric)
@@ -2857,8 +2860,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 a.rp[0] = s->row_pairs[0].p;
                 a.rp[1] = s->row_pairs[1].p;
                 a.rp_bias = 1;
-                HIP_TRY(launch_fit_logistic_tile(a, grid, lst, s->cus, &grid_used));
-                plan_flags |= 128 | 256;
+                if (loss == LFM_LOSS_LOGISTIC) HIP_TRY(launch_fit_logistic_tile(a, grid, lst, s->cus, &grid_used));
+                else HIP_TRY(launch_fit_bpr_tile(a, grid, lst, s->cus, &grid_used));
+                plan_flags |= 128 | (loss == LFM_LOSS_LOGISTIC ? 256 : 512);
             }
             else if (use_feat && hot_launch) {
                 lfm_session::HotSet &h = s->hot;

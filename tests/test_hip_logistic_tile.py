@@ -151,3 +151,121 @@ def test_training_learns_like_the_row_stream_kernel(monkeypatch):
         acc[arm] = float(np.mean((p > 0) == (data.data > 0)))
     print("accuracy on the training labels", acc)
     assert acc["tile"] > 0.7 and abs(acc["tile"] - acc["row-stream"]) < 0.01, acc
+
+
+# ------------------------------------------------------------------------------------------------ fit_bpr_tile_kernel
+
+def _hip_bpr(fast, coo, st, shuffle, seeds, weight):
+    Cm = fast.CSRMatrix
+    fl = fast.FastLightFM(*st.arrays(), st.d, 0, st.lr, st.rho, st.eps, st.max_sampled)
+    item_f, user_f = H.identity_features(coo.shape[1]), H.identity_features(coo.shape[0])
+    fast.fit_bpr(Cm(item_f), Cm(user_f), Cm(H.positives_csr(coo)), coo.row, coo.col, coo.data, weight, shuffle, fl, 0.05, 0.0, 0.0,
+                 len(seeds), H.FixedRandom(seeds))
+
+
+def _orc_bpr(coo, st, shuffle, seeds, weight):
+    o = oracle.Opts(len(shuffle), rng_mode=1, log=True)
+    item_f, user_f = H.identity_features(coo.shape[1]), H.identity_features(coo.shape[0])
+    oracle.fit_bpr(item_f, user_f, H.positives_csr(coo), coo.row, coo.col, coo.data, weight, shuffle, st, 0.0, 0.0, seeds, o)
+    return o
+
+
+@pytest.mark.parametrize("d", [4, 10, 12])
+def test_bpr_one_interaction_per_launch_matches_the_oracle(fast, d):
+    """Dense rows (a third of the catalogue per user): the first candidate is a positive in a third of the interactions, both
+    are in a ninth (the one-draw-at-a-time path with its late line fetch).  Sequential launches: negatives, draw counts and
+    counters exact, the arrays within the bar of float-atomic publication."""
+    from lightfm_amd.options import options
+    nu, ni = 24, 60
+    rng = np.random.RandomState(8 + d)
+    dense = rng.rand(nu, ni) < 0.33
+    dense[:, 0] = True
+    m = sp.coo_matrix(dense.astype(np.float32))
+    vals = (1.0 + rng.rand(m.nnz)).astype(np.float32)
+    vals[rng.rand(m.nnz) < 0.1] = 0.0  # (PYX:1116-1117: not a positive, skipped before any draw)
+    coo = sp.coo_matrix((vals, (m.row.astype(np.int32), m.col.astype(np.int32))), shape=(nu, ni), dtype=np.float32)
+    st = _state(ni, nu, d, 3)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=coo.nnz, update_mode=0)
+    multi = 0
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _hip_bpr(fast, coo, a, shuffle, seeds, coo.data)
+        assert options.last_kernel_used == 1 and options.last_plan_flags & 512, (options.last_kernel_used, options.last_plan_flags)
+        o = _orc_bpr(coo, b, shuffle, seeds, coo.data)
+        neg, sampled = options.last_logs
+        assert np.array_equal(sampled, o.sampled), int((sampled != o.sampled).sum())
+        assert np.array_equal(neg, o.neg), int((neg != o.neg).sum())
+        assert options.last_counters == o.counters
+        multi += int((o.sampled > 2).sum())
+    assert multi > 20, "the path past the two speculative candidates is not exercised"
+    assert not np.array_equal(a.item_embeddings, st.item_embeddings) and not np.array_equal(a.item_biases, st.item_biases)
+    H.assert_states_equal(a, b, exact=False, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [4, 12])
+def test_bpr_user_with_the_whole_catalogue(fast, d):
+    """Every draw is one of the user's positives, and the last of the no_examples draws may be the positive itself (PYX:1123-1127:
+    the loop ends on its bound): the reference then updates ONE row twice in sequence, first as the positive, then as the negative."""
+    from lightfm_amd.options import options
+    nu, ni = 2, 7
+    rng = np.random.RandomState(d)
+    coo = sp.coo_matrix(np.ones((nu, ni), dtype=np.float32))
+    coo = sp.coo_matrix(((1.0 + rng.rand(coo.nnz)).astype(np.float32), (coo.row.astype(np.int32), coo.col.astype(np.int32))), shape=(nu, ni))
+    st = _state(ni, nu, d, 5)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=coo.nnz, update_mode=0)
+    same = 0
+    for _ in range(3):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _hip_bpr(fast, coo, a, shuffle, seeds, coo.data)
+        assert options.last_plan_flags & 512
+        o = _orc_bpr(coo, b, shuffle, seeds, coo.data)
+        neg, sampled = options.last_logs
+        assert np.array_equal(sampled, o.sampled) and np.array_equal(neg, o.neg) and (o.sampled == coo.nnz).all()
+        same += int((o.neg == coo.col[shuffle]).sum())
+    assert same >= 3, "no interaction drew its own positive last"
+    H.assert_states_equal(a, b, exact=False, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [4, 10, 12])
+@pytest.mark.parametrize("waves", [0, 8], ids=["full-grid", "two-workgroups-many-passes"])
+def test_bpr_frozen_weights_samples_exact(fast, d, waves):
+    """sample_weight = 0 freezes the model (the reference's own trick): across the whole grid and with two workgroups walking
+    hundreds of passes -- records three passes deep, candidates requested two passes ahead, launch tails inside a pass -- every
+    position's negative and draw count and the counters equal the oracle's, and no array moves."""
+    from lightfm_amd.options import options
+    nu, ni = 3000, 500
+    coo = H.make_interactions(nu, ni, 60_011, seed=29, ratings=True, zipf=0.7)
+    rng = np.random.RandomState(4)
+    st = _state(ni, nu, d, 6)
+    a, b = st.copy(), st.copy()
+    zeros = np.zeros_like(coo.data)
+    shuffle, seeds = H.epoch_inputs(coo, rng)
+    options.set(log_samples=True, launches_per_epoch=3, ramp_k=-1, max_waves=waves)
+    _hip_bpr(fast, coo, a, shuffle, seeds, zeros)
+    assert options.last_kernel_used == 1 and options.last_plan_flags & 512
+    o = _orc_bpr(coo, b, shuffle, seeds, zeros)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled), "draw counts differ at %d positions" % int((sampled != o.sampled).sum())
+    assert np.array_equal(neg, o.neg), "negatives differ at %d positions" % int((neg != o.neg).sum())
+    assert options.last_counters == o.counters
+    assert (o.sampled > 2).sum() > 50
+    H.assert_states_equal(a, st, exact=True)
+
+
+def test_bpr_training_learns_like_the_row_stream_kernel(monkeypatch):
+    from lightfm_amd import LightFM
+    coo = H.make_interactions(14000, 11000, 450_000, seed=12, zipf=0.8)
+    rows, cols = np.ascontiguousarray(coo.row), np.ascontiguousarray(coo.col)
+    negs = np.random.RandomState(0).randint(0, 11000, size=coo.nnz).astype(np.int32)
+    acc = {}
+    for arm, env in (("tile", "1"), ("row-stream", "0")):
+        monkeypatch.setenv("LIGHTFM_AMD_BPR_TILE", env)
+        m = LightFM(loss="bpr", random_state=7)  # no_components = 10
+        m.fit(coo, epochs=6)
+        st = m._last_epoch_stats[-1]
+        assert bool(st["plan_flags"] & 512) == (arm == "tile") and st["kernel_used"] == (1 if arm == "tile" else 2), (arm, st)
+        acc[arm] = float(np.mean(m.predict(rows, cols) > m.predict(rows, negs)))
+    print("pairwise accuracy", acc)
+    assert acc["tile"] > 0.6 and abs(acc["tile"] - acc["row-stream"]) < 0.01, acc  # (both arms: 0.645 after six epochs)
