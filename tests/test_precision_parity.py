@@ -126,26 +126,46 @@ def test_warp_identity_c2_regime_regularised():
     _gap("warp", 64, train, test, None, epochs=5, item_alpha=1e-6, user_alpha=1e-6)
 
 
-@pytest.mark.timeout(900)
-def test_logistic_with_explicit_negatives():
-    """fit_logistic (PYX:694-781) in the SHIPPED (parallel) mode -- round-5 verdict, weak #3: the one loss without a quality
-    gate of its own.  Logistic needs both labels: the train split's positives plus as many uniformly drawn (user, item)
-    pairs with the value -1 (PYX:744-748: y <= 0 is the label 0); precision@10 on the held-out positives, as for the
-    other losses.  Identity features, no_components = 64: the row-stream kernel's logistic instantiation."""
+def _with_explicit_negatives(train, test):
+    """Logistic needs both labels: the train split's positives plus as many uniformly drawn (user, item) pairs with the value
+    -1 (PYX:744-748: y <= 0 is the label 0); a drawn pair that is a positive of either split is dropped."""
     import scipy.sparse as sp
-    train, test = _data(8656, 6686, 1_000_000)
     rng = np.random.RandomState(5)
     nu, ni = train.shape
     neg_r = rng.randint(0, nu, size=train.nnz).astype(np.int32)
     neg_c = rng.randint(0, ni, size=train.nnz).astype(np.int32)
     taken = np.concatenate([train.row.astype(np.int64) * ni + train.col, test.row.astype(np.int64) * ni + test.col])
-    free = ~np.isin(neg_r.astype(np.int64) * ni + neg_c, taken)  # (a drawn pair that is a positive of either split is dropped)
+    free = ~np.isin(neg_r.astype(np.int64) * ni + neg_c, taken)
     neg_r, neg_c = neg_r[free], neg_c[free]
     order = rng.permutation(train.nnz + len(neg_r))
-    both = sp.coo_matrix((np.concatenate([np.ones(train.nnz, np.float32), -np.ones(len(neg_r), np.float32)])[order],
+    return sp.coo_matrix((np.concatenate([np.ones(train.nnz, np.float32), -np.ones(len(neg_r), np.float32)])[order],
                           (np.concatenate([train.row, neg_r])[order], np.concatenate([train.col, neg_c])[order])),
                          shape=train.shape, dtype=np.float32)
-    _gap("logistic", 64, both, test, None, epochs=5, n_seeds=8)
+
+
+@pytest.mark.timeout(900)
+def test_logistic_with_explicit_negatives():
+    """fit_logistic (PYX:694-781) in the SHIPPED (parallel) mode -- round-5 verdict, weak #3: the one loss without a quality
+    gate of its own.  Precision@10 on the held-out positives, as for the other losses.  Identity features,
+    no_components = 64: the row-stream kernel's logistic instantiation."""
+    train, test = _data(8656, 6686, 1_000_000)
+    _gap("logistic", 64, _with_explicit_negatives(train, test), test, None, epochs=5, n_seeds=8)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("loss", ["logistic", "bpr"])
+def test_default_width_lane_group_kernels(loss):
+    """The reference's default width (no_components = 10, LFM:191; LightFM() itself is logistic) on identity features: the
+    lane-group kernels of csrc/logistic_tile.hip (asserted: plan_flags bit 8 / 9) at their full concurrency."""
+    from lightfm_amd import LightFM
+    train, test = _data(8656, 6686, 1_000_000)
+    fit_on = _with_explicit_negatives(train, test) if loss == "logistic" else train
+    probe = LightFM(no_components=10, loss=loss, random_state=1)
+    probe.fit(fit_on, epochs=1)
+    st = probe._last_epoch_stats[-1]
+    assert st["kernel_used"] == 1 and st["plan_flags"] & (256 if loss == "logistic" else 512), st
+    # (a fit takes a second here: 32 seeds per side resolve the gate -- standard error of the difference 0.0013; eight left it at 0.003)
+    _gap(loss, 10, fit_on, test, None, epochs=5, n_seeds=32)
 
 
 def _small_seeds(default):
