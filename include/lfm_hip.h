@@ -31,6 +31,12 @@ extern "C" {
 #define LFM_ENOMEM (-3)   /* device or host allocation failed */
 #define LFM_ECOMM (-4)    /* RCCL failure */
 #define LFM_EUNSUPPORTED (-5)
+
+/* Widest model lfm_session_create accepts (the reference has no bound on no_components, PYX:185-259; here a lane of the
+ * one-interaction-per-wavefront kernels keeps up to 16 coordinates of a row): LFM_EUNSUPPORTED beyond. */
+#ifndef LFM_MAX_COMPONENTS
+#define LFM_MAX_COMPONENTS 1024
+#endif
 #define LFM_ECORRUPT (-6) /* an epoch kernel read a shuffle entry outside [0, n) (invalid shuffle input or
                               corrupted device memory); LIGHTFM_AMD_VALIDATE=1 (debugging): a read-only device input of the session
                              changed, or the shuffle slot is not a permutation (csrc/session.hip) */

@@ -21,6 +21,9 @@ namespace lfm {
 
 constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef LFM_MAX_COMPONENTS
+#define LFM_MAX_COMPONENTS 1024  // include/lfm_hip.h: widest model (the generic kernels' NC = 16 coordinates per lane)
+#endif
 constexpr double MAX_REG_SCALE = 1000000.0;  // PYX:19
 constexpr double MAX_LOSS = 10.0;            // PYX:817
 // loss ids of include/lfm_hip.h (LFM_LOSS_*)

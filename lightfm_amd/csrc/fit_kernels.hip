@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void fit_warp_kos_kernel(FitArgs a)
 
 // ---------------------------------------------------- lazy regularisation ---
 
+#ifndef LFM_FIT_WIDE_UNIT
 // Parallel mode (device.hpp: RegScale): reg_log[2] = log(item_scale), log(user_scale) at the last launch
 // boundary (float64 running totals); reg_live = line 0 {the same as float32, the growth of the logs per
 // position measured over the last launch}, lines 1.. {slots collecting the growth of the logs since then}.
@@ -533,6 +534,8 @@ __global__ void nonfinite_kernel(const float *x, int64_t n, int *flag)
 
 // ---------------------------------------------------------------- launch ---
 
+#endif  // LFM_FIT_WIDE_UNIT
+
 // Launch with the grid capped at what is actually resident (blocks/CU from the
 // occupancy query x CUs): every wavefront then runs its grid-stride loop from the
 // start of the launch instead of queueing behind a first wave of blocks.
@@ -545,6 +548,10 @@ static hipError_t launch_resident(K kernel, const FitArgs &a, int grid, int bloc
         if (per_cu > 0) grid = std::min(grid, per_cu * cus);
     }
     if (grid_used) *grid_used = grid;
+    if (smem > 64 * 1024) {  // (rows wider than 1 024 floats, long k-OS pair buffers: beyond the default dynamic LDS bound)
+        const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     kernel<<<grid, block, smem, st>>>(a);
     return hipGetLastError();
 }
@@ -567,6 +574,15 @@ static hipError_t launch_nc(int loss, const FitArgs &a, int grid, int block, siz
     return hipGetLastError();
 }
 
+#ifdef LFM_FIT_WIDE_UNIT
+// fit_kernels_wide.hip: 512 < d <= LFM_MAX_COMPONENTS (the reference has no bound on no_components, PYX:185-259: a lane keeps
+// 16 coordinates of a row)
+hipError_t launch_fit_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus, int *grid_used)
+{
+    if (a.m.d <= LFM_MAX_COMPONENTS) return launch_nc<16>(loss, a, grid, block, smem, st, cus, grid_used);
+    return hipErrorInvalidValue;
+}
+#else
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
                       int cus, int *grid_used)
 {
@@ -575,7 +591,7 @@ hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t sm
     if (d <= 128) return launch_nc<2>(loss, a, grid, block, smem, st, cus, grid_used);
     if (d <= 256) return launch_nc<4>(loss, a, grid, block, smem, st, cus, grid_used);
     if (d <= 512) return launch_nc<8>(loss, a, grid, block, smem, st, cus, grid_used);
-    return hipErrorInvalidValue;
+    return launch_fit_wide(loss, a, grid, block, smem, st, cus, grid_used);
 }
 
 hipError_t launch_reg_log_init(const double *scales, double *reg_log, float *reg_live, hipStream_t st)
@@ -603,5 +619,7 @@ hipError_t launch_nonfinite(const float *x, int64_t n, int *flag, hipStream_t st
     nonfinite_kernel<<<grid, 256, 0, st>>>(x, n, flag);
     return hipGetLastError();
 }
+
+#endif  // LFM_FIT_WIDE_UNIT
 
 }  // namespace lfm

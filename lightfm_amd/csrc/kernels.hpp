@@ -59,6 +59,8 @@ struct RanksArgs {
 // grid_used (optional): the grid actually launched (after the residency clamp)
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
                       int cus = 0, int *grid_used = nullptr);
+// fit_kernels_wide.hip: the same kernels for 512 < d <= LFM_MAX_COMPONENTS
+hipError_t launch_fit_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus, int *grid_used);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)
 // ng = interactions per wavefront pass (1, 2, 4); vec = floats of a row per lane
 // dma4: the LDS-DMA (global_load_lds_dwordx4) variant of ng = 4 with its candidate-major tile

@@ -1330,6 +1330,10 @@ __global__ void auc_kernel(DCsr ranks, const int32_t *ntp, float *rank_data, flo
 template <int NC>
 static hipError_t predict_nc(const PredictArgs &a, int grid, size_t smem, hipStream_t st)
 {
+    if (smem > 64 * 1024) {  // (two rows of more than 2 000 floats per wavefront)
+        const hipError_t e = hipFuncSetAttribute((const void *)predict_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     predict_kernel<NC><<<grid, 256, smem, st>>>(a);
     return hipGetLastError();
 }
@@ -1341,6 +1345,7 @@ hipError_t launch_predict(const PredictArgs &a, int grid, size_t smem, hipStream
     if (d <= 128) return predict_nc<2>(a, grid, smem, st);
     if (d <= 256) return predict_nc<4>(a, grid, smem, st);
     if (d <= 512) return predict_nc<8>(a, grid, smem, st);
+    if (d <= LFM_MAX_COMPONENTS) return predict_nc<16>(a, grid, smem, st);
     return hipErrorInvalidValue;
 }
 
@@ -1353,6 +1358,7 @@ hipError_t launch_rep_rows(const DCsr &f, const float *W, const float *b, int d,
     else if (d <= 128) rep_rows_kernel<2><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
     else if (d <= 256) rep_rows_kernel<4><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
     else if (d <= 512) rep_rows_kernel<8><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
+    else if (d <= LFM_MAX_COMPONENTS) rep_rows_kernel<16><<<grid, 256, 0, st>>>(f, W, b, d, rs, out, transposed, bias_out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -736,7 +736,7 @@ static int validate_model(const lfm_model *m, bool scoring = false)
 {
     if (!m) return fail(LFM_EINVAL, "null model");
     if (m->d <= 0) return fail(LFM_EINVAL, "no_components must be positive");
-    if (m->d > 512) return fail(LFM_EUNSUPPORTED, "no_components > 512 is not supported by the HIP backend");
+    if (m->d > LFM_MAX_COMPONENTS) return fail(LFM_EUNSUPPORTED, "no_components > 1024 is not supported by the HIP backend");
     if (m->n_item_feat < 0 || m->n_user_feat < 0) return fail(LFM_EINVAL, "negative feature count");
     for (int s = 0; s < 2; ++s)
         for (int k = 0; k < 6; ++k)

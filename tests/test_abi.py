@@ -94,10 +94,10 @@ def test_argument_validation_happens_before_the_device_is_touched(native):
     bad = fast.CSRMatrix(sp.identity(ni, dtype=np.float32, format="csr"))
     bad.indptr[-1] += 1                                                       # indptr does not span nnz
     assert create(model.byref(), bad.byref(), usf.byref()) == -1
-    big = fast.FastLightFM(*[np.zeros((ni, 600), np.float32)] * 3, *[np.zeros(ni, np.float32)] * 3,
-                           *[np.zeros((nu, 600), np.float32)] * 3, *[np.zeros(nu, np.float32)] * 3,
-                           600, 0, 0.05, 0.95, 1e-6, 10)
-    assert create(big.byref(), itf.byref(), usf.byref()) == -5               # LFM_EUNSUPPORTED: d > 512
+    big = fast.FastLightFM(*[np.zeros((ni, 1100), np.float32)] * 3, *[np.zeros(ni, np.float32)] * 3,
+                           *[np.zeros((nu, 1100), np.float32)] * 3, *[np.zeros(nu, np.float32)] * 3,
+                           1100, 0, 0.05, 0.95, 1e-6, 10)
+    assert create(big.byref(), itf.byref(), usf.byref()) == -5               # LFM_EUNSUPPORTED: d > LFM_MAX_COMPONENTS = 1 024
     with pytest.raises(NotImplementedError):
         native.check(-5)
     with pytest.raises(ValueError):

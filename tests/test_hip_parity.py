@@ -241,6 +241,74 @@ def test_predict_ranks_auc_exact(fast, case):
     assert np.array_equal(ranks_a.data, ranks_b.data)
 
 
+# ------------------------------------------------------------------------------------------ models wider than 512 components
+# (the reference has no bound on no_components, PYX:185-259; fit_kernels_wide.hip: sixteen coordinates per lane, d <= 1 024)
+
+WIDE_CASES = [
+    ("id-adagrad-d1001", 30, 24, 260, 1001, None, None, "adagrad", 0.0, True),
+    ("tags-both-adadelta-alpha-d600", 24, 30, 220, 600, "tagsnorm", "tags", "adadelta", 1e-4, False),
+    ("id-adagrad-d1024", 20, 16, 150, 1024, None, None, "adagrad", 0.0, False),
+]
+
+
+@pytest.mark.parametrize("loss", ["warp", "bpr", "logistic", "warp-kos"])
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_wide_models_serial_mode_bit_exact(fast, loss, case):
+    from lightfm_amd.options import options
+    options.set(mode="serial", log_samples=True)
+    coo, item_f, user_f, st, rng, alpha = _problem(case)
+    a, b = st.copy(), st.copy()
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _run_hip(fast, loss, coo, item_f, user_f, a, shuffle, seeds, alpha)
+        assert options.last_kernel_used == 0
+        if loss == "logistic":
+            _run_orc(loss, coo, item_f, user_f, b, shuffle, seeds, alpha)
+        else:
+            o = _orc_logged(loss, coo, item_f, user_f, b, shuffle, seeds, alpha, rng_mode=0)
+            neg, sampled = options.last_logs
+            assert np.array_equal(sampled, o.sampled) and np.array_equal(neg, o.neg)
+            assert options.last_counters == o.counters
+    assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    if loss in ("warp", "warp-kos"):
+        H.assert_states_equal(a, b, exact=True)
+    else:
+        H.assert_states_equal(a, b, exact=False, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("loss", ["warp", "bpr", "warp-kos"])
+def test_wide_models_parallel_mode(fast, loss):
+    """d = 1 001 in the shipped mode: one interaction per launch is the sequential run (negatives and counters exact, arrays
+    within the bar of float-atomic publication); then predict / predict_ranks on the trained model equal the oracle's."""
+    from lightfm_amd.options import options
+    coo, item_f, user_f, st, rng, alpha = _problem(WIDE_CASES[0])
+    options.set(mode="parallel", log_samples=True, launches_per_epoch=coo.nnz)
+    a, b = st.copy(), st.copy()
+    shuffle, seeds = H.epoch_inputs(coo, rng)
+    _run_hip(fast, loss, coo, item_f, user_f, a, shuffle, seeds, alpha)
+    o = _orc_logged(loss, coo, item_f, user_f, b, shuffle, seeds, alpha, rng_mode=1)
+    neg, sampled = options.last_logs
+    assert np.array_equal(sampled, o.sampled) and np.array_equal(neg, o.neg) and options.last_counters == o.counters
+    H.assert_states_equal(a, b, exact=False, rtol=2e-5, atol=2e-6)
+    nu, ni = coo.shape
+    uids = np.repeat(np.arange(nu, dtype=np.int32), ni)
+    iids = np.tile(np.arange(ni, dtype=np.int32), nu)
+    want = oracle.predict(item_f, user_f, uids, iids, b)
+    got = np.empty_like(want)
+    Cm = fast.CSRMatrix
+    fast.predict_lightfm(Cm(item_f), Cm(user_f), uids, iids, got, _hip_struct(fast, b), 1)
+    assert np.array_equal(want, got)
+    train = H.positives_csr(coo).astype(np.float32)
+    test = H.make_interactions(nu, ni, 150, seed=99).tocsr().astype(np.float32)
+    test = (test - test.multiply(train.astype(bool))).tocsr().astype(np.float32)
+    test.eliminate_zeros()
+    test.sort_indices()
+    r_orc, r_hip = np.zeros_like(test.data), np.zeros_like(test.data)
+    oracle.predict_ranks(item_f, user_f, test, train, r_orc, b)
+    fast.predict_ranks(Cm(item_f), Cm(user_f), Cm(test), Cm(train), r_hip, _hip_struct(fast, b), 1)
+    assert np.array_equal(r_orc, r_hip) and r_orc.max() > 0
+
+
 def test_in_positives_truth_table(fast):
     # reference tests/test_fast_functions.py:9-17
     mat = sp.csr_matrix(np.array([[0, 1], [1, 0]], dtype=np.float32))

@@ -109,9 +109,11 @@ def test_scoring_kernel_budgets(tmp_path):
         assert u["Occupancy"] >= 2 and u["VGPRs"] + u["AGPRs"] <= 256, (ks, u)
     assert _one(k, "ranks_mfma2_kernelILi64EEE")["Occupancy"] >= 1
     # the bucket-search sweep (the default): three wavefronts per SIMD for d <= 64 (12.3 KB of LDS each), two for d <= 128
-    for ks, occ in ((16, 3), (32, 3), (64, 2)):
-        u = _one(k, "ranks_mfma3_kernelILi%dEEE" % ks)
-        assert u["Occupancy"] >= occ and u["VGPRs"] + u["AGPRs"] <= 512 // occ and u["LDS"] <= 160 * 1024 // (4 * occ), (ks, u)
+    # (Lb1: the products on the bf16 matrix pipe, the default; Lb0: fp32 products)
+    for bf in (1, 0):
+        for ks, occ in ((16, 3), (32, 3), (64, 2)):
+            u = _one(k, "ranks_mfma3_kernelILi%dELb%dEEE" % (ks, bf))
+            assert u["Occupancy"] >= occ and u["VGPRs"] + u["AGPRs"] <= 512 // occ and u["LDS"] <= 160 * 1024 // (4 * occ), (ks, bf, u)
 
 
 @pytest.mark.timeout(1200)
@@ -158,7 +160,12 @@ def test_instruction_selection_of_the_hot_kernels(tmp_path):
     assert "scratch_" not in sweep and "v_pk_add_f32" in sweep
     # the bucket-search sweep: biases as a 33rd step, the item table through buffer loads with scalar row offsets (no
     # per-load address arithmetic), bucket counts by LDS atomics, every rank published by a hardware float atomic
-    search = [b for n, b in ranks.items() if "ranks_mfma3_kernelILi32EEE" in n][0]
+    search = [b for n, b in ranks.items() if "ranks_mfma3_kernelILi32ELb0EEE" in n][0]  # fp32 products
     assert search.count("v_mfma_f32_32x32x2_f32") == 33 and "scratch_" not in search
     assert search.count("buffer_load_dword") >= 2 * 35 and search.count("ds_add_u32") >= 16
     assert "global_atomic_add_f32" in search
+    # the default: the products on the bf16 matrix pipe -- (hi, lo) split operands, three products per 16 components (hi hi,
+    # hi lo, lo hi: 4 steps of k = 16 at d = 64), the biases one fp32 step
+    split = [b for n, b in ranks.items() if "ranks_mfma3_kernelILi32ELb1EEE" in n][0]
+    assert split.count("v_mfma_f32_32x32x16_bf16") == 12 and split.count("v_mfma_f32_32x32x2_f32") == 1 and "scratch_" not in split
+    assert split.count("ds_add_u32") >= 16 and "global_atomic_add_f32" in split
