@@ -339,9 +339,11 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
                                                                "true" if int(getattr(stats_last, "user_store", 0)) else "false",
                                                                1 if narrow else 4)  # <candidates, SHARDED, USTORE, VEC>
     if used == 1:
-        return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s>" % (
+        if flags & 1024:  # fit_bpr on the tile kernel's BPR instantiations (csrc/warp_tile_bpr.hip: four floats of a row per lane)
+            return "fit_warp_tile_kernel<%d, 4, false, false, %s, false, 2>" % (64 // ng, "true" if ng == 4 and not (options.debug & 64) else "false")
+        return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s, 1>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
-            "true" if reg else "false")
+            "true" if reg else "false")  # <lanes per row, floats per lane, TIMED, ADADELTA, DMA4, REG, loss id>
     if used == 2:
         hot = bool(int(getattr(stats_last, "plan_flags", 0)) & 32)  # the shared rows in LDS slices (csrc/hot_slices.hip)
         ada = bool(getattr(stats_last, "_adadelta", False))

@@ -160,7 +160,9 @@ typedef struct lfm_opts {
                                    wavefront pass; csrc/warp_tile_narrow.hpp); bit 7 = ... on rows that carry W, G, b and bG
                                    of a feature in ONE 128-byte line (d <= 12: an update is three line operations); bit 8 = the
                                    logistic lane-group kernel ran on such rows (csrc/logistic_tile.hip: identity features,
-                                   d <= 12 -- the reference's default LightFM()); bit 9 = its BPR counterpart ran       */
+                                   d <= 12 -- the reference's default LightFM()); bit 9 = its BPR counterpart ran; bit 10 = fit_bpr ran
+                                   on the BPR instantiations of the tile kernel (csrc/warp_tile_bpr.hip: identity features, 12 < d <= 256);
+                                   bit 11 = fit_logistic on its logistic instantiations                                    */
 } lfm_opts;
 
 #define LFM_LOSS_LOGISTIC 0

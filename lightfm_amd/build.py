@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "liblfm_hip.so")
 SOURCES = ["fit_kernels.hip", "fit_kernels_wide.hip", "warp_tile.hip", "warp_tile_lpr16.hip", "warp_tile_lpr32.hip",
-           "warp_tile_lpr64.hip", "warp_tile_ahead.hip", "logistic_tile.hip", "feat_kernels.hip", "feat_kernels_wide.hip", "feat_kernels_hot.hip", "feat_kernels_ada.hip", "hot_slices.hip", "predict_kernels.hip", "csr_build.hip", "session.hip"]
+           "warp_tile_lpr64.hip", "warp_tile_ahead.hip", "warp_tile_bpr.hip", "logistic_tile.hip", "feat_kernels.hip", "feat_kernels_wide.hip", "feat_kernels_hot.hip", "feat_kernels_ada.hip", "hot_slices.hip", "predict_kernels.hip", "csr_build.hip", "session.hip"]
 HEADERS = ["device.hpp", "kernels.hpp", "pool.hpp", "warp_tile_kernel.hpp", "warp_tile_ahead.hpp", "warp_tile_narrow.hpp", "feat_kernel.hpp", os.path.join("..", "..", "include", "lfm_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -59,6 +59,9 @@ struct RanksArgs {
 // grid_used (optional): the grid actually launched (after the residency clamp)
 hipError_t launch_fit(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st,
                       int cus = 0, int *grid_used = nullptr);
+// warp_tile_bpr.hip: the BPR / logistic instantiations of the lane-group tile kernel (identity features, adagrad, no L2 penalty; vec = 4)
+hipError_t launch_fit_bpr_wide_tile(const FitArgs &a, int ng, int vec, int grid, size_t smem, hipStream_t st, int cus,
+                                    int *grid_used, bool dma4, bool logistic);
 // fit_kernels_wide.hip: the same kernels for 512 < d <= LFM_MAX_COMPONENTS
 hipError_t launch_fit_wide(int loss, const FitArgs &a, int grid, int block, size_t smem, hipStream_t st, int cus, int *grid_used);
 // warp_tile.hip: lane-group tile kernel (identity features, alpha == 0, parallel mode)

@@ -2457,7 +2457,18 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     struct TilePlan { bool ok = false, dma4 = false, ahead = false, narrow = false; size_t smem = 0; int rows = 0, stride = 0, vec = 0, first_batch = 1; };
     TilePlan tile[5];  // indexed by NG (1, 2, 4)
     bool use_tile = false;
-    if (!serial && loss == LFM_LOSS_WARP && opts->warp_kernel != 1 && s->itf.identity &&
+    // fit_logistic / fit_bpr of a NARROW identity model (d <= 12: the reference's default LightFM() is logistic at 10): the lane-group
+    // kernels on one-line-per-feature rows (logistic_tile.hip) -- adagrad, no L2 penalty, atomic publication
+    const size_t ltile_smem = loss == LFM_LOSS_LOGISTIC ? logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0])
+                              : (loss == LFM_LOSS_BPR ? bpr_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]) : 0);
+    // fit_bpr / fit_logistic of a WIDER identity model: the BPR / logistic instantiations of the tile kernel (warp_tile_bpr.hip) --
+    // plain adagrad, no L2 penalty; BPR: two candidates per batch (LIGHTFM_AMD_BPR_WIDE_TILE=0: the row-stream kernel)
+    const bool bpr_wide_env = [] { const char *e = getenv("LIGHTFM_AMD_BPR_WIDE_TILE"); return !e || atoi(e) != 0; }();  // (per epoch call: the tests switch arms inside one process)
+    const bool lgt_tile = loss == LFM_LOSS_LOGISTIC;
+    const bool bpr_tile = (loss == LFM_LOSS_BPR || lgt_tile) && bpr_wide_env && s->d > 12 && s->d <= 256 && !s->adadelta && item_alpha == 0.0 &&
+                          user_alpha == 0.0 && opts->feat_kernel == 0 && s->shards.n == 0 && s->n > 0 &&
+                          (lgt_tile || (s->pos.indptr.p != nullptr && s->item_ids.p != nullptr));
+    if (!serial && (loss == LFM_LOSS_WARP || bpr_tile) && opts->warp_kernel != 1 && s->itf.identity &&
         s->usf.identity && s->itf.rows >= 2 && !(s->adadelta && (item_alpha != 0.0 || user_alpha != 0.0))) {
         const int forced = opts->debug & 7;  // experiment override: 1, 2 or 4
         for (int ng : {4, 2, 1}) {
@@ -2466,18 +2477,20 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // four interactions per pass: rows go memory -> LDS by LDS-DMA (debug bit 6: the
             // register-staged variant instead)
             t.dma4 = ng == 4 && !(opts->debug & 64);
-            t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec, t.dma4);
+            const int batch = bpr_tile ? (lgt_tile ? 1 : 2) : s->max_sampled;  // candidate rows of a group's tile
+            t.smem = warp_tile_geometry(s->d, batch, ng, &t.rows, &t.stride, &t.vec, t.dma4);
             if (t.smem == 0 && t.dma4) {
                 t.dma4 = false;
-                t.smem = warp_tile_geometry(s->d, s->max_sampled, ng, &t.rows, &t.stride, &t.vec, false);
+                t.smem = warp_tile_geometry(s->d, batch, ng, &t.rows, &t.stride, &t.vec, false);
             }
             if (t.smem == 0) continue;
+            if (bpr_tile && t.vec != 4) continue;  // (instantiated with four floats per lane: d <= 64 / 128 / 256 at 4 / 2 / 1 interactions per pass)
             t.ok = true;
-            t.first_batch = opts->first_batch > 0 ? opts->first_batch : s->max_sampled;
+            t.first_batch = opts->first_batch > 0 ? opts->first_batch : batch;
             t.first_batch = std::max(1, std::min(t.first_batch, t.rows - 1));
             // the steady-state variant with the next pass's gather issued inside the current pass (warp_tile_ahead.hpp):
             // adagrad, no regularisation, max_sampled = 10 in one batch; debug bit 10 (1024) keeps the plain kernel
-            if (t.dma4 && !s->adadelta && item_alpha == 0.0 && user_alpha == 0.0 && opts->warp_kernel != 2 &&
+            if (!bpr_tile && t.dma4 && !s->adadelta && item_alpha == 0.0 && user_alpha == 0.0 && opts->warp_kernel != 2 &&
                 a.update_mode == 0 && !(opts->debug & (1024 | 512))) {  // (atomic publication only: no per-publication mode switch)
                 const size_t ahead = warp_tile_ahead_smem(s->d, s->max_sampled, t.first_batch);
                 if (ahead) {
@@ -2513,11 +2526,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                       "features, adagrad, no regularisation, d <= 64, max_sampled = 10)");
     // Every other parallel-mode adagrad model (with or without L2 regularisation): the pipelined row-stream kernels
     // (feat_kernel.hpp) -- feature CSRs, BPR, k-OS, logistic (BASELINE configs C3 / C5).
-    // fit_logistic of a NARROW identity model (the reference's default LightFM(): logistic, no_components = 10): the
-    // lane-group kernel on one-line-per-feature rows (logistic_tile.hip) -- adagrad, no L2 penalty, atomic publication
-    // ... and fit_bpr of the same models (three lines per interaction, candidates drawn from the interaction list)
-    const size_t ltile_smem = loss == LFM_LOSS_LOGISTIC ? logistic_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0])
-                              : (loss == LFM_LOSS_BPR ? bpr_tile_smem(s->d, (int64_t)s->n_feat[1], (int64_t)s->n_feat[0]) : 0);
+    // (the narrow lane-group kernels, logistic_tile.hip: ltile_smem above)
     const bool use_ltile = !serial && !use_tile && s->itf.identity && s->usf.identity && !s->adadelta &&
                            item_alpha == 0.0 && user_alpha == 0.0 && a.update_mode == 0 && opts->feat_kernel == 0 && s->shards.n == 0 &&
                            s->n > 0 && ltile_smem != 0 && (loss == LFM_LOSS_LOGISTIC || (s->pos.indptr.p != nullptr && s->item_ids.p != nullptr));
@@ -2848,6 +2857,10 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                     plan_flags |= 64;
                 }
                 else if (tile[ng].ahead) HIP_TRY(launch_fit_warp_tile_ahead(a, grid, lst, s->cus, &grid_used));
+                else if (bpr_tile) {
+                    HIP_TRY(launch_fit_bpr_wide_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, &grid_used, tile[ng].dma4, lgt_tile));
+                    plan_flags |= lgt_tile ? 2048 : 1024;
+                }
                 else HIP_TRY(launch_fit_warp_tile(a, ng, tile[ng].vec, grid, lsmem, lst, s->cus, opts->warp_kernel == 2,
                                                   &grid_used, tile[ng].dma4));
             }

@@ -203,10 +203,25 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 // and update phases, multiplies every updated cell by 1 + alpha * lr (cell_math), sums the cells' learning
 // rates and adds log1p(alpha * avg_lr) of its interactions to the global log-scales with one float64 atomic
 // per side and pass.
-template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false, bool REG = false>
+//
+// LOSS (round 6): LFM_LOSS_WARP_ID, or LFM_LOSS_BPR_ID -- fit_bpr (PYX:1074-1182) of an identity model on the same tile: the
+// candidates of a batch are item_ids[rand_r % no_examples] (PYX:1124-1125: negatives are drawn from the interaction list), the
+// negative is the FIRST candidate that is not one of the user's positives whatever it scores (PYX:1126-1127; the same
+// speculation: the first candidate almost always is), at most no_examples draws and the last one taken when the loop ends on
+// its bound; loss = weight (1 - sigmoid(pp - np)) (PYX:1158); the update is the same warp_update (PYX:537-649).  Two
+// candidates per batch (session.hip), adagrad, no L2 penalty.
+// LFM_LOSS_LOGISTIC_ID: fit_logistic (PYX:694-781) likewise -- every record is visited (y <= 0 is the label 0, PYX:751-755), no
+// candidates: the tile holds the user's and the item's row, lane 0 of a group scores the pair, loss = weight (sigmoid(score) - y)
+// (PYX:745-757), and `update` (PYX:454-535) is warp_update without the negative: the item's row moves along the user's and the
+// user's along the item's, both bias cells by the loss.
+template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false, bool REG = false, int LOSS = LFM_LOSS_WARP_ID>
 __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fit_warp_tile_kernel(FitArgs a)
 {
     static_assert(!DMA4 || (LPR == 16 && VEC == 4), "the LDS-DMA tile layout is the four-group one");
+    static_assert(LOSS == LFM_LOSS_WARP_ID || ((LOSS == LFM_LOSS_BPR_ID || LOSS == LFM_LOSS_LOGISTIC_ID) && !ADADELTA && !REG && !TIMED),
+                  "BPR / logistic: plain adagrad only");
+    static_assert(LOSS != LFM_LOSS_LOGISTIC_ID || VEC == 4, "logistic: the staged / LDS-DMA layouts with four floats per lane");
+    constexpr bool BPR = LOSS == LFM_LOSS_BPR_ID, LGT = LOSS == LFM_LOSS_LOGISTIC_ID;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMED) {
@@ -241,7 +256,9 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     const bool pc = VEC * p < d;  // this lane carries a piece (VEC floats) of every gathered row
     const float *Wi = a.m.W[0], *Wu = a.m.W[1];
     const float *bi_tab = a.b_read[0], *bu_tab = a.b_read[1];
-    const int max_sampled = a.m.max_sampled;
+    // (BPR: the draw loop is bounded by the number of interactions, PYX:1123)
+    const int max_sampled = LGT ? 0 : (BPR ? (int)std::min<int64_t>(a.n, 0x7fffffff) : a.m.max_sampled);
+    const uint32_t n_examples = (uint32_t)a.n;
     const uint32_t n_items = (uint32_t)a.itf.rows, magic = a.n_items_magic;
     const uint32_t base_seed = a.seeds[0];
     const Hyper h{ADADELTA ? 1 : 0, a.m.lr, a.m.rho, a.m.eps};
@@ -281,8 +298,10 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     int c_lo = 0, c_hi = 0, row2 = 0;
     if (ib + g < a.end) {
         cur = a.recs[guard_row(a, a.shuffle[ib + g])];
-        c_lo = indptr[cur.x];
-        c_hi = indptr[cur.x + 1];
+        if constexpr (!LGT) {  // (logistic has no positives lookup)
+            c_lo = indptr[cur.x];
+            c_hi = indptr[cur.x + 1];
+        }
     }
     if (ib + stride + g < a.end) nxt = a.recs[guard_row(a, a.shuffle[ib + stride + g])];
     if (ib + 2 * stride + g < a.end) row2 = a.shuffle[ib + 2 * stride + g];
@@ -292,9 +311,11 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         const bool in = i < a.end;
         int n_lo = 0, n_hi = 0, row3 = 0;
         int4 rec2 = make_int4(0, 0, 0, 0);
-        if (i + stride < a.end) {
-            n_lo = indptr[nxt.x];
-            n_hi = indptr[nxt.x + 1];
+        if constexpr (!LGT) {
+            if (i + stride < a.end) {
+                n_lo = indptr[nxt.x];
+                n_hi = indptr[nxt.x + 1];
+            }
         }
         if (i + 2 * stride < a.end) rec2 = a.recs[guard_row(a, row2)];
         if (i + 3 * stride < a.end) row3 = a.shuffle[i + 3 * stride];
@@ -302,9 +323,10 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         // addresses are scalar arithmetic (global_load with an SGPR base)
         const int c_user = LPR == 64 ? uni(cur.x) : cur.x, c_pos = LPR == 64 ? uni(cur.y) : cur.y;
         const float c_y = __int_as_float(cur.z), c_w = __int_as_float(cur.w);
-        bool act = in && (c_y > 0.0f);  // PYX:831-832, before any RNG use
+        bool act = in && (LGT || c_y > 0.0f);  // PYX:831-832, before any RNG use (logistic: every record, PYX:751-755)
         if constexpr (LPR == 64) act = __ballot(act) != 0ull;
         int sampled = 0, chosen = -1, chosen_r = 0;
+        float chosen_score = 0.0f;          // BPR: the negative's prediction
         stamp(0);
 
         if (__ballot(act) != 0ull) {
@@ -388,6 +410,25 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
             };
             double pp = 0.0;
             int done = 0;  // draws consumed by every group that is still looking (wave-uniform)
+            if constexpr (LGT) {
+                // the pair's prediction (PYX:320-334) by lane 0 of the group; the accumulator rows of its update requested at once
+                float bi = 0.0f;
+                if (act && p == 0) bi = bi_tab[c_pos];
+                if constexpr (DMA4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two DMA'd rows have landed
+                wave_sync();
+                float score = 0.0f;
+                if (act && p == 0) score = row_dot<false>(urow, vrows, d, bu, bi, 1.0f, 1.0f);
+                pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
+                if (act) chosen = c_pos;  // (the "negative" of the shared update code: never read)
+                spec_cand = c_pos;
+                specm = __ballot(act && p == 0);
+#pragma unroll
+                for (int gg = 0; gg < NG; ++gg) {
+                    if ((specm >> (gg * LPR)) & 1ull)
+                        load_rows(gg, __builtin_amdgcn_readlane(c_user, gg * LPR), __builtin_amdgcn_readlane(c_pos, gg * LPR),
+                                  __builtin_amdgcn_readlane(c_pos, gg * LPR), false);
+                }
+            }
             while (done < max_sampled) {
                 bool need = act && chosen < 0;
                 if constexpr (LPR == 64) need = __ballot(need) != 0ull;
@@ -400,7 +441,9 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     for (int j = 0; j < nb; ++j)
                         if (j < p) s = lcg(s);
                 }
-                const int myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);  // PYX:860-861
+                int myitem;
+                if constexpr (BPR) myitem = (p == 0 || !need) ? c_pos : a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
+                else myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);                        // PYX:860-861
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
                 if (rowlane) bi = bi_tab[myitem];
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     // one instruction per candidate: the k-th row of every group that is still looking
                     // (a finished group's lanes stay masked, its chosen row survives)
 #pragma unroll
-                    for (int k = 1; k < LPR; ++k) {
+                    for (int k = 1; k < (BPR ? 3 : LPR); ++k) {  // (BPR: batches of two candidates)
                         if (k <= nb) {  // wave-uniform
                             const int neg = row_bcast(myitem, k);
                             if (gln) dma_lane_x4(Wi + (size_t)neg * d + VEC * p, tile + (size_t)k * KS);
@@ -499,7 +542,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 // sampling control flow below in SGPRs and scalar branches)
                 if (done == 0) pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
                 // PYX:875 compares doubles: negative_prediction > positive_prediction - 1
-                const bool viol = need && p >= 1 && p <= nb && ((double)score > pp - 1.0);
+                // (BPR: every candidate is examined in draw order, PYX:1126-1127)
+                const bool viol = need && p >= 1 && p <= nb && (BPR || (double)score > pp - 1.0);
                 unsigned long long vm = (__ballot(viol) >> gbase) & GM;
                 if (bloom && !bloom_early && viol) bword = bloom[Bloom::word(bh, c_lo, c_hi)];  // probed for the violators only
                 int used = nb;
@@ -528,6 +572,8 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                     const int r = part ? (__ffsll((long long)vm) - 1) : 0;
                     if (part) vm &= vm - 1ull;
                     const int cand = LPR == 64 ? read_lane(myitem, r) : __shfl(myitem, gbase + r, WAVE);
+                    float cand_score = 0.0f;
+                    if constexpr (BPR) cand_score = LPR == 64 ? read_lanef(score, r) : __shfl(score, gbase + r, WAVE);
                     // the exact search (PYX:270-284) only where the filter cannot rule the candidate out
                     const bool ask = part && (LPR == 64 ? read_lane(maybe_pos, r) : __shfl(maybe_pos, gbase + r, WAVE)) != 0;
                     bool found = false;
@@ -539,11 +585,23 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         if (!found) {
                             chosen = cand;
                             chosen_r = r;
+                            chosen_score = cand_score;
                             used = r;
                         }
                     }
                 }
                 const uint32_t ns = (uint32_t)(LPR == 64 ? read_lane((int)s, used) : __shfl((int)s, gbase + used, WAVE));
+                if constexpr (BPR) {
+                    if (done + nb >= max_sampled) {  // PYX:1123-1127: the loop ends on its bound -- the last draw is the negative
+                        const int lc = LPR == 64 ? read_lane(myitem, nb) : __shfl(myitem, gbase + nb, WAVE);
+                        const float ls = LPR == 64 ? read_lanef(score, nb) : __shfl(score, gbase + nb, WAVE);
+                        if (need && chosen < 0) {
+                            chosen = lc;
+                            chosen_r = nb;
+                            chosen_score = ls;
+                        }
+                    }
+                }
                 if (need) {
                     sampled += used;
                     state = ns;
@@ -552,7 +610,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 done += nb;
                 stamp(3);  // in_positives searches
             }
-            c0 += (uint32_t)__popcll(__ballot(act && p == 0));
+            c0 += (uint32_t)__popcll(__ballot(act && p == 0 && (!LGT || c_y > 0.0f)));
             c2 += (uint32_t)__popcll(__ballot(act && chosen >= 0 && p == 0));
 #pragma unroll
             for (int gg = 0; gg < NG; ++gg)  // inactive groups hold sampled == 0
@@ -566,8 +624,14 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                          "+v"(rec2.w));
             double lossd = 0.0;
             if (act && chosen >= 0) {
-                lossd = (double)c_w * a.logtab[sampled];  // PYX:881-885, log from host libm
-                if (lossd > MAX_LOSS) lossd = MAX_LOSS;
+                if constexpr (BPR) {
+                    lossd = (double)c_w * (1.0 - (double)sigmoidf_ref((float)(pp - (double)chosen_score)));  // PYX:1158
+                } else if constexpr (LGT) {
+                    lossd = (double)c_w * ((double)sigmoidf_ref((float)pp) - (c_y <= 0.0f ? 0.0 : 1.0));    // PYX:745-757
+                } else {
+                    lossd = (double)c_w * a.logtab[sampled];  // PYX:881-885, log from host libm
+                    if (lossd > MAX_LOSS) lossd = MAX_LOSS;
+                }
             }
             const unsigned long long upd = __ballot(act && chosen >= 0 && p == 0);
             if (upd != 0ull) {
@@ -634,15 +698,26 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                             oWr[q][0] = Pr;
                             oWr[q][1] = Nr;
                             oWr[q][2] = Ur;
-                            cell_math(Pr, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, -loss * u, h, ia,
+                            cell_math(Pr, gP[gg][q], ADADELTA ? mP[gg][q] : 0.0f, 1.0, (LGT ? loss : -loss) * u, h, ia,
                                       nWr[q][0], nGr[q][0], nMr[q][0], lr);
                             if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);  // one cell's float64 chain at a time: registers
-                            cell_math(Nr, gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, ia,
-                                      nWr[q][1], nGr[q][1], nMr[q][1], lr);
+                            if constexpr (BPR) {
+                                // the negative IS the positive (a user with the whole catalogue: the draw loop ended on its bound):
+                                // the reference updates that row twice in sequence -- the second pass starts from what the first leaves
+                                if (neg == pos) {
+                                    oWr[q][1] = nWr[q][0];
+                                    gN[gg][q] = nGr[q][0];
+                                }
+                            }
+                            if constexpr (!LGT)
+                                cell_math(oWr[q][1], gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, ia,
+                                          nWr[q][1], nGr[q][1], nMr[q][1], lr);
+                            else nWr[q][1] = nGr[q][1] = nMr[q][1] = 0.0f;
                             if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
-                            cell_math(Ur, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * df, h, ua,
+                            // (logistic: the user's row moves along the item's, PYX:519-533)
+                            cell_math(Ur, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * (LGT ? (double)Pc : df), h, ua,
                                       nWr[q][2], nGr[q][2], nMr[q][2], lr);
                             if (REG && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
@@ -650,7 +725,17 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         float bnW, bnG, bnM;
                         const float ooM = ADADELTA ? obM[gg] : 0.0f;
                         const double balpha = lane == 2 ? ua : ia;
-                        cell_math(obW[gg], obG[gg], ooM, 1.0, lane == 0 ? -loss : loss, h, balpha, bnW, bnG, bnM, lr);
+                        cell_math(obW[gg], obG[gg], ooM, 1.0, (lane == 0 && !LGT) ? -loss : loss, h, balpha, bnW, bnG, bnM, lr);
+                        if constexpr (BPR) {
+                            if (neg == pos) {  // (the bias cell of that row likewise: lane 1 continues from lane 0's result)
+                                const float w0 = read_lanef(bnW, 0), g0 = read_lanef(bnG, 0);
+                                if (lane == 1) {
+                                    obW[gg] = w0;
+                                    obG[gg] = g0;
+                                    cell_math(w0, g0, ooM, 1.0, loss, h, balpha, bnW, bnG, bnM, lr);
+                                }
+                            }
+                        }
                         if constexpr (REG) {
                             // avg_learning_rate of PYX:640-646: the 3 (d + 1) cells of three identity rows
                             if (lane < 3) lr_acc += lr;
@@ -687,20 +772,22 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                 } else {
                                     publish(wP + cq, nWr[q][0], oWr[q][0], um);
                                     publish(aP + cq, nGr[q][0], gP[gg][q], um);
-                                    publish(wN + cq, nWr[q][1], oWr[q][1], um);
-                                    publish(aN + cq, nGr[q][1], gN[gg][q], um);
+                                    if constexpr (!LGT) {
+                                        publish(wN + cq, nWr[q][1], oWr[q][1], um);
+                                        publish(aN + cq, nGr[q][1], gN[gg][q], um);
+                                    }
                                     publish(wU + cq, nWr[q][2], oWr[q][2], umU);  // (FitArgs::user_store: plain stores)
                                     publish(aU + cq, nGr[q][2], gU[gg][q], umU);
                                 }
                             }
                         }
-                        if (lane < 3) {
+                        if (lane < 3 && !(LGT && lane == 1)) {
                             const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
                             float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
                             float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];
                             float *bMp = lane == 2 ? a.m.bM[1] : a.m.bM[0];
                             publish_cell(bWp + brow, bGp + brow, bMp + brow, obW[gg], obG[gg], ooM, bnW, bnG, bnM, 1.0,
-                                         lane == 0 ? -loss : loss, h, balpha, um);
+                                         (lane == 0 && !LGT) ? -loss : loss, h, balpha, um);
                         }
                     }
                 }
@@ -764,6 +851,22 @@ hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStrea
     else if (reg) kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, true>;
     else if (timed) kernel = fit_warp_tile_kernel<LPR, VEC, true, false, DMA4>;
     else kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4>;
+    if (cus > 0) {
+        const int per_cu = occupancy_cached(kernel, 256, smem);
+        if (per_cu > 0) grid = std::min(grid, per_cu * cus);
+    }
+    if (grid_used) *grid_used = grid;
+    kernel<<<grid, 256, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+// ... and of the BPR / logistic instantiations (warp_tile_bpr.hip)
+template <int LPR, int VEC, bool DMA4 = false>
+hipError_t launch_tile_bpr_variant(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus, int *grid_used, bool logistic)
+{
+    void (*kernel)(FitArgs) = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_BPR_ID>;
+    if (logistic) kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_LOGISTIC_ID>;
+    if (a.m.adadelta || a.item_alpha != 0.0 || a.user_alpha != 0.0) return hipErrorInvalidValue;
     if (cus > 0) {
         const int per_cu = occupancy_cached(kernel, 256, smem);
         if (per_cu > 0) grid = std::min(grid, per_cu * cus);

@@ -121,12 +121,14 @@ def test_outside_its_scope_the_row_stream_kernel_runs(fast, monkeypatch):
     rng = np.random.RandomState(2)
     coo, weight = _labels(H.make_interactions(60, 50, 500, seed=9), rng)
     shuffle, _ = H.epoch_inputs(coo, rng)
-    for d, alpha, env in ((16, 0.0, None), (10, 1e-6, None), (10, 0.0, "0")):
+    # (d = 16: the tile kernel's logistic instantiation, csrc/warp_tile_bpr.hip -- plan_flags bit 11; tests/test_hip_bpr_tile.py)
+    for d, alpha, env, used in ((16, 0.0, None, 1), (10, 1e-6, None, 2), (10, 0.0, "0", 2)):
         if env is not None:
             monkeypatch.setenv("LIGHTFM_AMD_LOGISTIC_TILE", env)
         st = _state(50, 60, d, 1)
         _hip(fast, coo, st, shuffle, weight, item_alpha=alpha)
-        assert options.last_kernel_used == 2 and not (options.last_plan_flags & 256), (d, alpha, env, options.last_plan_flags)
+        assert options.last_kernel_used == used and not (options.last_plan_flags & 256), (d, alpha, env, options.last_plan_flags)
+        assert bool(options.last_plan_flags & 2048) == (d == 16)
 
 
 def test_training_learns_like_the_row_stream_kernel(monkeypatch):
