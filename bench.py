@@ -43,7 +43,8 @@ traffic), `cpu_baseline` (the reference's own compiled Cython/OpenMP path on thi
 inside `config`: `quality` (precision@10 of this backend and of the reference on the same data), `end_to_end_fit`
 (LightFM.fit through the public API, uploads and downloads included) and `legs` -- short measurements of the
 other BASELINE shapes (c3, c4shard, c5shard at its full per-GPU size), of the reference's DEFAULT width
-(`c2_d10`: no_components = 10, rows padded to 12 floats on the device) and of `predict_ranks` (all users x all items
+(`c2_d10`: no_components = 10, rows padded to 12 floats on the device; `default_model`: LightFM()'s literal defaults, logistic
+at no_components = 10, on +-1 labels; `c2_bpr`: BPR at c2's width) and of `predict_ranks` (all users x all items
 of the ML-20M shape on the matrix cores), each with its own value, roofline and cpu baseline (--no-extra skips them).
 
 Prints ONE JSON line (rank 0).
@@ -76,6 +77,13 @@ CONFIGS = {
     "c3": dict(loss="bpr", d=128, shape="ml-20m", features="tags", default_scaling="strong",
                label="MovieLens-20M shape (138493 users x 26744 items x %d interactions), loss=bpr, "
                      "no_components=128, item features [identity | 8 tags of 1128] (9 nnz/row), adagrad"),
+    # the reference's literal default model, LightFM(): logistic loss, no_components = 10 (LFM:191), on +-1 labels; and BPR at c2's width
+    "default_model": dict(loss="logistic", d=10, shape="ml-20m", features=None, default_scaling="strong", labels="signed",
+                          label="MovieLens-20M shape (138493 users x 26744 items x %d interactions, +-1 labels), loss=logistic, "
+                                "no_components=10 (LightFM()'s defaults), identity features, adagrad"),
+    "c2_bpr": dict(loss="bpr", d=64, shape="ml-20m", features=None, default_scaling="strong",
+                   label="MovieLens-20M shape (138493 users x 26744 items x %d interactions), loss=bpr, no_components=64, "
+                         "identity features, adagrad"),
     "c4shard": dict(loss="warp", d=64, shape=(1_250_000, 5_000_000, 62_500_000), features=None,
                     default_scaling="weak",
                     label="one GPU's row shard of 10M users x 5M items x 500M interactions: 1.25M users x 5M "
@@ -280,7 +288,7 @@ def parse_args():
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="default: c2, followed at N = 1 by short legs of c3 / c4shard / c5shard (extra_configs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs of the default run")
-    ap.add_argument("--extra", default="ranks,c2_d10,c3,c4shard,c5shard", help="which extra legs (comma separated)")
+    ap.add_argument("--extra", default="ranks,c2_d10,default_model,c2_bpr,c3,c4shard,c5shard", help="which extra legs (comma separated)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the interactions (debug)")
     ap.add_argument("--emulate-shard", type=int, default=0,
@@ -329,6 +337,8 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
     ng, used = int(stats_last.tile_ng), int(stats_last.kernel_used)
     dp = (d + 3) // 4 * 4
     flags = int(getattr(stats_last, "plan_flags", 0))
+    if used == 1 and flags & (256 | 512):  # the narrow lane-group kernels (csrc/logistic_tile.hip)
+        return "fit_logistic_tile_kernel" if flags & 256 else "fit_bpr_tile_kernel<1>"
     if used == 1 and flags & 64:  # the narrow-model kernel: <candidates, USTORE, W and G of a row in one line, ... with the bias cells>
         rp = os.environ.get("LIGHTFM_AMD_ROW_PAIRS", "2") not in ("", "0")
         return "fit_warp_tile_narrow_kernel<10, %s, %s, %s>" % ("true" if int(getattr(stats_last, "user_store", 0)) else "false",
@@ -339,8 +349,9 @@ def kernel_label(loss, d, stats_last, reg, options, sharded=False):
                                                                "true" if int(getattr(stats_last, "user_store", 0)) else "false",
                                                                1 if narrow else 4)  # <candidates, SHARDED, USTORE, VEC>
     if used == 1:
-        if flags & 1024:  # fit_bpr on the tile kernel's BPR instantiations (csrc/warp_tile_bpr.hip: four floats of a row per lane)
-            return "fit_warp_tile_kernel<%d, 4, false, false, %s, false, 2>" % (64 // ng, "true" if ng == 4 and not (options.debug & 64) else "false")
+        if flags & (1024 | 2048):  # fit_bpr / fit_logistic on the tile kernel's instantiations (csrc/warp_tile_bpr.hip: four floats of a row per lane)
+            return "fit_warp_tile_kernel<%d, 4, false, false, %s, false, %d>" % (64 // ng, "true" if ng == 4 and not (options.debug & 64) else "false",
+                                                                                 2 if flags & 1024 else 0)
         return "fit_warp_tile_kernel<%d, %d, false, false, %s, %s, 1>" % (
             64 // ng, {4: 4, 2: 2, 1: 1}[ng], "true" if ng == 4 and not (options.debug & 64) else "false",
             "true" if reg else "false")  # <lanes per row, floats per lane, TIMED, ADADELTA, DMA4, REG, loss id>
@@ -403,6 +414,9 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
         from lightfm_amd.distributed import local_shard
         train, _ = local_shard(train, 0, args.emulate_shard, rebase=True)
         n_users, global_n, test = train.shape[0], train.nnz, None
+    if cfg.get("labels") == "signed":  # logistic trains on both labels (PYX:751-755: y <= 0 is the label 0)
+        sign = np.where(np.random.RandomState(3).rand(train.nnz) < 0.5, 1.0, -1.0).astype(np.float32)
+        train = sp.coo_matrix((sign, (train.row, train.col)), shape=train.shape, dtype=np.float32)
     log("%s: %d interactions (%d x %d) ready in %.1fs" % (name, train.nnz, n_users, n_items, time.time() - t0))
     loss, d = cfg["loss"], (d_override or cfg["d"])
     n_local = train.nnz
@@ -467,7 +481,8 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
         barrier()
         elapsed = all_max(time.perf_counter() - t_start)
         timed = stats[n_warm:]
-        total_pos = all_sum(float(sum(st.counters[0] for st in timed)))
+        # (logistic visits every record; its first counter counts the label-1 records only)
+        total_pos = all_sum(float(n_local * len(timed)) if loss == "logistic" else float(sum(st.counters[0] for st in timed)))
         run = dict(elapsed=elapsed, stats=timed, total_pos=total_pos, value=total_pos / elapsed,
                    merges=fit.merges - merges0, merge_bytes=fit.merge_bytes - mbytes0)
         if world == 1 and len(walls) >= 11:  # epochs 2..11 of this fresh fit (wall time per epoch, every epoch ends synchronised)
@@ -502,6 +517,7 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     counters = [sum(st.counters[i] for st in stats) for i in range(4)]
     n_epochs = steps * eps
     alg = algorithmic_total(loss, counters, d, feats, rows, n_users, float(n_local) * n_epochs)
+    visited = float(n_local) * n_epochs if loss == "logistic" else max(1.0, counters[0])  # (logistic: its first counter = the label-1 records)
     f_i = float(feats.nnz) / feats.shape[0] if feats is not None else 1.0
     launches = sum(int(st.launches) for st in stats)
     reg = bool(args.item_alpha or args.user_alpha)
@@ -512,12 +528,12 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": alg / launches,
-                "algorithmic_bytes_per_interaction": alg / max(1.0, counters[0]),
+                "algorithmic_bytes_per_interaction": alg / visited,
                 "avg_launch_ms": kernel_s * 1e3 / launches, "launches_per_epoch": launches / n_epochs,
                 "kernel_time_fraction_of_step": kernel_s / elapsed,
                 "interactions_in_flight": int(stats[-1].in_flight),
-                "draws_per_interaction": counters[1] / max(1.0, counters[0]),
-                "updates_per_interaction": counters[2] / max(1.0, counters[0])}
+                "draws_per_interaction": counters[1] / visited,
+                "updates_per_interaction": counters[2] / visited}
     if traffic is not None:
         roofline["traffic_over_algorithmic"] = traffic / (alg / launches)
         if "traffic_over_algorithmic_profiled" in traffic_extra:
@@ -545,7 +561,7 @@ def run_config(name, env, steps, warmup, epochs_per_step=1, fits=1, steady_secon
     roofline["user_rows_by_plain_stores"] = ustore
     roofline["atomic_unit"] = {"achieved": atomics / kernel_s / 1e9, "peak": ATOMIC_PEAK_GOPS, "unit": "G float atomics/s",
                                "frac": atomics / kernel_s / 1e9 / ATOMIC_PEAK_GOPS,
-                               "atomics_per_interaction": atomics / max(1.0, counters[0])}
+                               "atomics_per_interaction": atomics / visited}
     if options.feat_kernel == 2 and int(stats[-1].kernel_used) == 2:  # profiling build of the row-stream kernel
         ph = np.sum([list(st.phase_cycles) for st in stats], axis=0).astype(np.float64)
         roofline["phase_cycles_per_interaction"] = dict(zip(
@@ -761,6 +777,13 @@ def compact_leg(r, cpu=None):
     return out
 
 
+def mini_leg(r):
+    """... and in a few dozen: rate, roofline fraction, kernel."""
+    ro = r["roofline"]
+    return {"value": r["value"], "unit": r["unit"], "workload": r["config"]["workload"].split("), ", 1)[-1], "timed_epochs": r["config"]["timed_epochs"],
+            "roofline_frac": ro["frac"], "kernel": ro["kernel"], "atomic_unit_frac": ro["atomic_unit"]["frac"]}
+
+
 def main():
     args = parse_args()
     env = Env(args)
@@ -802,7 +825,8 @@ def main():
                 env.log("predict_ranks leg failed: %r" % (e,))
                 legs["predict_ranks"] = {"error": repr(e)}
         # the other BASELINE shapes and the reference's default width, short legs timed the same way
-        plans = {"c2_d10": dict(cfg="c2", steps=5, warmup=2, d=10), "c3": dict(cfg="c3", steps=5, warmup=2, steady=2.0),
+        plans = {"c2_d10": dict(cfg="c2", steps=5, warmup=2, d=10), "default_model": dict(cfg="default_model", steps=5, warmup=2, mini=True),
+                 "c2_bpr": dict(cfg="c2_bpr", steps=5, warmup=2, mini=True), "c3": dict(cfg="c3", steps=5, warmup=2, steady=2.0),
                  "c4shard": dict(cfg="c4shard", steps=5, warmup=2, steady=1.5), "c5shard": dict(cfg="c5shard", steps=2, warmup=1)}
         for extra in [e for e in wanted if e in plans and e != name]:
             try:
@@ -810,12 +834,12 @@ def main():
                 r, pc = run_config(pl["cfg"], env, pl["steps"], pl["warmup"], 1, fits=1, steady_seconds=pl.get("steady", 0.0),
                                    d_override=pl.get("d"), want_test=(CONFIGS[pl["cfg"]]["shape"] == "ml-20m"))
                 cpu = None
-                if not args.no_cpu_baseline and extra != "c2_d10":  # the reference on a bounded row sub-sample of THIS leg's workload
+                if not args.no_cpu_baseline and extra != "c2_d10" and not pl.get("mini"):  # the reference on a bounded row sub-sample of THIS leg's workload
                     try:
                         cpu = extra_cpu_leg(extra, env, pc)
                     except Exception as e:  # reporting only
                         env.log("cpu_baseline of %s failed: %r" % (extra, e))
-                legs[extra] = compact_leg(r, cpu)
+                legs[extra] = mini_leg(r) if pl.get("mini") else compact_leg(r, cpu)
             except BaseException as e:  # an extra leg never takes the contract line down
                 env.log("extra config %s failed: %r" % (extra, e))
                 legs[extra] = {"error": repr(e)}

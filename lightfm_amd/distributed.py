@@ -282,8 +282,11 @@ class DistributedFit(object):
             rank_user_f = sp.identity(b1 - b0, dtype=np.float32, format="csr")
         self.item_features, self.user_features = item_f, rank_user_f
         self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(rank_user_f), device=device)
+        # LFM:381-386: without a sample_weight matrix every interaction weighs 1 -- the VALUES are Y (logistic's labels; a
+        # positive wherever > 0), not weights
+        weights = shard.data if model._scan(shard.data)[0] else np.ones_like(shard.data)
         self.session.set_interactions(None, np.ascontiguousarray(shard.row),
-                                      np.ascontiguousarray(shard.col), shard.data, shard.data)
+                                      np.ascontiguousarray(shard.col), shard.data, weights)
         self.session.build_positives(b1 - b0, n_items)
         # what the merges cover: bit 0 = the item tables, bit 1 = user tables of shared user features
         self.sides = 1 | (2 if self.shared_users else 0)
