@@ -23,7 +23,7 @@ bool feat_plan(int loss, int d, int max_sampled, int n_positives, int first_batc
     case LFM_LOSS_BPR_ID: g.cand_base = 3; cb = 0; break;
     case LFM_LOSS_WARP_ID: g.cand_base = 2; break;
     case LFM_LOSS_WARP_KOS_ID:
-        if (n_positives < 1 || n_positives > 32) return false;
+        if (n_positives < 1 || n_positives > WAVE - 1) return false;  // (one job per lane: the user + n sampled positives)
         // row 0 = the user, rows 1 .. n = the sampled positives; once the k-th is chosen (and kept in registers) the
         // candidates take the same rows: 1 + max(n, batch) tile rows instead of 1 + n + batch
         g.cand_base = 1;

@@ -15,6 +15,7 @@ Bars:
 """
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from oracle import oracle
 from tests import helpers as H
@@ -196,6 +197,36 @@ def test_one_interaction_per_launch_matches_the_oracle(fast, case, loss, update_
         # the float adder of the L2 atomic unit does not round like v_add_f32: a cell updated ~100
         # times (the shared tag rows) drifts by tens of ulps
         H.assert_states_equal(a, b, exact=False, rtol=2e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("n,k,d,itf", [(40, 7, 16, "id"), (63, 63, 32, "tags"), (64, 5, 16, "id")],
+                         ids=["n40-k7-d16", "n63-k63-d32-tags", "n64-generic"])
+def test_kos_many_sampled_positives(fast, n, k, d, itf):
+    """fit_warp_kos with n up to 63 on the row-stream kernel (one job per lane: the user + n sampled positives; round 5 stopped
+    at 32); n = 64 runs the generic kernel.  One interaction per launch, plain stores: bit for bit the oracle."""
+    from lightfm_amd.options import options
+    nu, ni = 12, 150
+    rng = np.random.RandomState(n)
+    dense = rng.rand(nu, ni) < 0.6
+    dense[3, :] = False
+    dense[3, :5] = True  # (a user with fewer positives than n: no_pos = 5, PYX:975)
+    m = sp.coo_matrix(dense.astype(np.float32))
+    coo = sp.coo_matrix((np.ones(m.nnz, np.float32), (m.row.astype(np.int32), m.col.astype(np.int32))), shape=(nu, ni), dtype=np.float32)
+    item_f, user_f = _features(itf, ni, 5), _features("id", nu, 6)
+    st = oracle.State(item_f.shape[1], user_f.shape[1], d, rng, max_sampled=10)
+    _spread(st, item_f.nnz / ni, 1.0)
+    a, b = st.copy(), st.copy()
+    options.set(log_samples=True, launches_per_epoch=coo.nnz, update_mode=1, warp_kernel=1)
+    for _ in range(2):
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        _run_hip(fast, "warp-kos", coo, item_f, user_f, a, shuffle, seeds, coo.data, k=k, n=n)
+        o = _run_orc("warp-kos", coo, item_f, user_f, b, shuffle, seeds, coo.data, k=k, n=n)
+        neg, sampled = options.last_logs
+        assert np.array_equal(sampled, o.sampled) and np.array_equal(neg, o.neg)
+        assert options.last_counters == o.counters
+        assert options.last_kernel_used == (2 if n <= 63 else 0), options.last_kernel_used
+    assert not np.array_equal(a.item_embeddings, st.item_embeddings)
+    H.assert_states_equal(a, b, exact=True)
 
 
 @pytest.mark.parametrize("loss", ["bpr", "warp-kos", "logistic", "warp"])
