@@ -1049,6 +1049,15 @@ r6p)
   PROF_STEPS=3 PROF_WARMUP=1 bash tools/profile2.sh r06_c5shard --config c5shard --scale 0.25
   ls -la $R/gpurun_out/prof_r06_*/bench_fetch.json $R/gpurun_out/prof_r06_*/bench_trace.json 2>/dev/null | head
   ;;
+r6p2)
+  # the final tree's traces: C2 and the C4 shard with all counter passes (both run the steady-state kernel with bias pairs now), kernel traces
+  # of the narrow and identity-model kernels (c2 at d = 10, LightFM()'s default model, BPR at d = 64)
+  bash tools/profile2.sh r06_c2 --config c2
+  PROF_STEPS=8 PROF_WARMUP=3 bash tools/profile2.sh r06_c4shard --config c4shard
+  TRACE_ONLY=1 PROF_STEPS=8 PROF_WARMUP=3 bash tools/profile2.sh r06_c2_d10 --config c2 --no-components 10
+  TRACE_ONLY=1 PROF_STEPS=8 PROF_WARMUP=3 bash tools/profile2.sh r06_default_model --config default_model
+  TRACE_ONLY=1 PROF_STEPS=8 PROF_WARMUP=3 bash tools/profile2.sh r06_c2_bpr --config c2_bpr
+  ;;
 r6q)
   # multi-GPU semantics with the hot set in every emulated rank: C3, K = 1 against K = 8 (sparse merges + hot rows at their cadence), 3 seeds;
   # C2's per-rank kernel time at N = 8 (rank 0's shard of the strong-scaling split on this one GPU)
