@@ -209,7 +209,7 @@ __device__ __forceinline__ bool group_in_positives(const int32_t *indices, int i
 // negative is the FIRST candidate that is not one of the user's positives whatever it scores (PYX:1126-1127; the same
 // speculation: the first candidate almost always is), at most no_examples draws and the last one taken when the loop ends on
 // its bound; loss = weight (1 - sigmoid(pp - np)) (PYX:1158); the update is the same warp_update (PYX:537-649).  Two
-// candidates per batch (session.hip), adagrad, no L2 penalty.
+// candidates per batch (session.hip), adagrad, with or without the lazy L2 regularisation (REG).
 // LFM_LOSS_LOGISTIC_ID: fit_logistic (PYX:694-781) likewise -- every record is visited (y <= 0 is the label 0, PYX:751-755), no
 // candidates: the tile holds the user's and the item's row, lane 0 of a group scores the pair, loss = weight (sigmoid(score) - y)
 // (PYX:745-757), and `update` (PYX:454-535) is warp_update without the negative: the item's row moves along the user's and the
@@ -218,8 +218,8 @@ template <int LPR, int VEC, bool TIMED, bool ADADELTA, bool DMA4 = false, bool R
 __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fit_warp_tile_kernel(FitArgs a)
 {
     static_assert(!DMA4 || (LPR == 16 && VEC == 4), "the LDS-DMA tile layout is the four-group one");
-    static_assert(LOSS == LFM_LOSS_WARP_ID || ((LOSS == LFM_LOSS_BPR_ID || LOSS == LFM_LOSS_LOGISTIC_ID) && !ADADELTA && !REG && !TIMED),
-                  "BPR / logistic: plain adagrad only");
+    static_assert(LOSS == LFM_LOSS_WARP_ID || ((LOSS == LFM_LOSS_BPR_ID || LOSS == LFM_LOSS_LOGISTIC_ID) && !ADADELTA && !TIMED),
+                  "BPR / logistic: adagrad, with or without the lazy L2 regularisation");
     static_assert(LOSS != LFM_LOSS_LOGISTIC_ID || VEC == 4, "logistic: the staged / LDS-DMA layouts with four floats per lane");
     constexpr bool BPR = LOSS == LFM_LOSS_BPR_ID, LGT = LOSS == LFM_LOSS_LOGISTIC_ID;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 if (act && p == 0) bi = bi_tab[c_pos];
                 if constexpr (DMA4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two DMA'd rows have landed
                 wave_sync();
+                if constexpr (REG) RegScale::scales(a.reg_live, ib - a.begin, wi, wu);  // (float)(1.0 * scale), PYX:306; wave-uniform
                 float score = 0.0f;
-                if (act && p == 0) score = row_dot<false>(urow, vrows, d, bu, bi, 1.0f, 1.0f);
+                if (act && p == 0) score = row_dot<REG>(urow, vrows, d, bu, bi, wu, wi);
                 pp = (double)(LPR == 64 ? read_lanef(score, 0) : __shfl(score, gbase, WAVE));
                 if (act) chosen = c_pos;  // (the "negative" of the shared update code: never read)
                 spec_cand = c_pos;
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                 cell_math(oWr[q][1], gN[gg][q], ADADELTA ? mN[gg][q] : 0.0f, 1.0, loss * u, h, ia,
                                           nWr[q][1], nGr[q][1], nMr[q][1], lr);
                             else nWr[q][1] = nGr[q][1] = nMr[q][1] = 0.0f;
-                            if (REG && c < a.m.d_real) lr_acc += lr;
+                            if (REG && !LGT && c < a.m.d_real) lr_acc += lr;
                             if constexpr (REG) __builtin_amdgcn_sched_barrier(0);
                             // (logistic: the user's row moves along the item's, PYX:519-533)
                             cell_math(Ur, gU[gg][q], ADADELTA ? mU[gg][q] : 0.0f, 1.0, loss * (LGT ? (double)Pc : df), h, ua,
@@ -738,8 +739,9 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         }
                         if constexpr (REG) {
                             // avg_learning_rate of PYX:640-646: the 3 (d + 1) cells of three identity rows
-                            if (lane < 3) lr_acc += lr;
-                            avg_lr[gg] = unif((float)(wave_sum(lr_acc) / (double)(3 * (a.m.d_real + 1))));
+                            // (logistic, PYX:527-530: the 2 (d + 1) cells of two identity rows)
+                            if (lane < 3 && !(LGT && lane == 1)) lr_acc += lr;
+                            avg_lr[gg] = unif((float)(wave_sum(lr_acc) / (double)((LGT ? 2 : 3) * (a.m.d_real + 1))));
                         }
                         // keep the arithmetic above one block: nothing of it may sink below a publication
 #pragma unroll
@@ -864,9 +866,13 @@ hipError_t launch_tile_variant(const FitArgs &a, int grid, size_t smem, hipStrea
 template <int LPR, int VEC, bool DMA4 = false>
 hipError_t launch_tile_bpr_variant(const FitArgs &a, int grid, size_t smem, hipStream_t st, int cus, int *grid_used, bool logistic)
 {
-    void (*kernel)(FitArgs) = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_BPR_ID>;
-    if (logistic) kernel = fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_LOGISTIC_ID>;
-    if (a.m.adadelta || a.item_alpha != 0.0 || a.user_alpha != 0.0) return hipErrorInvalidValue;
+    const bool reg = a.item_alpha != 0.0 || a.user_alpha != 0.0;
+    void (*kernel)(FitArgs);
+    if (logistic) kernel = reg ? fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, true, LFM_LOSS_LOGISTIC_ID>
+                               : fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_LOGISTIC_ID>;
+    else kernel = reg ? fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, true, LFM_LOSS_BPR_ID>
+                      : fit_warp_tile_kernel<LPR, VEC, false, false, DMA4, false, LFM_LOSS_BPR_ID>;
+    if (a.m.adadelta) return hipErrorInvalidValue;
     if (cus > 0) {
         const int per_cu = occupancy_cached(kernel, 256, smem);
         if (per_cu > 0) grid = std::min(grid, per_cu * cus);

@@ -10,7 +10,8 @@ Bars (those of the WARP tile kernels):
     itself -- the reference then updates ONE row twice in sequence;
   * frozen weights (sample_weight = 0) at full concurrency and with two workgroups walking hundreds of passes: negatives, draw
     counts, counters exact, no array moves -- the batches after the first (both speculative candidates were positives) included;
-  * outside its scope (adadelta, an L2 penalty, feature matrices) the row-stream kernel runs as before;
+  * outside its scope (adadelta, feature matrices) the row-stream kernel runs as before; with an L2 penalty the REG instantiations run:
+    one interaction per launch equals the sequential oracle incl. the two scales (the fold tests: tests/test_hip_round2.py);
   * full-concurrency training learns what the row-stream kernel learns;
   * logistic: one interaction per launch and conflict-free concurrent launches (every user and item once: no two interactions
     share a row) equal the sequential oracle; both labels, zero values, sample weights.
@@ -180,7 +181,7 @@ def test_conflict_free_concurrent_launch_matches_the_oracle(fast):
     np.testing.assert_allclose(a.user_biases[clean], b.user_biases[clean], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("what", ["adadelta", "l2", "item-features", "disabled"])
+@pytest.mark.parametrize("what", ["adadelta", "item-features", "disabled"])
 def test_outside_its_scope_the_row_stream_kernel_runs(fast, what, monkeypatch):
     from lightfm_amd.options import options
     coo = H.make_interactions(300, 200, 5000, seed=3)
@@ -190,7 +191,7 @@ def test_outside_its_scope_the_row_stream_kernel_runs(fast, what, monkeypatch):
     shuffle, seeds = H.epoch_inputs(coo, rng)
     if what == "disabled":
         monkeypatch.setenv("LIGHTFM_AMD_BPR_WIDE_TILE", "0")
-    _hip(fast, coo, st, shuffle, seeds, coo.data, item_f=item_f, alpha=1e-5 if what == "l2" else 0.0)
+    _hip(fast, coo, st, shuffle, seeds, coo.data, item_f=item_f)
     assert options.last_kernel_used == 2 and not options.last_plan_flags & BPR_TILE, (options.last_kernel_used, options.last_plan_flags)
 
 
@@ -294,3 +295,44 @@ def test_logistic_training_learns_like_the_row_stream_kernel(monkeypatch):
         acc[arm] = float(np.mean((p > 0) == (data.data > 0)))
     print("accuracy on the training labels", acc)
     assert acc["tile"] > 0.7 and abs(acc["tile"] - acc["row-stream"]) < 0.01, acc
+
+
+# ------------------------------------------------------------------------------------------------ lazy L2 regularisation
+
+@pytest.mark.parametrize("loss", ["bpr", "logistic"])
+@pytest.mark.parametrize("d", [16, 64, 100])
+def test_regularised_one_interaction_per_launch_matches_the_oracle(fast, loss, d):
+    """item_alpha, user_alpha != 0 (PYX:640-691): the REG instantiations -- scaled representations in the scoring and in the
+    gradients, cells multiplied by 1 + alpha lr, the scales advanced by the interaction's average learning rate (2 (d + 1) cells
+    for logistic, 3 (d + 1) for BPR).  Sequential launches: the arrays equal the oracle's (an epoch call ends with the
+    scales folded into them, PYX:775-781, 1176-1182)."""
+    from lightfm_amd.options import options
+    rng = np.random.RandomState(d)
+    base = H.make_interactions(40, 30, 400, seed=5)
+    alpha = 2e-3
+    st = _state(30, 40, d, 2)
+    a, b = st.copy(), st.copy()
+    Cm = fast.CSRMatrix
+    item_f, user_f = H.identity_features(30), H.identity_features(40)
+    options.set(launches_per_epoch=base.nnz, update_mode=0, log_samples=(loss == "bpr"))
+    for _ in range(2):
+        if loss == "bpr":
+            coo, w = base, base.data
+        else:
+            coo, w = _labels(base, rng)
+        shuffle, seeds = H.epoch_inputs(coo, rng)
+        fl = fast.FastLightFM(*a.arrays(), a.d, 0, a.lr, a.rho, a.eps, a.max_sampled)
+        if loss == "bpr":
+            fast.fit_bpr(Cm(item_f), Cm(user_f), Cm(H.positives_csr(coo)), coo.row, coo.col, coo.data, w, shuffle, fl, 0.05, alpha, 2 * alpha,
+                         len(seeds), H.FixedRandom(seeds))
+            o = oracle.Opts(len(shuffle), rng_mode=1, log=True)
+            oracle.fit_bpr(item_f, user_f, H.positives_csr(coo), coo.row, coo.col, coo.data, w, shuffle, b, alpha, 2 * alpha, seeds, o)
+            neg, sampled = options.last_logs
+            assert np.array_equal(neg, o.neg) and np.array_equal(sampled, o.sampled)
+        else:
+            fast.fit_logistic(Cm(item_f), Cm(user_f), coo.row, coo.col, coo.data, w, shuffle, fl, 0.05, alpha, 2 * alpha, 1)
+            o = oracle.Opts(len(shuffle), rng_mode=1, log=True)
+            oracle.fit_logistic(item_f, user_f, coo.row, coo.col, coo.data, w, shuffle, b, alpha, 2 * alpha, o)
+        assert options.last_kernel_used == 1 and options.last_plan_flags & (BPR_TILE if loss == "bpr" else LGT_TILE)
+        assert options.last_counters == o.counters
+    H.assert_states_equal(a, b, exact=False, rtol=5e-5, atol=5e-6)
