@@ -42,7 +42,7 @@ def _p10(model, train_csr, test_csr, feats):
                                 item_features=feats).mean())
 
 
-def _gap(loss, d, train, test, feats, epochs, n_seeds=N_SEEDS, **model_kw):
+def _gap(loss, d, train, test, feats, epochs, n_seeds=N_SEEDS, ref_threads=None, **model_kw):
     from concurrent.futures import ThreadPoolExecutor
     from lightfm_amd import LightFM, options
     from oracle import oracle
@@ -57,7 +57,7 @@ def _gap(loss, d, train, test, feats, epochs, n_seeds=N_SEEDS, **model_kw):
         # the reference's native epoch loop releases the GIL: REF_PARALLEL seeds train side by side
         # (16 OpenMP threads each) while the main thread drives the GPU
         r = RefLightFM(no_components=d, loss=loss, random_state=seed, **model_kw)
-        r.fit(train, item_features=feats, epochs=epochs, num_threads=_ref_threads())
+        r.fit(train, item_features=feats, epochs=epochs, num_threads=ref_threads or _ref_threads())
         return r
 
     seeds = list(range(1, n_seeds + 1))
@@ -169,6 +169,18 @@ def test_identity_bpr_and_logistic_lane_group_kernels(loss, d, bit):
     assert st["kernel_used"] == 1 and st["plan_flags"] & bit, st
     # (a fit takes a second here: 32 seeds per side resolve the gate -- standard error of the difference 0.0013; eight left it at 0.003)
     _gap(loss, d, fit_on, test, None, epochs=5, n_seeds=32 if d <= 16 else 8)  # (d = 64: +0.0003 +- 0.0003 over 16)
+
+
+@pytest.mark.timeout(900)
+def test_regularised_logistic_lands_on_the_one_thread_reference():
+    """item_alpha = user_alpha = 1e-5, logistic with explicit negatives (every interaction is a regularisation step, PYX:533-535).
+    The reference's threads advance lightfm.item_scale / user_scale with an unsynchronised read-modify-write, so its regularisation
+    WEAKENS with the thread count (precision@10 here: 0.126 at one thread, 0.138 at four, 0.148 at sixteen,
+    profiles/r06_regularised_identity.txt); this backend applies every step (device.hpp: RegScale) at any concurrency -- a
+    regularised model is gated against the reference's SEQUENTIAL result."""
+    train, test = _data(8656, 6686, 1_000_000)
+    _gap("logistic", 32, _with_explicit_negatives(train, test), test, None, epochs=5, n_seeds=6, ref_threads=1,
+         item_alpha=1e-5, user_alpha=1e-5)
 
 
 def _small_seeds(default):
