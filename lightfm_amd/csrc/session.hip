@@ -2465,7 +2465,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
     // adagrad, with or without an L2 penalty; BPR: two candidates per batch (LIGHTFM_AMD_BPR_WIDE_TILE=0: the row-stream kernel)
     const bool bpr_wide_env = [] { const char *e = getenv("LIGHTFM_AMD_BPR_WIDE_TILE"); return !e || atoi(e) != 0; }();  // (per epoch call: the tests switch arms inside one process)
     const bool lgt_tile = loss == LFM_LOSS_LOGISTIC;
-    const bool bpr_tile = (loss == LFM_LOSS_BPR || lgt_tile) && bpr_wide_env && s->d > 12 && s->d <= 256 && !s->adadelta &&
+    // (rows of up to 12 floats without an L2 penalty belong to the narrow lane-group kernels above)
+    const bool narrow_scope = s->d <= 12 && item_alpha == 0.0 && user_alpha == 0.0 && a.update_mode == 0;
+    const bool bpr_tile = (loss == LFM_LOSS_BPR || lgt_tile) && bpr_wide_env && !narrow_scope && s->d <= 256 && !s->adadelta &&
                           opts->feat_kernel == 0 && s->shards.n == 0 && s->n > 0 &&
                           (lgt_tile || (s->pos.indptr.p != nullptr && s->item_ids.p != nullptr));
     if (!serial && (loss == LFM_LOSS_WARP || bpr_tile) && opts->warp_kernel != 1 && s->itf.identity &&

@@ -116,19 +116,20 @@ def test_concurrent_conflict_free_launches_match_the_oracle(fast, d, per_launch)
     H.assert_states_within_ulps(a, b, ulps=4)
 
 
-def test_outside_its_scope_the_row_stream_kernel_runs(fast, monkeypatch):
+def test_outside_its_scope_other_kernels_run(fast, monkeypatch):
     from lightfm_amd.options import options
     rng = np.random.RandomState(2)
     coo, weight = _labels(H.make_interactions(60, 50, 500, seed=9), rng)
     shuffle, _ = H.epoch_inputs(coo, rng)
     # (d = 16: the tile kernel's logistic instantiation, csrc/warp_tile_bpr.hip -- plan_flags bit 11; tests/test_hip_bpr_tile.py)
-    for d, alpha, env, used in ((16, 0.0, None, 1), (10, 1e-6, None, 2), (10, 0.0, "0", 2)):
+    # (... and with an L2 penalty its regularised one, at the default width too)
+    for d, alpha, env, used in ((16, 0.0, None, 1), (10, 1e-6, None, 1), (10, 0.0, "0", 2)):
         if env is not None:
             monkeypatch.setenv("LIGHTFM_AMD_LOGISTIC_TILE", env)
         st = _state(50, 60, d, 1)
         _hip(fast, coo, st, shuffle, weight, item_alpha=alpha)
         assert options.last_kernel_used == used and not (options.last_plan_flags & 256), (d, alpha, env, options.last_plan_flags)
-        assert bool(options.last_plan_flags & 2048) == (d == 16)
+        assert bool(options.last_plan_flags & 2048) == (used == 1)
 
 
 def test_training_learns_like_the_row_stream_kernel(monkeypatch):

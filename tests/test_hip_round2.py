@@ -106,9 +106,9 @@ def test_excessive_regularisation_parallel_mode(loss, d):
     # a launch covers its slice of the epoch whatever alpha is (round 2 cut it after 56 interactions:
     # ~1 700 launches per epoch here); every loss runs its production kernel
     assert all(st["launches"] <= 100 for st in m._last_epoch_stats), [st["launches"] for st in m._last_epoch_stats]
-    # (identity BPR / logistic at d = 16: the tile kernel's regularised BPR / logistic instantiations, csrc/warp_tile_bpr.hip; at the
-    # default width the narrow lane-group kernels take unregularised models only: the row-stream kernels)
-    want = 1 if (loss == "warp" or (d == 16 and loss in ("bpr", "logistic"))) else 2
+    # (identity BPR / logistic: the tile kernel's regularised BPR / logistic instantiations, csrc/warp_tile_bpr.hip -- at the default
+    # width too, where the narrow lane-group kernels take unregularised models only)
+    want = 1 if loss in ("warp", "bpr", "logistic") else 2
     assert all(st["kernel_used"] == want for st in m._last_epoch_stats), [st["kernel_used"] for st in m._last_epoch_stats]
 
 
@@ -153,7 +153,7 @@ def test_frozen_weight_scale_folding_matches_the_oracle(loss, layout, d):
     import lightfm_amd._lightfm_fast as fast
     coo = H.make_interactions(300, 200, 8000, seed=4)
     # "tags": the row-stream kernels (feat_kernel.hpp, REG); "identity": the lane-group tile kernel (warp_tile_kernel.hpp, REG) for
-    # WARP and, at d = 16, for BPR / logistic (its LOSS instantiations); the row-stream kernels for BPR / logistic at d = 10
+    # WARP, BPR and logistic (its LOSS instantiations)
     item_f = H.tag_features(200, 12, 3, seed=1) if layout == "tags" else H.identity_features(200)
     user_f = H.identity_features(300)
     rng = np.random.RandomState(0)
@@ -181,8 +181,8 @@ def test_frozen_weight_scale_folding_matches_the_oracle(loss, layout, d):
                           alpha * 2, 1)
         oracle.fit_logistic(item_f, user_f, coo.row, coo.col, coo.data, zeros, shuffle, b, alpha, alpha * 2)
     assert not np.array_equal(b.item_embeddings, st.item_embeddings)  # the regularisation did act
-    # (identity: the tile kernel's REG instantiations -- WARP at every width, BPR / logistic above 12 floats per row)
-    assert options.last_kernel_used == ((1 if (loss == "warp" or d == 16) else 2) if layout == "identity" else 2)
+    # (identity: the tile kernel's REG instantiations of the three losses)
+    assert options.last_kernel_used == (1 if layout == "identity" else 2)
     H.assert_states_equal(a, b, exact=False, rtol=5e-4, atol=1e-9)
 
 
