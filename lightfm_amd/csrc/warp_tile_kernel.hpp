@@ -305,10 +305,20 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     }
     if (ib + stride + g < a.end) nxt = a.recs[guard_row(a, a.shuffle[ib + stride + g])];
     if (ib + 2 * stride + g < a.end) row2 = a.shuffle[ib + 2 * stride + g];
+    // BPR: this lane's candidate of the first batch (it depends on the position's stream alone) is looked up a pass ahead --
+    // item_ids[rand_r % no_examples] is a round trip of its own in front of the gather otherwise
+    int pf_item = 0;
+    if constexpr (BPR) {
+        if (ib + g < a.end) pf_item = a.item_ids[draw(lcgA * position_seed(base_seed, (uint64_t)(ib + g)) + lcgC) % n_examples];
+    }
 
     for (; ib < a.end; ib += stride) {
         const int64_t i = ib + g;
         const bool in = i < a.end;
+        int pf_next = 0;
+        if constexpr (BPR) {
+            if (i + stride < a.end) pf_next = a.item_ids[draw(lcgA * position_seed(base_seed, (uint64_t)(i + stride)) + lcgC) % n_examples];
+        }
         int n_lo = 0, n_hi = 0, row3 = 0;
         int4 rec2 = make_int4(0, 0, 0, 0);
         if constexpr (!LGT) {
@@ -443,7 +453,10 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                         if (j < p) s = lcg(s);
                 }
                 int myitem;
-                if constexpr (BPR) myitem = (p == 0 || !need) ? c_pos : a.item_ids[draw(s) % n_examples];  // PYX:1124-1125
+                if constexpr (BPR) {  // PYX:1124-1125 (the first batch's lookups were made a pass ago)
+                    if (done == 0) myitem = (p == 0 || !need) ? c_pos : pf_item;
+                    else myitem = (p == 0 || !need) ? c_pos : a.item_ids[draw(s) % n_examples];
+                }
                 else myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);                        // PYX:860-861
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
             // acknowledgements.
             asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(row3), "+v"(rec2.x), "+v"(rec2.y), "+v"(rec2.z),
                          "+v"(rec2.w));
+            if constexpr (BPR) asm volatile("" : "+v"(pf_next));
             double lossd = 0.0;
             if (act && chosen >= 0) {
                 if constexpr (BPR) {
@@ -825,6 +839,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
         c_hi = n_hi;
         nxt = rec2;
         row2 = row3;
+        if constexpr (BPR) pf_item = pf_next;
     }
     if constexpr (REG) RegScale::publish(a.reg_live, reg.p_i, reg.p_u, lane, (unsigned)gw);
 

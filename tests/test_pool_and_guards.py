@@ -46,8 +46,8 @@ def test_buffers_of_a_closed_session_are_reused_not_returned_to_the_runtime():
     LightFM(no_components=32, loss="warp", random_state=2).fit(coo, epochs=1)  # works again after a trim
 
 
-@pytest.mark.parametrize("family", ["tile", "generic", "row-stream", "serial"])
-def test_shuffle_entry_out_of_range_is_an_error_not_a_gpu_fault(family):
+@pytest.mark.parametrize("family", ["tile", "generic", "row-stream", "serial", "bpr-tile"])
+def test_shuffle_entry_out_of_range_is_an_error_not_a_gpu_fault(family, monkeypatch):
     """A shuffle slot that is not a permutation of [0, n) used to index the COO out of range (GPU memory fault,
     SIGABRT of the process).  Every kernel family now clamps the index and the epoch fails with LFM_ECORRUPT."""
     from lightfm_amd import LightFM, options
@@ -55,7 +55,9 @@ def test_shuffle_entry_out_of_range_is_an_error_not_a_gpu_fault(family):
     from lightfm_amd._native import HipBackendError
     nu, ni = 400, 300
     coo = H.make_interactions(nu, ni, 9000, seed=6)
-    loss = "bpr" if family == "row-stream" else "warp"
+    loss = "bpr" if family in ("row-stream", "bpr-tile") else "warp"
+    if family == "row-stream":  # (identity BPR runs the tile kernel's BPR instantiation otherwise: the fifth family)
+        monkeypatch.setenv("LIGHTFM_AMD_BPR_WIDE_TILE", "0")
     if family == "generic":
         options.set(warp_kernel=1, feat_kernel=1)
     if family == "serial":
@@ -73,7 +75,7 @@ def test_shuffle_entry_out_of_range_is_an_error_not_a_gpu_fault(family):
         o, _ = make_opts()
         with pytest.raises(HipBackendError, match="shuffle entry outside"):
             s.epoch(loss, 0.0, 0.0, 5, 10, seeds, o)
-        want = {"tile": 1, "generic": 0, "row-stream": 2, "serial": 0}[family]
+        want = {"tile": 1, "generic": 0, "row-stream": 2, "serial": 0, "bpr-tile": 1}[family]
         assert o.kernel_used == want
         # the session stays usable: a valid slot trains
         s.upload_shuffle(np.arange(n, dtype=np.int32))
