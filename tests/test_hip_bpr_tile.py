@@ -336,3 +336,18 @@ def test_regularised_one_interaction_per_launch_matches_the_oracle(fast, loss, d
         assert options.last_kernel_used == 1 and options.last_plan_flags & (BPR_TILE if loss == "bpr" else LGT_TILE)
         assert options.last_counters == o.counters
     H.assert_states_equal(a, b, exact=False, rtol=5e-5, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ randomised
+
+def test_randomised_sequential_parity_of_the_identity_kernels():
+    """tools/identity_fuzz.py: 150 random problems (1..40 users, 2..60 items, densities up to the whole catalogue, widths 1..256 incl.
+    padded ones, labels with zeros, sample weights, with and without an L2 penalty) through fit_bpr / fit_logistic, one interaction
+    per launch, against the oracle: all four identity kernels (lane-group d <= 12, tile instantiations above) take part."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "identity_fuzz.py"), "150", "11"], capture_output=True, text=True, timeout=600)
+    tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-2000:]
+    assert out.returncode == 0 and "150 cases, 0 failed" in tail, (out.stdout[-3000:], out.stderr[-2000:])
+    for bit in ("512", "1024", "256", "2048"):
+        assert ("1, %s)" % bit) in tail, tail
