@@ -2807,7 +2807,9 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                 const int rows_env = [] { const char *e = getenv("LIGHTFM_AMD_ROW_PAIRS"); return e ? atoi(e) : 2; }();
                 const bool want_rows = rows_env != 0 && tile[ng].narrow && (int64_t)std::max(s->n_feat[0], s->n_feat[1]) * 32 < (1ll << 30);
                 const bool want_rows_bias = want_rows && rows_env >= 2 && s->d <= 12;
-                const bool want_pairs = pairs_env && tile[ng].ahead && s->shards.n == 0 && !want_rows_bias;
+                // (... and the tile kernel's BPR / logistic instantiations: an update on every interaction)
+                // (not with the lazy regularisation: its folds at the launch boundaries work on the bias tables)
+                const bool want_pairs = pairs_env && (tile[ng].ahead || (bpr_tile && a.update_mode == 0 && !reg)) && s->shards.n == 0 && !want_rows_bias;
                 if (want_pairs && !s->pairs_live) LFM_TRY(bias_pairs_pack(s, s->stream));  // (before the streams fork: both see it)
                 if (!want_pairs && s->pairs_live) {  // (a launch of another kernel after steady-state launches: does not happen in the shipped plan)
                     if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));

@@ -270,6 +270,12 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
     // plain search, A/B of one box, profiles/r04_visit_b.txt), or -- debug bit 9 (512) -- for every candidate
     // together with its embedding row (no round trip of its own but ten times the requests: +3 % / +5 %)
     const bool bloom_early = (a.debug & 512) != 0;
+    // BPR / logistic (an update on EVERY interaction): the live bias cells as (b, bG) pairs of one line when the session packed them
+    // (FitArgs::bb, as for the steady-state kernel) -- a row's two cells are then loaded with one 8-byte load and published by ONE
+    // instruction (lanes 0-2 the W cells of the positive / negative / user, lanes 3-5 the accumulator cells next to them): three
+    // line operations per update instead of six.  Scoring reads b_read with its stride (the pair table, or a launch's snapshot).
+    const bool paired = (BPR || LGT) && a.bb[0] != nullptr && um == 0;
+    const size_t bstr_i = (BPR || LGT) ? (size_t)a.b_read_stride[0] : 1, bstr_u = (BPR || LGT) ? (size_t)a.b_read_stride[1] : 1;
 
     // rand_r's LCG is affine, so k steps collapse into one multiply-add.  For the first batch of
     // every pass lane p needs the stream after min(p, nb_first) more draws: it keeps
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 p4 = ldp<VEC>(gl ? Wi + (size_t)c_pos * d + VEC * p : Wi);
             }
             float bu = 0.0f;
-            if (act) bu = bu_tab[c_user];
+            if (act) bu = bu_tab[(size_t)c_user * bstr_u];
             uint32_t state = position_seed(base_seed, (uint64_t)i);  // stream of this position
             if constexpr (!DMA && !DMA4) {
                 if (gl) {
@@ -412,7 +418,13 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 const float *bWp = lane >= 2 ? a.m.b[1] : a.m.b[0];
                 const float *bGp = lane >= 2 ? a.m.bG[1] : a.m.bG[0];
                 const float *bMp = lane >= 2 ? a.m.bM[1] : a.m.bM[0];
-                if (!only_neg || lane == 1) {
+                if ((BPR || LGT) && paired) {
+                    if (!only_neg || lane == 1) {
+                        const float2 pr = *reinterpret_cast<const float2 *>(a.bb[lane >= 2 ? 1 : 0] + 2 * (size_t)brow);
+                        obW[gg] = pr.x;
+                        obG[gg] = pr.y;
+                    }
+                } else if (!only_neg || lane == 1) {
                     obW[gg] = bWp[brow];
                     obG[gg] = bGp[brow];
                     if (ADADELTA) obM[gg] = bMp[brow];
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
             if constexpr (LGT) {
                 // the pair's prediction (PYX:320-334) by lane 0 of the group; the accumulator rows of its update requested at once
                 float bi = 0.0f;
-                if (act && p == 0) bi = bi_tab[c_pos];
+                if (act && p == 0) bi = bi_tab[(size_t)c_pos * bstr_i];
                 if constexpr (DMA4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two DMA'd rows have landed
                 wave_sync();
                 if constexpr (REG) RegScale::scales(a.reg_live, ib - a.begin, wi, wu);  // (float)(1.0 * scale), PYX:306; wave-uniform
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                 else myitem = (p == 0) ? c_pos : fast_mod(draw(s), n_items, magic);                        // PYX:860-861
                 const bool rowlane = need && p <= nb && (p > 0 || done == 0);
                 float bi = 0.0f;
-                if (rowlane) bi = bi_tab[myitem];
+                if (rowlane) bi = bi_tab[(size_t)myitem * bstr_i];
                 // in_positives pre-filter (device.hpp: Bloom); early variant: the filter word of every candidate
                 // travels with its embedding row (its address needs only the user's row bounds, prefetched a pass ahead)
                 const uint32_t bh = Bloom::mix((uint32_t)myitem);
@@ -797,7 +809,17 @@ __global__ __launch_bounds__(256, (DMA4 && !ADADELTA && !TIMED) ? 3 : 2) void fi
                                 }
                             }
                         }
-                        if (lane < 3 && !(LGT && lane == 1)) {
+                        if ((BPR || LGT) && paired) {
+                            // lanes 0-2: the W cell's delta; lanes 3-5: the accumulator cell's, handed over from lanes 0-2
+                            const float dWb = __fsub_rn(bnW, obW[gg]), dGb = __fsub_rn(bnG, obG[gg]);
+                            const float dGs = __shfl(dGb, lane >= 3 ? lane - 3 : lane, WAVE);
+                            const int role = lane < 3 ? lane : lane - 3;
+                            if (lane < 6 && !(LGT && role == 1)) {
+                                const int brow = role == 0 ? pos : (role == 1 ? neg : user);
+                                const float dl = lane < 3 ? dWb : dGs;
+                                if (dl != 0.0f) atomicAdd(a.bb[role == 2 ? 1 : 0] + 2 * (size_t)brow + (lane < 3 ? 0 : 1), dl);
+                            }
+                        } else if (lane < 3 && !(LGT && lane == 1)) {
                             const int brow = lane == 0 ? pos : (lane == 1 ? neg : user);
                             float *bWp = lane == 2 ? a.m.b[1] : a.m.b[0];
                             float *bGp = lane == 2 ? a.m.bG[1] : a.m.bG[0];

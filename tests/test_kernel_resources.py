@@ -72,13 +72,13 @@ def test_tile_kernel_budgets(tmp_path):
 @pytest.mark.timeout(1200)
 def test_bpr_and_logistic_tile_kernel_budgets(tmp_path):
     """warp_tile_bpr.hip: <lanes per row, 4, TIMED, ADADELTA, DMA4, REG, loss id (2 = BPR, 0 = logistic)>.  The LDS-DMA variants keep the
-    third workgroup per CU; the BPR ones pay for it with a few spilled pointers (<= 32 / 64 bytes per lane without / with the lazy
+    third workgroup per CU; the BPR ones pay for it with a few spilled pointers (<= 48 / 80 bytes per lane without / with the lazy
     regularisation, reloaded in the update); every other instantiation runs without scratch at two or three workgroups per CU."""
     k = _usage("warp_tile_bpr.hip", tmp_path)
     assert len(k) == 16, sorted(k)
     for name, u in k.items():
         dma, reg, bpr = "ELb0ELb0ELb1ELb" in name, "ELb1ELi" in name.split("ELb0ELb0ELb", 1)[1], "ELi2EEE" in name
-        assert u["ScratchSize"] <= ((64 if reg else 32) if (dma and bpr) else 0), (name, u)
+        assert u["ScratchSize"] <= ((80 if reg else 48) if (dma and bpr) else 0), (name, u)
         assert u["Occupancy"] >= (3 if dma else 2), (name, u)
 
 
