@@ -2717,7 +2717,19 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // wavefront -- LIGHTFM_AMD_FEAT_LDS_KB, feat_kernels.hip -- must allow it)
             static const int feat_waves_env = [] { const char *e = getenv("LIGHTFM_AMD_FEAT_WAVES_PER_CU"); return e ? atoi(e) : 0; }();
             const int feat_waves = feat_waves_env > 0 ? feat_waves_env : fplan.waves_per_cu;
-            const size_t cu_blocks = use_feat ? (size_t)std::max(1, feat_waves / wpb) : 8;
+            size_t cu_blocks = use_feat ? (size_t)std::max(1, feat_waves / wpb) : 8;
+            // The tile kernel's LOGISTIC instantiation: two workgroups per CU (8 192 interactions in flight at four per pass) on ONE
+            // stream.  Logistic steps on every interaction with a loss that does not shrink as the model converges (noisy labels), so the
+            // popular rows take many stale full-size steps at once: at the FULL ML-20M shape (38 M labelled interactions, d = 64)
+            // precision@10 against the reference's 0.08008 is 0.0793 / 0.0786 / 0.0777 at 4 096 / 8 192 / 12 288+ in flight (547 / 946 /
+            // 1 300 M interactions/s) -- the third workgroup per CU (and the second stream, which doubles what is in flight whenever a
+            // grid is below the hardware's residency) buys rate outside the +-0.002 gate (profiles/r06_quality20m_identity_logistic.txt).
+            // BPR and WARP, whose losses vanish where the ranking is right, hold at full residency (+0.0002, -0.0002).
+            // (LIGHTFM_AMD_LGT_BLOCKS = 1..3: experiments)
+            if (ng && bpr_tile && lgt_tile) {
+                const int lgt_blocks = [] { const char *e = getenv("LIGHTFM_AMD_LGT_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 3 ? v : 2; }();
+                cu_blocks = std::min<size_t>(cu_blocks, (size_t)lgt_blocks);
+            }
             const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_blocks, (160 * 1024) / std::max<size_t>(lsmem, 1)));
             int max_grid = s->cus * blocks_per_cu;
             bool below_residency = allowed / (wpb * per_wave) < max_grid;
@@ -2776,7 +2788,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
             // (tile kernel only: its grid IS the hardware's residency.  The row-stream and generic kernels are launched
             // with fewer workgroups than would fit -- 8 wavefronts per CU publish fastest -- and two of their launches
             // side by side would double the interactions in flight: C3 fell from 42.5 to 37.6 M interactions/s)
-            if (two_streams && (ng || use_ltile) && !below_residency && !fixed_cap) {
+            if (two_streams && (ng || use_ltile) && !(bpr_tile && lgt_tile) && !below_residency && !fixed_cap) {
                 par = n_full++ & 1;
                 if (par) {
                     if (!s->stream2) {
