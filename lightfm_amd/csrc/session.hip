@@ -2367,10 +2367,12 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
         // only for a model that lives in the Infinity Cache -- on the C4 shard (3.3 GB of tables) the same switch LOST 5-10 %
         // (uncached partial-line stores to HBM; profiles/r05_visit_f.txt).  lfm_opts.debug bit 11 (2048) forces it for uncached
         // tables of any size and collision rate, bit 12 (4096) switches it off.
-        // And only for rows WIDER than one 128-byte line (d > 32): the cost of a lost user update grows as the rows shrink, and the
+        // And only for rows of more than 48 floats: the cost of a lost user update grows as the rows shrink, and the
         // gain vanishes -- at the full ML-20M shape, 16 seeds per arm (profiles/r06_narrow_quality20m.txt): d = 32 stores -0.0006
         // against atomics -0.0002 at the SAME kernel time (11.5 ms per epoch); d = 10 stores -0.0041 / -0.0032 / -0.0023 (24 576 /
         // 12 288 / 8 192 in flight) against atomics -0.0004 ... +0.0001; d = 64: -0.0002 for +15 % (profiles/r05_ustore_quality.txt).
+        // Kernel time, stores against atomics (profiles/r06_ustore_ab.txt): d = 48: +-1 % for WARP / BPR / logistic alike; d = 64: WARP
+        // +10 %, BPR +20 %, logistic +7 %; d = 128: BPR +24 %, logistic +30 % -- so the line is drawn above 48.
         size_t bytes = 0;
         for (int side = 0; side < 2; ++side)
             for (int kk = 0; kk < 6; ++kk) bytes += s->tab[side][kk].n * sizeof(float);
@@ -2387,7 +2389,7 @@ extern "C" int lfm_session_epoch(lfm_session *s, int32_t loss, int32_t slot, dou
                                 warp_tile_narrow_smem(s->d, 10, 10, (int64_t)s->itf.rows) != 0;
             static const int narrow_blocks = [] { const char *e = getenv("LIGHTFM_AMD_NARROW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
             const double per_cu = narrow ? 32.0 * narrow_blocks : 48.0;
-            rare_collisions = s->d_host > 32 && share * per_cu * (double)std::max(1, s->cus) <= 0.3;
+            rare_collisions = s->d_host > 48 && share * per_cu * (double)std::max(1, s->cus) <= 0.3;
         }
         base_user_store = a.user_store = (eligible && !(opts->debug & 4096) && (rare_collisions || (opts->debug & 2048))) ? 1 : 0;
     }
