@@ -351,3 +351,24 @@ def test_randomised_sequential_parity_of_the_identity_kernels():
     assert out.returncode == 0 and "150 cases, 0 failed" in tail, (out.stdout[-3000:], out.stderr[-2000:])
     for bit in ("512", "1024", "256", "2048"):
         assert ("1, %s)" % bit) in tail, tail
+
+
+@pytest.mark.parametrize("loss", ["warp", "bpr", "logistic"])
+def test_plain_store_user_rows_only_above_48_components(loss):
+    """lfm_opts.user_store (csrc/session.hip "rare_collisions"): the user row of an update is written by plain stores only for
+    no_components > 48 -- at or below that the switch buys no kernel time and a lost user update costs more
+    (profiles/r06_narrow_quality20m.txt, r06_ustore_ab.txt).  A problem the collision-rate rule itself accepts: 200 000
+    users with ~2.5 interactions each (12 288 in flight x sum c_u^2 / n^2 ~ 0.09 <= 0.3), tables in uncached memory."""
+    from lightfm_amd import LightFM
+    rng = np.random.RandomState(5)
+    nu, ni, n = 200_000, 5_000, 500_000
+    y = np.ones(n, np.float32) if loss != "logistic" else np.where(rng.rand(n) < 0.5, 1.0, -1.0).astype(np.float32)
+    coo = sp.coo_matrix((y, (rng.randint(0, nu, n).astype(np.int32), rng.randint(0, ni, n).astype(np.int32))), shape=(nu, ni), dtype=np.float32)
+    took = {}
+    for d in (32, 48, 64):
+        m = LightFM(loss=loss, no_components=d, random_state=3)
+        m.fit(coo, epochs=2)
+        st = m._last_epoch_stats[-1]
+        assert st["kernel_used"] == 1, (d, st)
+        took[d] = st["user_store"]
+    assert took == {32: 0, 48: 0, 64: 1}, took
