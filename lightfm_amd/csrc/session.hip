@@ -819,6 +819,14 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
     s->n_feat[1] = model->n_user_feat;
     s->d_host = model->d;
     s->d = (model->d + 3) / 4 * 4;
+    // Training sessions: rows of 17..63 floats are padded on to 32 / 48 / 64, so that no row straddles more 128-byte lines than
+    // its length needs (an 80-byte row at a 16-byte-aligned offset touches 1.6 lines on average, a 224-byte row 2.5, a 128- or
+    // 192- or 256-byte row at its own stride exactly 1 / 2 / 2): the kernels are bound by line operations, not bytes (WARP at
+    // the ML-20M shape: d = 20 12.2 ms per epoch against 11.8 at d = 32, d = 56 15.2 against 14.2 at d = 64,
+    // profiles/r06_width_sweep.txt).  LIGHTFM_AMD_ROW_ALIGN=0: multiples of 4 as before.  (Scoring sessions keep the
+    // multiple of 4: their cost is the K extent of the matrix sweep.)
+    static const bool row_align = [] { const char *e = getenv("LIGHTFM_AMD_ROW_ALIGN"); return !e || atoi(e) != 0; }();
+    if (!scoring && row_align && s->d > 16 && s->d < 64) s->d = s->d <= 32 ? 32 : s->d <= 48 ? 48 : 64;
     s->adadelta = model->adadelta;
     s->max_sampled = model->max_sampled;
     s->lr = model->lr;
