@@ -821,12 +821,18 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
     s->d = (model->d + 3) / 4 * 4;
     // Training sessions: rows of 17..63 floats are padded on to 32 / 48 / 64, so that no row straddles more 128-byte lines than
     // its length needs (an 80-byte row at a 16-byte-aligned offset touches 1.6 lines on average, a 224-byte row 2.5, a 128- or
-    // 192- or 256-byte row at its own stride exactly 1 / 2 / 2): the kernels are bound by line operations, not bytes (WARP at
-    // the ML-20M shape: d = 20 12.2 ms per epoch against 11.8 at d = 32, d = 56 15.2 against 14.2 at d = 64,
-    // profiles/r06_width_sweep.txt).  LIGHTFM_AMD_ROW_ALIGN=0: multiples of 4 as before.  (Scoring sessions keep the
-    // multiple of 4: their cost is the K extent of the matrix sweep.)
+    // 192- or 256-byte row at its own stride exactly 1 / 2 / 2): the tile kernels are bound by line operations, not bytes (WARP
+    // at the ML-20M shape: d = 20 12.4 -> 11.8 ms per epoch, d = 40 13.5 -> 13.3, d = 56 15.0 -> 13.8).  The row-stream kernels
+    // pay for every padded component's cell arithmetic: on the C3 shape (BPR + item tags) d = 50 -> 64 gains 22 %, but
+    // d = 20 -> 32 loses 2 % and d = 40 -> 48 8 % -- so rows of 49..63 floats always go to 64, rows of 17..47 only when BOTH
+    // feature matrices are identities (the models the tile kernels serve); profiles/r06_row_align.txt.
+    // LIGHTFM_AMD_ROW_ALIGN=0: multiples of 4 as before.  (Scoring sessions keep the multiple of 4: their cost is the K
+    // extent of the matrix sweep.)
     static const bool row_align = [] { const char *e = getenv("LIGHTFM_AMD_ROW_ALIGN"); return !e || atoi(e) != 0; }();
-    if (!scoring && row_align && s->d > 16 && s->d < 64) s->d = s->d <= 32 ? 32 : s->d <= 48 ? 48 : 64;
+    if (!scoring && row_align && s->d > 16 && s->d < 64) {
+        if (s->d > 48) s->d = 64;
+        else if (DevCsr::is_identity(item_features) && DevCsr::is_identity(user_features)) s->d = s->d <= 32 ? 32 : 48;
+    }
     s->adadelta = model->adadelta;
     s->max_sampled = model->max_sampled;
     s->lr = model->lr;
