@@ -826,12 +826,15 @@ static int create_session(lfm_session **out, int device, const lfm_model *model,
     // pay for every padded component's cell arithmetic: on the C3 shape (BPR + item tags) d = 50 -> 64 gains 22 %, but
     // d = 20 -> 32 loses 2 % and d = 40 -> 48 8 % -- so rows of 49..63 floats always go to 64, rows of 17..47 only when BOTH
     // feature matrices are identities (the models the tile kernels serve); profiles/r06_row_align.txt.
-    // LIGHTFM_AMD_ROW_ALIGN=0: multiples of 4 as before.  (Scoring sessions keep the multiple of 4: their cost is the K
-    // extent of the matrix sweep.)
-    static const bool row_align = [] { const char *e = getenv("LIGHTFM_AMD_ROW_ALIGN"); return !e || atoi(e) != 0; }();
-    if (!scoring && row_align && s->d > 16 && s->d < 64) {
+    // LIGHTFM_AMD_ROW_ALIGN (read per session): 0 = multiples of 4 as before; 2 = the 49..63 rule only -- what
+    // lightfm_amd/distributed.py asks for, because the ranks of a job exchange item rows and must agree on their stride,
+    // while a rank's slice of the user feature matrix may look like an identity on one rank and not on another.  (Scoring
+    // sessions keep the multiple of 4: their cost is the K extent of the matrix sweep.)
+    const char *row_align_env = getenv("LIGHTFM_AMD_ROW_ALIGN");
+    const int row_align = row_align_env ? atoi(row_align_env) : 1;
+    if (!scoring && row_align != 0 && s->d > 16 && s->d < 64) {
         if (s->d > 48) s->d = 64;
-        else if (DevCsr::is_identity(item_features) && DevCsr::is_identity(user_features)) s->d = s->d <= 32 ? 32 : 48;
+        else if (row_align == 1 && DevCsr::is_identity(item_features) && DevCsr::is_identity(user_features)) s->d = s->d <= 32 ? 32 : 48;
     }
     s->adadelta = model->adadelta;
     s->max_sampled = model->max_sampled;

@@ -25,6 +25,7 @@ the RCCL unique id and the initial tables, and gathering the user rows at the en
 path never goes through it.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -281,7 +282,19 @@ class DistributedFit(object):
         else:
             rank_user_f = sp.identity(b1 - b0, dtype=np.float32, format="csr")
         self.item_features, self.user_features = item_f, rank_user_f
-        self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(rank_user_f), device=device)
+        # The ranks exchange item rows: they must agree on the device row stride, which a one-GPU session pads by what ITS
+        # feature matrices look like (csrc/session.hip, LIGHTFM_AMD_ROW_ALIGN) -- a rank's slice of the user features can
+        # look like an identity on one rank only.  So a rank's session takes the width-only rule (mode 2) unless padding is off.
+        align = os.environ.get("LIGHTFM_AMD_ROW_ALIGN")
+        if align != "0":
+            os.environ["LIGHTFM_AMD_ROW_ALIGN"] = "2"
+        try:
+            self.session = _Session(self.struct, CSRMatrix(item_f), CSRMatrix(rank_user_f), device=device)
+        finally:
+            if align is None:
+                os.environ.pop("LIGHTFM_AMD_ROW_ALIGN", None)
+            else:
+                os.environ["LIGHTFM_AMD_ROW_ALIGN"] = align
         # LFM:381-386: without a sample_weight matrix every interaction weighs 1 -- the VALUES are Y (logistic's labels; a
         # positive wherever > 0), not weights
         weights = shard.data if model._scan(shard.data)[0] else np.ones_like(shard.data)
