@@ -1,6 +1,8 @@
 """Host-side logic of lightfm_amd.LightFM that runs before (or without) the device: argument
 checks, input coercion, initialisation order, error types -- the reference's contract
 (lightfm/lightfm.py, "LFM"; tests/test_api.py, "T_API").  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -359,3 +361,35 @@ def test_native_input_scan_matches_numpy():
         assert N.host_scan(a) == (False, False)
     a[:] = 3e38   # finite values whose float32 sum is not (the reference tests isfinite(sum))
     assert N.host_scan(a) == (False, False)
+
+
+@pytest.mark.parametrize("preset", [None, "0", "1"])
+def test_distributed_fit_asks_for_the_rank_independent_row_stride(monkeypatch, preset):
+    """csrc/session.hip pads a training session's rows by what ITS feature matrices look like (LIGHTFM_AMD_ROW_ALIGN = 1);
+    the ranks of a job exchange item rows, so DistributedFit creates its session under mode 2 (the width-only rule) --
+    unless padding is switched off -- and leaves the variable as it found it, also when the session cannot be created."""
+    import scipy.sparse as sp
+    import lightfm_amd.lightfm as L
+    from lightfm_amd import LightFM
+    from lightfm_amd.distributed import DistributedFit
+    seen = []
+
+    class Stop(Exception):
+        pass
+
+    class FakeSession(object):
+        def __init__(self, *args, **kw):
+            seen.append(os.environ.get("LIGHTFM_AMD_ROW_ALIGN"))
+            raise Stop()
+
+    monkeypatch.setattr(L, "_Session", FakeSession)
+    if preset is None:
+        monkeypatch.delenv("LIGHTFM_AMD_ROW_ALIGN", raising=False)
+    else:
+        monkeypatch.setenv("LIGHTFM_AMD_ROW_ALIGN", preset)
+    rng = np.random.RandomState(0)
+    coo = sp.coo_matrix((np.ones(200, np.float32), (rng.randint(0, 50, 200), rng.randint(0, 30, 200))), shape=(50, 30))
+    with pytest.raises(Stop):
+        DistributedFit(LightFM(no_components=20, loss="warp", random_state=1), coo, 0, 1)
+    assert seen == ["0" if preset == "0" else "2"]
+    assert os.environ.get("LIGHTFM_AMD_ROW_ALIGN") == preset
